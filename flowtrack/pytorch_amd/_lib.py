@@ -1,0 +1,121 @@
+"""ctypes binding of libflowtrack_hip.so (the C ABI declared in include/flowtrack_hip.h).
+
+This is the Python-side FFI stub that takes the place of the reference's cffi `_ext` modules
+(lib/flownet/networks/*/_ext/*/__init__.py) and of the torch.nn -> cuDNN dispatch under
+lib/pose/models.  There is no CPU or PyTorch fallback: if the shared library is missing or a call
+returns a non-zero status, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libflowtrack_hip.so")
+
+FT_OK = 0
+FT_F16, FT_F32 = 0, 1
+FT_ACT_NONE, FT_ACT_RELU, FT_ACT_LEAKY = 0, 1, 2
+FT_LAYOUT_NHWC, FT_LAYOUT_NCHW_F32 = 0, 1
+FT_RGB_MEAN_SPLITS = 64
+
+
+class FlowtrackHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `ft_conv_desc` (include/flowtrack_hip.h)."""
+
+    _fields_ = [
+        ("dtype", c_int), ("N", c_int), ("Hi", c_int), ("Wi", c_int), ("Cin", c_int),
+        ("x_cstride", c_int), ("x_coff", c_int), ("Cout", c_int), ("kh", c_int), ("kw", c_int),
+        ("stride", c_int), ("pad", c_int), ("transposed", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("y_cstride", c_int), ("y_coff", c_int), ("out_layout", c_int), ("has_residual", c_int),
+        ("res_cstride", c_int), ("res_coff", c_int), ("act", c_int), ("slope", c_float),
+    ]
+
+
+_PROTOTYPES = {
+    # name: (restype, argtypes)
+    "ft_version": (c_int, []),
+    "ft_status_string": (c_char_p, [c_int]),
+    "ft_last_hip_error": (c_char_p, []),
+    "ft_device_info": (c_int, [c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_uint64)]),
+    "ft_graph_begin_capture": (c_int, [c_void_p]),
+    "ft_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "ft_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "ft_graph_destroy": (c_int, [c_void_p]),
+    "ft_event_create": (c_int, [POINTER(c_void_p)]),
+    "ft_event_record": (c_int, [c_void_p, c_void_p]),
+    "ft_event_synchronize": (c_int, [c_void_p]),
+    "ft_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "ft_event_destroy": (c_int, [c_void_p]),
+    "ft_stream_synchronize": (c_int, [c_void_p]),
+    "ft_conv_pack_geometry": (c_int, [POINTER(ConvDesc)] + [POINTER(c_int)] * 5),
+    "ft_conv_tap_source": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "ft_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "ft_conv_flops": (c_double, [POINTER(ConvDesc)]),
+    "ft_pack_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_unpack_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
+    "ft_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_heatmap_max_preds": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "ft_flow_rgb_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ft_flow_pack_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
+    "ft_upsample_bilinear4x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ft_correlation_out_shape": (c_int, [c_int] * 8 + [POINTER(c_int)] * 3),
+    "ft_correlation_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "ft_correlation_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_int, c_void_p]),
+    "ft_resample2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_channelnorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def load():
+    """Load libflowtrack_hip.so once; raises FlowtrackHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlowtrackHipError(
+            f"{LIB_PATH} is missing: build it with `python -m flowtrack.pytorch_amd.build` "
+            "(there is no CPU / PyTorch fallback for the HIP path)")
+    # torch must be imported first so that the process has ONE HIP runtime: the library's
+    # DT_NEEDED libamdhip64.so.7 then resolves to the copy torch already loaded.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != FT_OK:
+        lib = load()
+        msg = lib.ft_status_string(status).decode()
+        detail = lib.ft_last_hip_error().decode()
+        raise FlowtrackHipError(f"{what or 'libflowtrack_hip'}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+
+    if torch_dtype == torch.float16:
+        return FT_F16
+    if torch_dtype == torch.float32:
+        return FT_F32
+    raise FlowtrackHipError(f"unsupported dtype {torch_dtype}; the HIP path computes in fp16 or fp32")

@@ -1,0 +1,324 @@
+// HBM-bound helper kernels around the implicit-GEMM convs: layout packing, 3x3/s2 max-pool,
+// heatmap arg-max (max_preds / final_preds nudge), FlowNet input normalisation, x4 bilinear
+// upsampling.  All are one-pass, vectorised to 16 bytes per lane on the NHWC side.
+#include "ft_common.h"
+
+namespace ft {
+
+template <typename T> struct Vec8;  // 8 channels of T
+template <> struct Vec8<half_t> { typedef half8_t type; };
+template <> struct Vec8<float> { struct type { float4_t lo, hi; }; };
+
+template <typename T> __device__ __forceinline__ void store8(T* dst, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<half_t>(half_t* dst, const float (&v)[8]) {
+  half8_t h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (half_t)v[i];
+  *reinterpret_cast<half8_t*>(dst) = h;
+}
+template <> __device__ __forceinline__ void store8<float>(float* dst, const float (&v)[8]) {
+  float4_t a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  reinterpret_cast<float4_t*>(dst)[0] = a;
+  reinterpret_cast<float4_t*>(dst)[1] = b;
+}
+template <typename T> __device__ __forceinline__ void load8(const T* src, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* src, float (&v)[8]) {
+  half8_t h = *reinterpret_cast<const half8_t*>(src);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* src, float (&v)[8]) {
+  float4_t a = reinterpret_cast<const float4_t*>(src)[0], b = reinterpret_cast<const float4_t*>(src)[1];
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// ---- NCHW fp32 -> NHWC T (channel-padded) ----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                                int C, size_t HW, size_t total, int cpad) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, pix = i - n * HW;
+    const float* xp = x + n * C * HW + pix;
+    T* yp = y + i * cpad;
+    for (int c0 = 0; c0 < cpad; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? xp[(size_t)(c0 + e) * HW] : 0.f;
+      store8<T>(yp + c0, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y,
+                                                                  int C, size_t HW, size_t total, int cstride, int coff) {
+  // one thread per output element, lanes along the pixel axis (coalesced NCHW writes)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i % HW;
+    const size_t nc = i / HW;
+    const size_t n = nc / C, c = nc - n * C;
+    y[i] = (float)x[(n * HW + pix) * cstride + coff + c];
+  }
+}
+
+// ---- MaxPool2d(3, 2, 1), NHWC ----------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int Hi, int Wi,
+                                                           int Ho, int Wo, int C8, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    size_t t = i / C8;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const size_t n = t / Ho;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)Hi) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)Wi) continue;
+        float v[8];
+        load8<T>(x + (((n * Hi + iy) * Wi + ix) * (size_t)C8 + c8) * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    store8<T>(y + i * 8, m);
+  }
+}
+
+// ---- max_preds (+ final_preds nudge): one workgroup per (n,k) map ------------------------------
+__global__ __launch_bounds__(256) void heatmap_max_preds_kernel(const float* __restrict__ hm, int H, int W, int adjust,
+                                                                int32_t* __restrict__ idx_out, float* __restrict__ score_out,
+                                                                float* __restrict__ coords_out) {
+  const int map = blockIdx.x;
+  const int HW = H * W;
+  const float* p = hm + (size_t)map * HW;
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float v = p[i];
+    if (v > best) { best = v; bidx = i; }  // strided ascending i: keeps the first occurrence per thread
+  }
+  // wave64 butterfly: larger value wins, ties go to the smaller index (first occurrence, row-major)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bidx, off);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_v[wave] = best; s_i[wave] = bidx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_v[w] > best || (s_v[w] == best && s_i[w] < bidx)) { best = s_v[w]; bidx = s_i[w]; }
+    if (bidx == 0x7fffffff) bidx = 0;  // all-NaN / empty map
+    idx_out[map] = bidx;
+    score_out[map] = best;
+    float cx = 0.f, cy = 0.f;
+    if (best > 0.f) {  // coords.mul(mask), evaluation.py:17-19
+      const int x = bidx % W, y = bidx / W;
+      cx = (float)x;
+      cy = (float)y;
+      if (adjust && x > 0 && x < W - 1 && y > 0 && y < H - 1) {  // evaluation.py:31-33
+        const float dx = p[y * W + x + 1] - p[y * W + x - 1];
+        const float dy = p[(y + 1) * W + x] - p[(y - 1) * W + x];
+        cx += dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f);
+        cy += dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f);
+      }
+    }
+    coords_out[2 * map] = cx;
+    coords_out[2 * map + 1] = cy;
+  }
+}
+
+// ---- FlowNet2* rgb mean: stage 1 partial sums, stage 2 finish -----------------------------------
+__global__ __launch_bounds__(256) void rgb_partial_sum_kernel(const float* __restrict__ x, size_t L,
+                                                              float* __restrict__ partial) {
+  const int bc = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const size_t per = (L + nsplit - 1) / nsplit;
+  const size_t lo = (size_t)split * per;
+  const size_t hi = lo + per < L ? lo + per : L;
+  const float* p = x + (size_t)bc * L;
+  float s = 0.f;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  __shared__ float sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[bc * nsplit + split] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+__global__ __launch_bounds__(64) void rgb_mean_finish_kernel(const float* __restrict__ partial, int nsplit, float inv_L,
+                                                             float* __restrict__ mean) {
+  const int bc = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nsplit; i += 64) s += partial[bc * nsplit + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (threadIdx.x == 0) mean[bc] = s * inv_L;
+}
+
+// ---- (x - mean) / rgb_max and NHWC packing of the frame pair ------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __restrict__ in, const float* __restrict__ mean,
+                                                             float rgb_max, T* __restrict__ y, int B, size_t HW,
+                                                             size_t total, int mode) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    float v[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float m = mean[b * 3 + c];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) v[f][c] = (in[((b * 3 + c) * 2 + f) * HW + pix] - m) / rgb_max;
+    }
+    if (mode == 0) {
+      const float o[8] = {v[0][0], v[0][1], v[0][2], v[1][0], v[1][1], v[1][2], 0.f, 0.f};
+      store8<T>(y + i * 8, o);
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float o[8] = {v[f][0], v[f][1], v[f][2], 0.f, 0.f, 0.f, 0.f, 0.f};
+        store8<T>(y + (((size_t)f * B + b) * HW + pix) * 8, o);
+      }
+    }
+  }
+}
+
+// ---- nn.Upsample(scale_factor=4, mode='bilinear'), align_corners=False, times `mul` -------------
+__global__ __launch_bounds__(256) void upsample_bilinear4x_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int h, int w, size_t total, float mul) {
+  const int H = 4 * h, W = 4 * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % W);
+    const size_t t = i / W;
+    const int oy = (int)(t % H);
+    const size_t nc = t / H;
+    float sy = ((float)oy + 0.5f) * 0.25f - 0.5f;
+    float sx = ((float)ox + 0.5f) * 0.25f - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = x + nc * (size_t)h * w;
+    const float v00 = p[y0 * w + x0] * mul, v01 = p[y0 * w + x1] * mul;
+    const float v10 = p[y1 * w + x0] * mul, v11 = p[y1 * w + x1] * mul;
+    y[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
+static inline int grid_for(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace ft
+
+using namespace ft;
+
+extern "C" int ft_pack_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int cpad, int dtype,
+                                    ft_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cpad < C || cpad % 8) return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const size_t HW = (size_t)H * W, total = (size_t)N * HW;
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,
+                       static_cast<half_t*>(y), C, HW, total, cpad);
+  else
+    hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,
+                       static_cast<float*>(y), C, HW, total, cpad);
+  FT_LAUNCH_CHECK("pack_nchw_to_nhwc_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_unpack_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int x_cstride, int x_coff,
+                                      int dtype, ft_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || x_coff < 0 || x_cstride < x_coff + C) return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const size_t HW = (size_t)H * W, total = (size_t)N * C * HW;
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(unpack_nhwc_to_nchw_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const half_t*>(x), y, C, HW, total, x_cstride, x_coff);
+  else
+    hipLaunchKernelGGL(unpack_nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(x), y, C, HW, total, x_cstride, x_coff);
+  FT_LAUNCH_CHECK("unpack_nhwc_to_nchw_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_maxpool3x3s2_fwd(const void* x, void* y, int N, int Hi, int Wi, int C, int dtype, ft_stream_t stream) {
+  if (!x || !y || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || C % 8) return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 8);
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const half_t*>(x), static_cast<half_t*>(y), Hi, Wi, Ho, Wo, C / 8, total);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(x), static_cast<float*>(y), Hi, Wi, Ho, Wo, C / 8, total);
+  FT_LAUNCH_CHECK("maxpool3x3s2_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_heatmap_max_preds(const float* heatmaps, int N, int K, int H, int W, int adjust_coords, int32_t* idx,
+                                    float* score, float* coords, ft_stream_t stream) {
+  if (!heatmaps || !idx || !score || !coords || N <= 0 || K <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(heatmap_max_preds_kernel, dim3(N * K), dim3(256), 0, as_stream(stream), heatmaps, H, W,
+                     adjust_coords, idx, score, coords);
+  FT_LAUNCH_CHECK("heatmap_max_preds_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_flow_rgb_mean(const float* inputs, int B, int H, int W, float* partial, float* mean,
+                                ft_stream_t stream) {
+  if (!inputs || !partial || !mean || B <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
+  const size_t L = (size_t)2 * H * W;
+  hipLaunchKernelGGL(rgb_partial_sum_kernel, dim3(B * 3, FT_RGB_MEAN_SPLITS), dim3(256), 0, as_stream(stream), inputs, L,
+                     partial);
+  FT_LAUNCH_CHECK("rgb_partial_sum_kernel");
+  hipLaunchKernelGGL(rgb_mean_finish_kernel, dim3(B * 3), dim3(64), 0, as_stream(stream), partial, FT_RGB_MEAN_SPLITS,
+                     1.0f / (float)L, mean);
+  FT_LAUNCH_CHECK("rgb_mean_finish_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max, void* y, int B, int H, int W,
+                                 int mode, int dtype, ft_stream_t stream) {
+  if (!inputs || !mean || !y || B <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1) || rgb_max == 0.f)
+    return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(flow_pack_pair_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,
+                       rgb_max, static_cast<half_t*>(y), B, HW, total, mode);
+  else
+    hipLaunchKernelGGL(flow_pack_pair_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,
+                       rgb_max, static_cast<float*>(y), B, HW, total, mode);
+  FT_LAUNCH_CHECK("flow_pack_pair_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_upsample_bilinear4x(const float* x, float* y, int N, int C, int h, int w, float mul,
+                                      ft_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0) return FT_ERR_INVALID_ARG;
+  const size_t total = (size_t)N * C * 16 * h * w;
+  hipLaunchKernelGGL(upsample_bilinear4x_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, h, w,
+                     total, mul);
+  FT_LAUNCH_CHECK("upsample_bilinear4x_kernel");
+  return FT_OK;
+}

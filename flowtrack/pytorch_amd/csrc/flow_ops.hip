@@ -1,0 +1,382 @@
+// FlowNet2's three custom operators, forward only (the reference ships them as CUDA-only cffi
+// extensions; its CPU entry points are empty stubs, correlation_package/src/correlation.c:3-33):
+//   Correlation   correlation_package/src/correlation_cuda_kernel.cu:10-106
+//   Resample2d    resample2d_package/src/Resample2d_kernel.cu:20-66
+//   ChannelNorm   channelnorm_package/src/ChannelNorm_kernel.cu:19-51
+// plus the fused warp/diff/norm/concat stage that sits between stacked FlowNets (models.py:396-403).
+// The reference's NCHW->padded-NHWC copy kernels (`channels_first`) do not exist here: padding is a
+// bounds test, and the in-network form reads the NHWC activations the conv stack already produces.
+#include "ft_common.h"
+
+namespace ft {
+
+// ---- Correlation, reference-compatible API: NCHW fp32, any parameters ---------------------------
+// One thread per output element, lanes along x so both feature reads are coalesced; the sum runs over
+// (j, i, c) of the kernel window exactly as correlation_cuda_kernel.cu:75-88 (fp32 accumulation,
+// different association order: within fp32 round-off, tolerance stated in the tests).
+__global__ __launch_bounds__(256) void correlation_nchw_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
+                                                               float* __restrict__ out, int C, int H, int W, int oc, int oh,
+                                                               int ow, int pad, int ksize, int max_disp, int s1, int s2,
+                                                               size_t total) {
+  const int krad = (ksize - 1) / 2;
+  const int drad = max_disp / s2;
+  const int D = 2 * drad + 1;
+  const float nelems = (float)(ksize * ksize * C);
+  const size_t HW = (size_t)H * W;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % ow);
+    size_t t = idx / ow;
+    const int y = (int)(t % oh);
+    t /= oh;
+    const int tc = (int)(t % oc);
+    const size_t n = t / oc;
+    const int tj = tc / D - drad, ti = tc % D - drad;
+    // coordinates in the zero-padded frame of the reference, shifted back by pad
+    const int y1 = y * s1 + max_disp + krad - pad, x1 = x * s1 + max_disp + krad - pad;
+    const int y2 = y1 + tj * s2, x2 = x1 + ti * s2;
+    const float* p1 = in1 + n * C * HW;
+    const float* p2 = in2 + n * C * HW;
+    float acc = 0.f;
+    for (int j = -krad; j <= krad; ++j) {
+      const int ya = y1 + j, yb = y2 + j;
+      if ((unsigned)ya >= (unsigned)H || (unsigned)yb >= (unsigned)H) continue;  // zero padding
+      for (int i = -krad; i <= krad; ++i) {
+        const int xa = x1 + i, xb = x2 + i;
+        if ((unsigned)xa >= (unsigned)W || (unsigned)xb >= (unsigned)W) continue;
+        const float* a = p1 + (size_t)ya * W + xa;
+        const float* b = p2 + (size_t)yb * W + xb;
+        for (int c = 0; c < C; ++c) acc += a[c * HW] * b[c * HW];
+      }
+    }
+    out[idx] = acc / nelems;
+  }
+}
+
+// ---- Correlation, in-network form: NHWC features, kernel_size 1, stride1 1, pad = max_disp --------
+// out[pix, coff + (dy+r)*D + (dx+r)] = act( 1/C * sum_c f1[pix, c] * f2[pix + s2*(dy,dx), c] )
+// Workgroup = TX consecutive pixels of one image row.  The f1 row tile stays in LDS for the whole
+// workgroup; for each of the D displaced rows the (TX + 2*max_disp)-pixel f2 window is staged once in
+// LDS and reused by all D horizontal displacements (the reference re-reads both operands from global
+// for every displacement with one 32-thread block per pixel, correlation_cuda_kernel.cu:69-101).
+// Thread = (pixel x, group of GX horizontal displacements): the f1 chunk is loaded once per GX dots.
+// Results collect in an LDS tile and leave as contiguous D*D-channel runs per pixel.
+template <typename T, int TX, int GX, int NT>
+__global__ __launch_bounds__(NT) void correlation_nhwc_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
+                                                               T* __restrict__ y, int C, int H, int W, int max_disp,
+                                                               int s2, int f_cstride, int y_cstride, int y_coff, int act,
+                                                               float slope) {
+  constexpr int VEC = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int drad = max_disp / s2;
+  const int D = 2 * drad + 1;
+  const int DD = D * D;
+  const int win = TX + 2 * max_disp;           // f2 pixels per displaced row
+  const int pstride = C * (int)sizeof(T) + 16;  // LDS bytes per pixel (+16: bank spread)
+  char* s_f1 = smem;
+  char* s_f2 = s_f1 + TX * pstride;
+  float* s_out = reinterpret_cast<float*>(s_f2 + win * pstride);  // [TX][DD]
+
+  const int tilesx = (W + TX - 1) / TX;
+  const int bx = blockIdx.x % tilesx;
+  const int yrow = blockIdx.x / tilesx;
+  const int n = blockIdx.y;
+  const int x0 = bx * TX;
+  const int cvecs = C / VEC;
+  const T* f1row = f1 + ((size_t)n * H + yrow) * W * f_cstride;
+
+  for (int i = threadIdx.x; i < TX * cvecs; i += NT) {
+    const int px = i / cvecs, cv = i - px * cvecs;
+    uint4_t v = {0u, 0u, 0u, 0u};
+    if (x0 + px < W) v = *reinterpret_cast<const uint4_t*>(f1row + (size_t)(x0 + px) * f_cstride + cv * VEC);
+    *reinterpret_cast<uint4_t*>(s_f1 + px * pstride + cv * 16) = v;
+  }
+
+  const int ngx = (D + GX - 1) / GX;  // displacement groups per pixel
+  const int nwork = TX * ngx;
+  const float inv_c = 1.0f / (float)C;
+
+  for (int dyi = 0; dyi < D; ++dyi) {
+    const int y2 = yrow + (dyi - drad) * s2;
+    const bool row_ok = (unsigned)y2 < (unsigned)H;
+    __syncthreads();  // previous row's readers are done with s_f2 (and s_f1 is written, first time)
+    if (row_ok) {
+      const T* f2row = f2 + ((size_t)n * H + y2) * W * f_cstride;
+      for (int i = threadIdx.x; i < win * cvecs; i += NT) {
+        const int px = i / cvecs, cv = i - px * cvecs;
+        const int x2 = x0 - max_disp + px;
+        uint4_t v = {0u, 0u, 0u, 0u};
+        if ((unsigned)x2 < (unsigned)W) v = *reinterpret_cast<const uint4_t*>(f2row + (size_t)x2 * f_cstride + cv * VEC);
+        *reinterpret_cast<uint4_t*>(s_f2 + px * pstride + cv * 16) = v;
+      }
+    }
+    __syncthreads();
+    for (int wk = threadIdx.x; wk < nwork; wk += NT) {
+      const int px = wk % TX, g = wk / TX;
+      float acc[GX];
+#pragma unroll
+      for (int e = 0; e < GX; ++e) acc[e] = 0.f;
+      if (row_ok) {
+        const char* a = s_f1 + px * pstride;
+        for (int cv = 0; cv < cvecs; ++cv) {
+          const uint4_t av = *reinterpret_cast<const uint4_t*>(a + cv * 16);
+#pragma unroll
+          for (int e = 0; e < GX; ++e) {
+            const int dxi = g * GX + e;
+            if (dxi < D) {
+              const int p2 = px + max_disp + (dxi - drad) * s2;  // index inside the staged window
+              const uint4_t bv = *reinterpret_cast<const uint4_t*>(s_f2 + p2 * pstride + cv * 16);
+              if constexpr (sizeof(T) == 2) {
+                const half8_t ah = __builtin_bit_cast(half8_t, av), bh = __builtin_bit_cast(half8_t, bv);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[e] += (float)ah[q] * (float)bh[q];
+              } else {
+                const float4_t af = __builtin_bit_cast(float4_t, av), bf = __builtin_bit_cast(float4_t, bv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[e] += af[q] * bf[q];
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < GX; ++e) {
+        const int dxi = g * GX + e;
+        if (dxi < D) {
+          float v = acc[e] * inv_c;
+          if (act == FT_ACT_RELU) v = v > 0.f ? v : 0.f;
+          else if (act == FT_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+          s_out[px * DD + dyi * D + dxi] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TX * DD; i += NT) {
+    const int px = i / DD, ch = i - px * DD;
+    if (x0 + px < W)
+      y[(((size_t)n * H + yrow) * W + x0 + px) * y_cstride + y_coff + ch] = (T)s_out[i];
+  }
+}
+
+// ---- Resample2d: backward bilinear warp with border clamp -----------------------------------------
+// Weights from the UNclamped floor, neighbour indices clamped, no renormalisation
+// (Resample2d_kernel.cu:42-59).  Thread = output pixel, all channels (flow read once).
+__global__ __launch_bounds__(256) void resample2d_kernel(const float* __restrict__ in1, const float* __restrict__ flow,
+                                                         float* __restrict__ out, int C, int H, int W, size_t total) {
+  const size_t HW = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    const float dx = flow[(b * 2 + 0) * HW + pix], dy = flow[(b * 2 + 1) * HW + pix];
+    const float xf = (float)x + dx, yf = (float)y + dy;
+    const float fx = floorf(xf), fy = floorf(yf);
+    const float alpha = xf - fx, beta = yf - fy;
+    // clamp in float first so huge/inf flows cannot overflow the int conversion
+    const int xL = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    const int xR = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
+    const int yT = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    const int yB = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
+    const float w00 = (1.f - alpha) * (1.f - beta), w01 = alpha * (1.f - beta);
+    const float w10 = (1.f - alpha) * beta, w11 = alpha * beta;
+    for (int c = 0; c < C; ++c) {
+      const float* p = in1 + (b * C + c) * HW;
+      float v = w00 * p[(size_t)yT * W + xL];
+      v += w01 * p[(size_t)yT * W + xR];
+      v += w10 * p[(size_t)yB * W + xL];
+      v += w11 * p[(size_t)yB * W + xR];
+      out[(b * C + c) * HW + pix] = v;
+    }
+  }
+}
+
+// ---- ChannelNorm: sqrt(sum_c x^2) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channelnorm_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                          size_t HW, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = in[(b * C + c) * HW + pix];
+      s += v * v;
+    }
+    out[i] = sqrtf(s);
+  }
+}
+
+// ---- fused inter-network stage: warp img1 by flow, brightness error, 12-channel concat ------------------
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<half_t>(const half_t* p, float (&v)[8]) {
+  const half8_t h = *reinterpret_cast<const half8_t*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+  const float4_t a = reinterpret_cast<const float4_t*>(p)[0], b = reinterpret_cast<const float4_t*>(p)[1];
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<half_t>(half_t* p, const float (&v)[8]) {
+  half8_t h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (half_t)v[i];
+  *reinterpret_cast<half8_t*>(p) = h;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  const float4_t a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  reinterpret_cast<float4_t*>(p)[0] = a;
+  reinterpret_cast<float4_t*>(p)[1] = b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void flow_warp_concat_kernel(const T* __restrict__ x6, const float* __restrict__ flow,
+                                                               float div_flow, T* __restrict__ y, int H, int W,
+                                                               size_t total) {
+  const size_t HW = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
+    const float dx = flow[(b * 2 + 0) * HW + pix], dy = flow[(b * 2 + 1) * HW + pix];
+    const float xf = (float)xx + dx, yf = (float)yy + dy;
+    const float fx = floorf(xf), fy = floorf(yf);
+    const float alpha = xf - fx, beta = yf - fy;
+    const int xL = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    const int xR = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
+    const int yT = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    const int yB = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
+    const float w00 = (1.f - alpha) * (1.f - beta), w01 = alpha * (1.f - beta);
+    const float w10 = (1.f - alpha) * beta, w11 = alpha * beta;
+    const T* img = x6 + b * HW * 8;
+    float c[8], tl[8], tr[8], bl[8], br[8];
+    ld8<T>(img + pix * 8, c);
+    ld8<T>(img + ((size_t)yT * W + xL) * 8, tl);
+    ld8<T>(img + ((size_t)yT * W + xR) * 8, tr);
+    ld8<T>(img + ((size_t)yB * W + xL) * 8, bl);
+    ld8<T>(img + ((size_t)yB * W + xR) * 8, br);
+    float warp[3], nrm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = w00 * tl[3 + k];
+      v += w01 * tr[3 + k];
+      v += w10 * bl[3 + k];
+      v += w11 * br[3 + k];
+      warp[k] = v;
+      const float d = c[k] - v;
+      nrm += d * d;
+    }
+    const float lo[8] = {c[0], c[1], c[2], c[3], c[4], c[5], warp[0], warp[1]};
+    const float hi[8] = {warp[2], dx / div_flow, dy / div_flow, sqrtf(nrm), 0.f, 0.f, 0.f, 0.f};
+    st8<T>(y + i * 16, lo);
+    st8<T>(y + i * 16 + 8, hi);
+  }
+}
+
+static inline int grid_for(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+constexpr int kCorrGX = 3;  // horizontal displacements per thread
+
+}  // namespace ft
+
+using namespace ft;
+
+extern "C" int ft_correlation_out_shape(int C, int H, int W, int pad_size, int kernel_size, int max_displacement,
+                                        int stride1, int stride2, int* out_c, int* out_h, int* out_w) {
+  if (C <= 0 || H <= 0 || W <= 0 || pad_size < 0 || kernel_size <= 0 || max_displacement < 0 || stride1 <= 0 ||
+      stride2 <= 0)
+    return FT_ERR_INVALID_ARG;
+  // correlation_cuda.c:25-35
+  const int krad = (kernel_size - 1) / 2;
+  const int border = krad + max_displacement;
+  const int ph = H + 2 * pad_size, pw = W + 2 * pad_size;
+  const int D = (max_displacement / stride2) * 2 + 1;
+  const int oh = (ph - 2 * border + stride1 - 1) / stride1;  // ceil
+  const int ow = (pw - 2 * border + stride1 - 1) / stride1;
+  if (oh <= 0 || ow <= 0) return FT_ERR_INVALID_ARG;
+  if (out_c) *out_c = D * D;
+  if (out_h) *out_h = oh;
+  if (out_w) *out_w = ow;
+  return FT_OK;
+}
+
+extern "C" int ft_correlation_fwd(const float* in1, const float* in2, float* out, int B, int C, int H, int W,
+                                  int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                  int corr_type_multiply, ft_stream_t stream) {
+  if (!in1 || !in2 || !out || B <= 0) return FT_ERR_INVALID_ARG;
+  if (corr_type_multiply != 1) return FT_ERR_UNSUPPORTED;
+  int oc, oh, ow;
+  int st = ft_correlation_out_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow);
+  if (st != FT_OK) return st;
+  const size_t total = (size_t)B * oc * oh * ow;
+  hipLaunchKernelGGL(correlation_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), in1, in2, out, C, H,
+                     W, oc, oh, ow, pad_size, kernel_size, max_displacement, stride1, stride2, total);
+  FT_LAUNCH_CHECK("correlation_nchw_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, int B, int C, int H, int W,
+                                       int max_displacement, int stride2, int f_cstride, int y_cstride, int y_coff,
+                                       int act, float slope, int dtype, ft_stream_t stream) {
+  if (!f1 || !f2 || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || max_displacement < 0 || stride2 <= 0)
+    return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  if (C % 8 || f_cstride % 8 || f_cstride < C) return FT_ERR_INVALID_ARG;
+  const int D = (max_displacement / stride2) * 2 + 1;
+  if (y_coff < 0 || y_cstride < y_coff + D * D) return FT_ERR_INVALID_ARG;
+  const size_t esz = dtype_size(dtype);
+  const size_t pstride = C * esz + 16;
+  // fp16: 32-pixel tiles / 256 threads; fp32 (parity mode): 16-pixel tiles / 128 threads (LDS budget)
+  const int tx = dtype == FT_F16 ? 32 : 16;
+  const size_t lds = (size_t)(tx + tx + 2 * max_displacement) * pstride + (size_t)tx * D * D * 4;
+  if (lds > 160 * 1024) return FT_ERR_UNSUPPORTED;
+  dim3 grid(ceil_div(W, tx) * H, B);
+  if (dtype == FT_F16) {
+    auto k = correlation_nhwc_kernel<half_t, 32, kCorrGX, 256>;
+    if (lds > 64 * 1024) FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, as_stream(stream), static_cast<const half_t*>(f1),
+                       static_cast<const half_t*>(f2), static_cast<half_t*>(y), C, H, W, max_displacement, stride2,
+                       f_cstride, y_cstride, y_coff, act, slope);
+  } else {
+    auto k = correlation_nhwc_kernel<float, 16, kCorrGX, 128>;
+    if (lds > 64 * 1024) FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(128), lds, as_stream(stream), static_cast<const float*>(f1),
+                       static_cast<const float*>(f2), static_cast<float*>(y), C, H, W, max_displacement, stride2,
+                       f_cstride, y_cstride, y_coff, act, slope);
+  }
+  FT_LAUNCH_CHECK("correlation_nhwc_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_resample2d_fwd(const float* in1, const float* flow, float* out, int B, int C, int H, int W,
+                                 ft_stream_t stream) {
+  if (!in1 || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
+  const size_t total = (size_t)B * H * W;
+  hipLaunchKernelGGL(resample2d_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), in1, flow, out, C, H, W,
+                     total);
+  FT_LAUNCH_CHECK("resample2d_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_channelnorm_fwd(const float* in1, float* out, int B, int C, int H, int W, ft_stream_t stream) {
+  if (!in1 || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
+  const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+  hipLaunchKernelGGL(channelnorm_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), in1, out, C, HW, total);
+  FT_LAUNCH_CHECK("channelnorm_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_flow_warp_concat(const void* x6, const float* flow, float div_flow, void* y, int B, int H, int W,
+                                   int dtype, ft_stream_t stream) {
+  if (!x6 || !flow || !y || B <= 0 || H <= 0 || W <= 0 || div_flow == 0.f) return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const size_t total = (size_t)B * H * W;
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(flow_warp_concat_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const half_t*>(x6), flow, div_flow, static_cast<half_t*>(y), H, W, total);
+  else
+    hipLaunchKernelGGL(flow_warp_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(x6), flow, div_flow, static_cast<float*>(y), H, W, total);
+  FT_LAUNCH_CHECK("flow_warp_concat_kernel");
+  return FT_OK;
+}

@@ -1,0 +1,79 @@
+"""Base class of the HIP-backed models: plan cache, packed-weight invalidation, stream hand-off.
+
+A *plan* is the static launch sequence (hip_ops.Program) of one network for one input shape, with
+all activation buffers pre-allocated in HBM, optionally captured into a HIP graph.  The module's
+parameters stay in the reference's layout; plans hold the packed copies.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .hip_ops import FlowtrackHipError, Program, require_gpu
+
+
+class HipModule(nn.Module):
+    #: set to torch.float16 / torch.float32 to override the dtype implied by the parameters
+    compute_dtype: Optional[torch.dtype] = None
+    #: capture each plan into a HIP graph after its first (eager, validating) run
+    use_graph: bool = True
+
+    def __init__(self):
+        super().__init__()
+        self._plans: Dict[tuple, object] = {}
+        self._stream: Optional[torch.cuda.Stream] = None
+
+    # -- parameter changes invalidate packed weights ------------------------------------------
+    def _invalidate(self):
+        self._plans = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _param_device_dtype(self):
+        p = next(self.parameters())
+        return p.device, p.dtype
+
+    def _resolve(self):
+        device, pdtype = self._param_device_dtype()
+        require_gpu(device)
+        dtype = self.compute_dtype or pdtype
+        if dtype not in (torch.float16, torch.float32):
+            raise FlowtrackHipError(f"compute dtype {dtype} unsupported (fp16 or fp32)")
+        _lib.load()
+        return device, dtype
+
+    def _side_stream(self, device) -> torch.cuda.Stream:
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def _check_eval(self):
+        if self.training:
+            raise FlowtrackHipError(
+                f"{type(self).__name__}: only the inference path is implemented on HIP — call .eval() "
+                "(training-mode BatchNorm / multi-scale outputs are out of scope, SURVEY §8)")
+
+    def _run_plan(self, prog: Program, first: bool) -> None:
+        """Run on the plan's side stream, ordered after/before the caller's current stream."""
+        cur = torch.cuda.current_stream(prog.stream.device)
+        prog.stream.wait_stream(cur)
+        if first:
+            prog.run_eager()          # surfaces argument errors before any capture
+            if self.use_graph:
+                prog.stream.synchronize()
+                prog.capture()
+        else:
+            prog.run()
+        cur.wait_stream(prog.stream)

@@ -1,0 +1,370 @@
+"""FlowNet2-family optical flow on MI355X: FlowNet2S, FlowNet2C, FlowNet2CS as fused HIP launches.
+
+Drop-in surface (reference: lib/flownet/model/models.py:180-292,346-409; trunks
+lib/flownet/networks/FlowNetS.py:15-94, FlowNetC.py:13-128; builders submodules.py:7-38):
+    models.FlowNet2S(args, batchNorm=False, div_flow=20)      args: .rgb_max, .fp16
+    models.FlowNet2C(args, batchNorm=False, div_flow=20)
+    models.FlowNet2CS(args, batchNorm=False, div_flow=20.)
+    module.forward(inputs[B,3,2,H,W] in 0..rgb_max) -> flow [B,2,H,W] (fp32)
+with the reference's state_dict keys so NVIDIA flownet2-pytorch checkpoints
+(`ckpt['state_dict']`, tools/flownet/demo.py:52-54) load unchanged.
+
+What differs by design: conv+bias+LeakyReLU (or folded BN) is one launch; every `torch.cat` is a
+channel slice of a pre-allocated NHWC buffer that its producers write directly; FlowNetC's siamese
+trunk runs once on a 2B batch; correlation reads the NHWC features and writes its LeakyReLU'd cost
+volume into the conv3_1 input buffer; warp + brightness-error + concat between stacked nets is one
+kernel; the x4 bilinear upsample folds in div_flow.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..engine import HipModule
+from ..hip_ops import ActView, FlowtrackHipError, FusedConv, Program, new_act, record_upsample4x
+from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
+
+LEAK = 0.1
+
+
+# ---- parameter layout (submodules.py:7-38) -------------------------------------------------------
+def conv(batchNorm: bool, in_planes: int, out_planes: int, kernel_size: int = 3, stride: int = 1) -> nn.Sequential:
+    pad = (kernel_size - 1) // 2
+    if batchNorm:
+        return nn.Sequential(ConvParams(in_planes, out_planes, kernel_size, stride, pad, bias=False),
+                             BatchNormParams(out_planes), ActMarker("leaky", LEAK))
+    return nn.Sequential(ConvParams(in_planes, out_planes, kernel_size, stride, pad, bias=True),
+                         ActMarker("leaky", LEAK))
+
+
+def predict_flow(in_planes: int) -> ConvParams:
+    return ConvParams(in_planes, 2, 3, 1, 1, bias=True)
+
+
+def deconv(in_planes: int, out_planes: int) -> nn.Sequential:
+    return nn.Sequential(ConvTransposeParams(in_planes, out_planes, bias=True), ActMarker("leaky", LEAK))
+
+
+def _reference_init(module: nn.Module) -> None:
+    """FlowNetS.py:47-56: xavier_uniform weights, U(0,1) biases for every conv / transposed conv."""
+    for m in module.modules():
+        if isinstance(m, (ConvParams, ConvTransposeParams)):
+            if m.bias is not None:
+                nn.init.uniform_(m.bias)
+            nn.init.xavier_uniform_(m.weight)
+
+
+class _Decoder(nn.Module):
+    """Layers shared by FlowNetS and FlowNetC from deconv5 down (FlowNetS.py:31-45)."""
+
+    def _make_decoder(self, upflow_bias: bool) -> None:
+        self.deconv5 = deconv(1024, 512)
+        self.deconv4 = deconv(1026, 256)
+        self.deconv3 = deconv(770, 128)
+        self.deconv2 = deconv(386, 64)
+        self.predict_flow6 = predict_flow(1024)
+        self.predict_flow5 = predict_flow(1026)
+        self.predict_flow4 = predict_flow(770)
+        self.predict_flow3 = predict_flow(386)
+        self.predict_flow2 = predict_flow(194)
+        self.upsampled_flow6_to_5 = ConvTransposeParams(2, 2, bias=upflow_bias)
+        self.upsampled_flow5_to_4 = ConvTransposeParams(2, 2, bias=upflow_bias)
+        self.upsampled_flow4_to_3 = ConvTransposeParams(2, 2, bias=upflow_bias)
+        self.upsampled_flow3_to_2 = ConvTransposeParams(2, 2, bias=upflow_bias)
+
+
+class FlowNetS(_Decoder):
+    """Parameter layout of FlowNetS.py:16-45 (holders only)."""
+
+    def __init__(self, args=None, input_channels: int = 12, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.input_channels = input_channels
+        self.conv1 = conv(batchNorm, input_channels, 64, kernel_size=7, stride=2)
+        self.conv2 = conv(batchNorm, 64, 128, kernel_size=5, stride=2)
+        self.conv3 = conv(batchNorm, 128, 256, kernel_size=5, stride=2)
+        self.conv3_1 = conv(batchNorm, 256, 256)
+        self.conv4 = conv(batchNorm, 256, 512, stride=2)
+        self.conv4_1 = conv(batchNorm, 512, 512)
+        self.conv5 = conv(batchNorm, 512, 512, stride=2)
+        self.conv5_1 = conv(batchNorm, 512, 512)
+        self.conv6 = conv(batchNorm, 512, 1024, stride=2)
+        self.conv6_1 = conv(batchNorm, 1024, 1024)
+        self._make_decoder(upflow_bias=False)
+        _reference_init(self)
+        self.upsample1 = ActMarker("upsample_bilinear_x4")
+
+
+class FlowNetC(_Decoder):
+    """Parameter layout of FlowNetC.py:14-57 (holders only)."""
+
+    def __init__(self, args=None, batchNorm: bool = True, div_flow: float = 20):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.div_flow = div_flow
+        self.conv1 = conv(batchNorm, 3, 64, kernel_size=7, stride=2)
+        self.conv2 = conv(batchNorm, 64, 128, kernel_size=5, stride=2)
+        self.conv3 = conv(batchNorm, 128, 256, kernel_size=5, stride=2)
+        self.conv_redir = conv(batchNorm, 256, 32, kernel_size=1, stride=1)
+        # Correlation(pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2), FlowNetC.py:25-31
+        self.corr = ActMarker("correlation(pad=20,k=1,d=20,s1=1,s2=2)")
+        self.corr_activation = ActMarker("leaky", LEAK)
+        self.conv3_1 = conv(batchNorm, 473, 256)
+        self.conv4 = conv(batchNorm, 256, 512, stride=2)
+        self.conv4_1 = conv(batchNorm, 512, 512)
+        self.conv5 = conv(batchNorm, 512, 512, stride=2)
+        self.conv5_1 = conv(batchNorm, 512, 512)
+        self.conv6 = conv(batchNorm, 512, 1024, stride=2)
+        self.conv6_1 = conv(batchNorm, 1024, 1024)
+        self._make_decoder(upflow_bias=True)
+        _reference_init(self)
+        self.upsample1 = ActMarker("upsample_bilinear_x4")
+
+
+CORR_MAX_DISP, CORR_STRIDE2 = 20, 2
+CORR_CH = (2 * (CORR_MAX_DISP // CORR_STRIDE2) + 1) ** 2  # 441
+
+
+# ---- plan builders ----------------------------------------------------------------------------
+def _fc(seq: nn.Sequential, label: str, mk: dict) -> FusedConv:
+    c = seq[0]
+    bn = seq[1].as_dict() if isinstance(seq[1], BatchNormParams) else None
+    return FusedConv(c.weight, stride=c.stride, pad=c.padding, bias=c.bias, bn=bn, act="leaky", slope=LEAK,
+                     label=label, **mk)
+
+
+def _fd(seq: nn.Sequential, label: str, mk: dict) -> FusedConv:
+    c = seq[0]
+    return FusedConv(c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act="leaky", slope=LEAK, label=label, **mk)
+
+
+def _fp(c: ConvParams, label: str, mk: dict) -> FusedConv:
+    return FusedConv(c.weight, stride=1, pad=1, bias=c.bias, act=None, label=label, **mk)
+
+
+def _fu(c: ConvTransposeParams, label: str, mk: dict) -> FusedConv:
+    return FusedConv(c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act=None, label=label, **mk)
+
+
+def _record_decoder(prog: Program, p: _Decoder, conv6: ActView, cc5, cc4, cc3, cc2, prefix: str, mk: dict):
+    """predict_flow6 .. predict_flow2 with concat-free writes (FlowNetS.py:69-89).
+    cc5..cc2: NHWC buffers [B,h,w,1032|776|392|200] whose channel slice 0 already holds the skip
+    feature; returns flow2 as NCHW fp32 [B,2,H/4,W/4]."""
+    B, dtype, device = conv6.N, mk["dtype"], mk["device"]
+    flow6 = new_act(B, conv6.H, conv6.W, 2, dtype, device)
+    _fp(p.predict_flow6, prefix + "predict_flow6", mk).record(prog, conv6, flow6)
+    _fu(p.upsampled_flow6_to_5, prefix + "upsampled_flow6_to_5", mk).record(prog, flow6, ActView(cc5, 2, 1024))
+    _fd(p.deconv5, prefix + "deconv5", mk).record(prog, conv6, ActView(cc5, 512, 512))
+    concat5 = ActView(cc5, 1026, 0)
+
+    flow5 = new_act(B, concat5.H, concat5.W, 2, dtype, device)
+    _fp(p.predict_flow5, prefix + "predict_flow5", mk).record(prog, concat5, flow5)
+    _fu(p.upsampled_flow5_to_4, prefix + "upsampled_flow5_to_4", mk).record(prog, flow5, ActView(cc4, 2, 768))
+    _fd(p.deconv4, prefix + "deconv4", mk).record(prog, concat5, ActView(cc4, 256, 512))
+    concat4 = ActView(cc4, 770, 0)
+
+    flow4 = new_act(B, concat4.H, concat4.W, 2, dtype, device)
+    _fp(p.predict_flow4, prefix + "predict_flow4", mk).record(prog, concat4, flow4)
+    _fu(p.upsampled_flow4_to_3, prefix + "upsampled_flow4_to_3", mk).record(prog, flow4, ActView(cc3, 2, 384))
+    _fd(p.deconv3, prefix + "deconv3", mk).record(prog, concat4, ActView(cc3, 128, 256))
+    concat3 = ActView(cc3, 386, 0)
+
+    flow3 = new_act(B, concat3.H, concat3.W, 2, dtype, device)
+    _fp(p.predict_flow3, prefix + "predict_flow3", mk).record(prog, concat3, flow3)
+    _fu(p.upsampled_flow3_to_2, prefix + "upsampled_flow3_to_2", mk).record(prog, flow3, ActView(cc2, 2, 192))
+    _fd(p.deconv2, prefix + "deconv2", mk).record(prog, concat3, ActView(cc2, 64, 128))
+    concat2 = ActView(cc2, 194, 0)
+
+    flow2 = torch.empty((B, 2, concat2.H, concat2.W), dtype=torch.float32, device=device)
+    _fp(p.predict_flow2, prefix + "predict_flow2", mk).record(prog, concat2, flow2)
+    return flow2
+
+
+def _concat_buffers(B: int, H: int, W: int, dtype, device, b2: int = None):
+    """cc5, cc4, cc3, cc2 tensors; cc2 may carry a larger batch (siamese FlowNetC trunk)."""
+    z = lambda n, h, w, c: torch.zeros((n, h, w, c), dtype=dtype, device=device)
+    return (z(B, H // 32, W // 32, 1032), z(B, H // 16, W // 16, 776), z(B, H // 8, W // 8, 392),
+            z(b2 or B, H // 4, W // 4, 200))
+
+
+def record_flownets(prog: Program, p: FlowNetS, x: ActView, prefix: str, mk: dict) -> torch.Tensor:
+    """FlowNetS.forward (FlowNetS.py:60-94) on an NHWC input view; returns flow2 NCHW fp32."""
+    B, H, W, dtype, device = x.N, x.H, x.W, mk["dtype"], mk["device"]
+    cc5, cc4, cc3, cc2 = _concat_buffers(B, H, W, dtype, device)
+    c1 = new_act(B, H // 2, W // 2, 64, dtype, device)
+    _fc(p.conv1, prefix + "conv1", mk).record(prog, x, c1)
+    _fc(p.conv2, prefix + "conv2", mk).record(prog, c1, ActView(cc2, 128, 0))
+    c3 = new_act(B, H // 8, W // 8, 256, dtype, device)
+    _fc(p.conv3, prefix + "conv3", mk).record(prog, ActView(cc2, 128, 0), c3)
+    _fc(p.conv3_1, prefix + "conv3_1", mk).record(prog, c3, ActView(cc3, 256, 0))
+    c4 = new_act(B, H // 16, W // 16, 512, dtype, device)
+    _fc(p.conv4, prefix + "conv4", mk).record(prog, ActView(cc3, 256, 0), c4)
+    _fc(p.conv4_1, prefix + "conv4_1", mk).record(prog, c4, ActView(cc4, 512, 0))
+    c5 = new_act(B, H // 32, W // 32, 512, dtype, device)
+    _fc(p.conv5, prefix + "conv5", mk).record(prog, ActView(cc4, 512, 0), c5)
+    _fc(p.conv5_1, prefix + "conv5_1", mk).record(prog, c5, ActView(cc5, 512, 0))
+    c6 = new_act(B, H // 64, W // 64, 1024, dtype, device)
+    _fc(p.conv6, prefix + "conv6", mk).record(prog, ActView(cc5, 512, 0), c6)
+    c61 = new_act(B, H // 64, W // 64, 1024, dtype, device)
+    _fc(p.conv6_1, prefix + "conv6_1", mk).record(prog, c6, c61)
+    return _record_decoder(prog, p, c61, cc5, cc4, cc3, cc2, prefix, mk)
+
+
+def record_flownetc(prog: Program, p: FlowNetC, x2b: ActView, prefix: str, mk: dict) -> torch.Tensor:
+    """FlowNetC.forward (FlowNetC.py:71-128). x2b: [2B,H,W,8] view with 3 channels, images
+    0..B-1 = frame 0 and B..2B-1 = frame 1 (the siamese conv1-3 run once on the 2B batch)."""
+    B2, H, W, dtype, device = x2b.N, x2b.H, x2b.W, mk["dtype"], mk["device"]
+    B = B2 // 2
+    cc5, cc4, cc3, cc2 = _concat_buffers(B, H, W, dtype, device, b2=B2)
+    c1 = new_act(B2, H // 2, W // 2, 64, dtype, device)
+    _fc(p.conv1, prefix + "conv1", mk).record(prog, x2b, c1)
+    _fc(p.conv2, prefix + "conv2", mk).record(prog, c1, ActView(cc2, 128, 0))       # out_conv2a = images 0..B-1
+    c3 = new_act(B2, H // 8, W // 8, 256, dtype, device)
+    _fc(p.conv3, prefix + "conv3", mk).record(prog, ActView(cc2, 128, 0), c3)
+    c3a, c3b = c3.batch_slice(0, B), c3.batch_slice(B, B2)
+    # in_conv3_1 = cat(conv_redir(32), leaky(corr)(441)) -> 473 channels (FlowNetC.py:86-92)
+    cin31 = torch.zeros((B, H // 8, W // 8, 480), dtype=dtype, device=device)
+    _fc(p.conv_redir, prefix + "conv_redir", mk).record(prog, c3a, ActView(cin31, 32, 0))
+    prog.add("ft_correlation_nhwc_fwd", c3a.t.data_ptr(), c3b.t.data_ptr(), cin31.data_ptr(), B, 256, H // 8, W // 8,
+             CORR_MAX_DISP, CORR_STRIDE2, c3.cstride, 480, 32, _lib.FT_ACT_LEAKY, ctypes.c_float(LEAK),
+             _lib.dtype_code(dtype), keep=(c3.t, cin31))
+    _fc(p.conv3_1, prefix + "conv3_1", mk).record(prog, ActView(cin31, 473, 0), ActView(cc3, 256, 0))
+    c4 = new_act(B, H // 16, W // 16, 512, dtype, device)
+    _fc(p.conv4, prefix + "conv4", mk).record(prog, ActView(cc3, 256, 0), c4)
+    _fc(p.conv4_1, prefix + "conv4_1", mk).record(prog, c4, ActView(cc4, 512, 0))
+    c5 = new_act(B, H // 32, W // 32, 512, dtype, device)
+    _fc(p.conv5, prefix + "conv5", mk).record(prog, ActView(cc4, 512, 0), c5)
+    _fc(p.conv5_1, prefix + "conv5_1", mk).record(prog, c5, ActView(cc5, 512, 0))
+    c6 = new_act(B, H // 64, W // 64, 1024, dtype, device)
+    _fc(p.conv6, prefix + "conv6", mk).record(prog, ActView(cc5, 512, 0), c6)
+    c61 = new_act(B, H // 64, W // 64, 1024, dtype, device)
+    _fc(p.conv6_1, prefix + "conv6_1", mk).record(prog, c6, c61)
+    return _record_decoder(prog, p, c61, cc5, cc4, cc3, cc2[:B], prefix, mk)
+
+
+class _FlowPlan:
+    def __init__(self, prog, x_static, out):
+        self.prog, self.x_static, self.out = prog, x_static, out
+        self.runs = 0
+
+
+class _FlowBase(HipModule):
+    """Shared forward / plan cache of the FlowNet2* wrappers."""
+    rgb_max: float = 255.0
+    div_flow: float = 20.0
+
+    def _record_normalise(self, prog: Program, x_static: torch.Tensor, modes, dtype, device):
+        """rgb_mean + (x-mean)/rgb_max (models.py:255-257); returns one NHWC buffer per mode."""
+        B, _, _, H, W = x_static.shape
+        partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
+        mean = torch.empty((B * 3,), dtype=torch.float32, device=device)
+        prog.add("ft_flow_rgb_mean", x_static.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(),
+                 keep=(x_static, partial, mean))
+        outs = []
+        for mode in modes:
+            n = B if mode == 0 else 2 * B
+            buf = torch.zeros((n, H, W, 8), dtype=dtype, device=device)
+            prog.add("ft_flow_pack_pair", x_static.data_ptr(), mean.data_ptr(), ctypes.c_float(self.rgb_max),
+                     buf.data_ptr(), B, H, W, mode, _lib.dtype_code(dtype), keep=(buf,))
+            outs.append(buf)
+        return outs
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def plan_for(self, B: int, H: int, W: int) -> _FlowPlan:
+        device, dtype = self._resolve()
+        if H % 64 or W % 64:
+            raise FlowtrackHipError(f"frame size {H}x{W}: FlowNet needs multiples of 64")
+        key = (B, H, W, device, dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            with torch.no_grad():
+                plan = self._build_plan(B, H, W, device, dtype)
+            self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def forward(self, inputs: torch.Tensor, copy_output: bool = True) -> torch.Tensor:
+        """inputs [B,3,2,H,W] (RGB, 0..rgb_max) -> flow [B,2,H,W] fp32 in pixels."""
+        self._check_eval()
+        if inputs.dim() != 5 or inputs.shape[1] != 3 or inputs.shape[2] != 2:
+            raise FlowtrackHipError(f"expected [B,3,2,H,W], got {tuple(inputs.shape)}")
+        B, _, _, H, W = inputs.shape
+        plan = self.plan_for(B, H, W)
+        if inputs.device != plan.x_static.device:
+            raise FlowtrackHipError("input and model are on different devices")
+        plan.x_static.copy_(inputs)
+        self._run_plan(plan.prog, first=plan.runs == 0)
+        plan.runs += 1
+        return plan.out.clone() if copy_output else plan.out
+
+
+class FlowNet2S(FlowNetS, _FlowBase):
+    def __init__(self, args, batchNorm: bool = False, div_flow: float = 20):
+        _FlowBase.__init__(self)
+        FlowNetS.__init__(self, args, input_channels=6, batchNorm=batchNorm)
+        self.rgb_max = float(args.rgb_max)
+        self.div_flow = float(div_flow)
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device)
+        x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
+        (x6,) = self._record_normalise(prog, x_static, (0,), dtype, device)
+        flow2 = record_flownets(prog, self, ActView(x6, 6, 0), "", mk)
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2, out, self.div_flow)  # upsample1(flow2 * div_flow), models.py:292
+        return _FlowPlan(prog, x_static, out)
+
+
+class FlowNet2C(FlowNetC, _FlowBase):
+    def __init__(self, args, batchNorm: bool = False, div_flow: float = 20):
+        _FlowBase.__init__(self)
+        FlowNetC.__init__(self, args, batchNorm=batchNorm, div_flow=20)  # models.py:182 pins 20
+        self.rgb_max = float(args.rgb_max)
+        self.div_flow = 20.0
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device)
+        x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
+        (x2b,) = self._record_normalise(prog, x_static, (1,), dtype, device)
+        flow2 = record_flownetc(prog, self, ActView(x2b, 3, 0), "", mk)
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2, out, self.div_flow)
+        return _FlowPlan(prog, x_static, out)
+
+
+class FlowNet2CS(_FlowBase):
+    def __init__(self, args, batchNorm: bool = False, div_flow: float = 20.):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.div_flow = float(div_flow)
+        self.rgb_max = float(args.rgb_max)
+        self.args = args
+        self.channelnorm = ActMarker("channelnorm")
+        self.flownetc = FlowNetC(args, batchNorm=batchNorm)
+        self.upsample1 = ActMarker("upsample_bilinear_x4")
+        self.resample1 = ActMarker("resample2d")
+        self.flownets_1 = FlowNetS(args, batchNorm=batchNorm)
+        self.upsample2 = ActMarker("upsample_bilinear_x4")
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device)
+        x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
+        x6, x2b = self._record_normalise(prog, x_static, (0, 1), dtype, device)
+        flow2c = record_flownetc(prog, self.flownetc, ActView(x2b, 3, 0), "flownetc.", mk)
+        flowc = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2c, flowc, self.div_flow)           # models.py:393-394
+        concat1 = torch.zeros((B, H, W, 16), dtype=dtype, device=device)
+        prog.add("ft_flow_warp_concat", x6.data_ptr(), flowc.data_ptr(), ctypes.c_float(self.div_flow),
+                 concat1.data_ptr(), B, H, W, _lib.dtype_code(dtype), keep=(x6, flowc, concat1))  # models.py:396-403
+        flow2s = record_flownets(prog, self.flownets_1, ActView(concat1, 12, 0), "flownets_1.", mk)
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2s, out, self.div_flow)             # models.py:406-407
+        return _FlowPlan(prog, x_static, out)

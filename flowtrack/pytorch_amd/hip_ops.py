@@ -1,0 +1,331 @@
+"""Host-side operator layer over the C ABI (include/flowtrack_hip.h).
+
+PyTorch is used here for device memory, streams and parameter bookkeeping only; every arithmetic
+step of the pose / flow hot paths is a launch into libflowtrack_hip.so.  Nothing in this module
+falls back to torch ops: a missing library or GPU raises FlowtrackHipError.
+
+Vocabulary: an *activation view* (`ActView`) is an NHWC tensor [N, H, W, cstride] plus a channel
+window [coff, coff + C) — the unit the fused conv reads and writes, so that `torch.cat` in the
+reference graphs (lib/flownet/networks/FlowNetS.py:73-88) becomes "write into a slice".
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (FT_ACT_LEAKY, FT_ACT_NONE, FT_ACT_RELU, FT_LAYOUT_NCHW_F32, FT_LAYOUT_NHWC,
+                   ConvDesc, FlowtrackHipError, check)
+
+ACT_CODES = {None: FT_ACT_NONE, "none": FT_ACT_NONE, "relu": FT_ACT_RELU, "leaky": FT_ACT_LEAKY}
+
+
+def require_gpu(device: torch.device) -> None:
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise FlowtrackHipError(
+            "the flowtrack HIP path needs a ROCm GPU (model.cuda()); there is no CPU fallback — "
+            "use oracle/ for CPU reference results")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class ActView:
+    """Channel window [coff, coff+C) of an NHWC buffer t = [N, H, W, cstride]."""
+    t: torch.Tensor
+    C: int
+    coff: int = 0
+
+    @property
+    def N(self): return self.t.shape[0]
+    @property
+    def H(self): return self.t.shape[1]
+    @property
+    def W(self): return self.t.shape[2]
+    @property
+    def cstride(self): return self.t.shape[3]
+
+    def batch_slice(self, lo: int, hi: int) -> "ActView":
+        return ActView(self.t[lo:hi], self.C, self.coff)
+
+
+def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int] = None) -> ActView:
+    """Zero-filled NHWC buffer; the channel stride is rounded up to 8 (16-byte vectors) and the
+    padding channels stay zero for the buffer's lifetime (the conv reads them against zero weights)."""
+    cs = round_up(C if cstride is None else cstride, 8)
+    return ActView(torch.zeros((N, H, W, cs), dtype=dtype, device=device), C, 0)
+
+
+# --------------------------------------------------------------------------------------------
+# launch recording: a Program is the static launch sequence of one network at one input shape.
+# --------------------------------------------------------------------------------------------
+class Program:
+    """Ordered list of C-ABI calls with fully bound arguments, replayable eagerly or as a HIP graph."""
+
+    def __init__(self, stream: torch.cuda.Stream):
+        self.lib = _lib.load()
+        self.stream = stream
+        self.calls: List[Tuple[str, tuple]] = []
+        self.keepalive: list = []
+        self.graph_exec = None
+        self.flops = 0.0
+        self.conv_records: list = []  # (label, desc, flops) for per-layer timing / roofline
+
+    @property
+    def stream_handle(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    def add(self, name: str, *args, keep: Sequence = ()) -> None:
+        self.calls.append((name, args))
+        self.keepalive.extend(keep)
+
+    def run_eager(self) -> None:
+        sh = self.stream_handle
+        lib = self.lib
+        for name, args in self.calls:
+            check(getattr(lib, name)(*args, sh), name)
+
+    def capture(self) -> None:
+        """Record the launch sequence into a HIP graph (hipStreamBeginCapture on our side stream)."""
+        if self.graph_exec is not None:
+            return
+        sh = self.stream_handle
+        check(self.lib.ft_graph_begin_capture(sh), "ft_graph_begin_capture")
+        try:
+            self.run_eager()
+        finally:
+            exec_ = ctypes.c_void_p()
+            st = self.lib.ft_graph_end_capture(sh, ctypes.byref(exec_))
+        check(st, "ft_graph_end_capture")
+        self.graph_exec = exec_
+
+    def run(self) -> None:
+        if self.graph_exec is not None:
+            check(self.lib.ft_graph_launch(self.graph_exec, self.stream_handle), "ft_graph_launch")
+        else:
+            self.run_eager()
+
+    def time_calls(self, iters: int = 5):
+        """Per-call hipEvent timing on the program's stream (eager). Returns [(name, ms_avg)]."""
+        lib, sh = self.lib, self.stream_handle
+        evs = []
+        for _ in range(len(self.calls) + 1):
+            e = ctypes.c_void_p()
+            check(lib.ft_event_create(ctypes.byref(e)), "ft_event_create")
+            evs.append(e)
+        acc = [0.0] * len(self.calls)
+        for _ in range(iters):
+            check(lib.ft_event_record(evs[0], sh))
+            for i, (name, args) in enumerate(self.calls):
+                check(getattr(lib, name)(*args, sh), name)
+                check(lib.ft_event_record(evs[i + 1], sh))
+            check(lib.ft_event_synchronize(evs[-1]))
+            for i in range(len(self.calls)):
+                ms = ctypes.c_float()
+                check(lib.ft_event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
+                acc[i] += ms.value
+        for e in evs:
+            lib.ft_event_destroy(e)
+        return [(self.calls[i][0], acc[i] / iters) for i in range(len(self.calls))]
+
+    def __del__(self):
+        try:
+            if self.graph_exec is not None:
+                self.lib.ft_graph_destroy(self.graph_exec)
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------------
+# fused conv / transposed conv
+# --------------------------------------------------------------------------------------------
+def _probe_desc(dtype_code: int, cin: int, cout: int, k: int, stride: int, pad: int, transposed: bool) -> ConvDesc:
+    """A geometrically consistent dummy descriptor, used only to query the packed-weight layout."""
+    d = ConvDesc()
+    d.dtype = dtype_code
+    d.N, d.Hi, d.Wi = 1, 64, 64
+    d.Cin, d.x_cstride, d.x_coff = cin, round_up(cin, 8), 0
+    d.Cout, d.kh, d.kw, d.stride, d.pad, d.transposed = cout, k, k, stride, pad, int(transposed)
+    if transposed:
+        d.Ho, d.Wo = 128, 128
+    else:
+        d.Ho = d.Wo = (64 + 2 * pad - k) // stride + 1
+    d.y_cstride, d.y_coff, d.out_layout = round_up(cout, 8), 0, FT_LAYOUT_NHWC
+    d.act = FT_ACT_NONE
+    return d
+
+
+def pack_conv_weights(weight: torch.Tensor, *, transposed: bool, stride: int, pad: int, dtype: torch.dtype,
+                      device: torch.device) -> Tuple[torch.Tensor, int]:
+    """Re-lay reference weights for the implicit-GEMM kernel.
+
+    weight: Conv2d [Cout, Cin, kh, kw] or ConvTranspose2d [Cin, Cout, 4, 4] (reference layouts,
+    SURVEY Appendix B).  Returns ([nphases, Cout_pad, Kpad] tensor of `dtype` on `device`,
+    Cout_pad); k = tap * Cin8 + ci, zeros in all padding.  The tap -> (ky, kx) map comes from the
+    library (ft_conv_tap_source) so packer and kernel cannot disagree."""
+    lib = _lib.load()
+    w = weight.detach().to(torch.float32).cpu()
+    if transposed:
+        cin, cout, kh, kw = w.shape
+    else:
+        cout, cin, kh, kw = w.shape
+    if kh != kw:
+        raise FlowtrackHipError("only square kernels are used by the FlowTrack hot paths")
+    code = _lib.dtype_code(dtype)
+    d = _probe_desc(code, cin, cout, kh, stride, pad, transposed)
+    nph, ntaps, cin8, cout_pad, kpad = (ctypes.c_int() for _ in range(5))
+    check(lib.ft_conv_pack_geometry(ctypes.byref(d), ctypes.byref(nph), ctypes.byref(ntaps), ctypes.byref(cin8),
+                                    ctypes.byref(cout_pad), ctypes.byref(kpad)), "ft_conv_pack_geometry")
+    nph, ntaps, cin8, cout_pad, kpad = nph.value, ntaps.value, cin8.value, cout_pad.value, kpad.value
+    packed = torch.zeros((nph, cout_pad, kpad), dtype=torch.float32)
+    ky, kx = ctypes.c_int(), ctypes.c_int()
+    for ph in range(nph):
+        for t in range(ntaps):
+            check(lib.ft_conv_tap_source(ctypes.byref(d), ph, t, ctypes.byref(ky), ctypes.byref(kx)),
+                  "ft_conv_tap_source")
+            if transposed:
+                tap_w = w[:, :, ky.value, kx.value].t()  # [Cout, Cin]
+            else:
+                tap_w = w[:, :, ky.value, kx.value]      # [Cout, Cin]
+            packed[ph, :cout, t * cin8:t * cin8 + cin] = tap_w
+    return packed.to(device=device, dtype=dtype).contiguous(), cout_pad
+
+
+def fold_scale_shift(cout: int, cout_pad: int, bias: Optional[torch.Tensor], bn: Optional[dict],
+                     device: torch.device) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Eval-mode BatchNorm2d (running stats) and/or conv bias folded into fp32 scale/shift:
+    y = conv * scale + shift, scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ bias * scale)."""
+    scale = shift = None
+    if bn is not None:
+        g = bn["weight"].detach().double().cpu()
+        b = bn["bias"].detach().double().cpu()
+        m = bn["running_mean"].detach().double().cpu()
+        v = bn["running_var"].detach().double().cpu()
+        s = g / torch.sqrt(v + bn.get("eps", 1e-5))
+        sh = b - m * s
+        if bias is not None:
+            sh = sh + bias.detach().double().cpu() * s
+        scale = torch.ones(cout_pad, dtype=torch.float32)
+        shift = torch.zeros(cout_pad, dtype=torch.float32)
+        scale[:cout] = s.float()
+        shift[:cout] = sh.float()
+    elif bias is not None:
+        shift = torch.zeros(cout_pad, dtype=torch.float32)
+        shift[:cout] = bias.detach().float().cpu()
+    if scale is not None:
+        scale = scale.to(device)
+    if shift is not None:
+        shift = shift.to(device)
+    return scale, shift
+
+
+class FusedConv:
+    """One Conv2d / ConvTranspose2d(4,2,1) with its folded BN / bias and activation, packed for HIP."""
+
+    def __init__(self, weight: torch.Tensor, *, dtype: torch.dtype, device: torch.device, stride: int = 1,
+                 pad: int = 0, transposed: bool = False, bias: Optional[torch.Tensor] = None,
+                 bn: Optional[dict] = None, act: Optional[str] = None, slope: float = 0.0, label: str = ""):
+        require_gpu(device)
+        self.lib = _lib.load()
+        self.dtype, self.device = dtype, device
+        self.code = _lib.dtype_code(dtype)
+        self.transposed = transposed
+        if transposed:
+            self.cin, self.cout, self.k, _ = weight.shape
+        else:
+            self.cout, self.cin, self.k, _ = weight.shape
+        self.stride, self.pad = stride, pad
+        self.act, self.slope, self.label = ACT_CODES[act], float(slope), label
+        self.w, self.cout_pad = pack_conv_weights(weight, transposed=transposed, stride=stride, pad=pad, dtype=dtype,
+                                                  device=device)
+        self.scale, self.shift = fold_scale_shift(self.cout, self.cout_pad, bias, bn, device)
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        if self.transposed:
+            return 2 * H, 2 * W
+        return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+
+    def record(self, prog: Program, x: ActView, y, residual: Optional[ActView] = None) -> None:
+        """Append this layer to `prog`. y is an ActView (NHWC) or a contiguous NCHW fp32 tensor."""
+        if x.C != self.cin:
+            raise FlowtrackHipError(f"{self.label}: input has {x.C} channels, layer expects {self.cin}")
+        if x.t.dtype != self.dtype or not x.t.is_contiguous():
+            raise FlowtrackHipError(f"{self.label}: input buffer must be contiguous {self.dtype}")
+        Ho, Wo = self.out_hw(x.H, x.W)
+        d = ConvDesc()
+        d.dtype = self.code
+        d.N, d.Hi, d.Wi = x.N, x.H, x.W
+        d.Cin, d.x_cstride, d.x_coff = self.cin, x.cstride, x.coff
+        d.Cout, d.kh, d.kw = self.cout, self.k, self.k
+        d.stride, d.pad, d.transposed = self.stride, self.pad, int(self.transposed)
+        d.Ho, d.Wo = Ho, Wo
+        if isinstance(y, ActView):
+            if (y.N, y.H, y.W) != (x.N, Ho, Wo) or y.C != self.cout or y.t.dtype != self.dtype:
+                raise FlowtrackHipError(f"{self.label}: output view mismatch {tuple(y.t.shape)} C={y.C}")
+            d.y_cstride, d.y_coff, d.out_layout = y.cstride, y.coff, FT_LAYOUT_NHWC
+            yt = y.t
+        else:
+            if tuple(y.shape) != (x.N, self.cout, Ho, Wo) or y.dtype != torch.float32 or not y.is_contiguous():
+                raise FlowtrackHipError(f"{self.label}: NCHW output must be contiguous fp32 {(x.N, self.cout, Ho, Wo)}")
+            d.y_cstride, d.y_coff, d.out_layout = 0, 0, FT_LAYOUT_NCHW_F32
+            yt = y
+        res_ptr = None
+        if residual is not None:
+            if (residual.N, residual.H, residual.W) != (x.N, Ho, Wo) or residual.C != self.cout:
+                raise FlowtrackHipError(f"{self.label}: residual view mismatch")
+            d.has_residual, d.res_cstride, d.res_coff = 1, residual.cstride, residual.coff
+            res_ptr = residual.t.data_ptr()
+        d.act, d.slope = self.act, self.slope
+        flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
+        prog.flops += flops
+        prog.conv_records.append((self.label, len(prog.calls), flops))
+        prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), self.w.data_ptr(),
+                 self.scale.data_ptr() if self.scale is not None else None,
+                 self.shift.data_ptr() if self.shift is not None else None, res_ptr, yt.data_ptr(),
+                 keep=(d, x.t, yt, self.w, self.scale, self.shift, residual.t if residual is not None else None))
+
+
+# --------------------------------------------------------------------------------------------
+# thin wrappers for the remaining entry points (recorded into a Program)
+# --------------------------------------------------------------------------------------------
+def record_pack_input(prog: Program, x_nchw: torch.Tensor, y: ActView) -> None:
+    N, C, H, W = x_nchw.shape
+    prog.add("ft_pack_nchw_to_nhwc", x_nchw.data_ptr(), y.t.data_ptr(), N, C, H, W, y.cstride,
+             _lib.dtype_code(y.t.dtype), keep=(x_nchw, y.t))
+
+
+def record_maxpool(prog: Program, x: ActView, y: ActView) -> None:
+    if x.coff or y.coff or x.cstride != x.C or y.cstride != y.C:
+        raise FlowtrackHipError("maxpool works on dense NHWC buffers")
+    prog.add("ft_maxpool3x3s2_fwd", x.t.data_ptr(), y.t.data_ptr(), x.N, x.H, x.W, x.C, _lib.dtype_code(x.t.dtype),
+             keep=(x.t, y.t))
+
+
+def record_upsample4x(prog: Program, x: torch.Tensor, y: torch.Tensor, mul: float) -> None:
+    N, C, h, w = x.shape
+    prog.add("ft_upsample_bilinear4x", x.data_ptr(), y.data_ptr(), N, C, h, w, ctypes.c_float(mul), keep=(x, y))
+
+
+def current_stream_handle() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def heatmap_max_preds(heatmaps: torch.Tensor, adjust_coords: bool):
+    """Device part of max_preds/final_preds (lib/pose/utils/evaluation.py:11-33).
+    Returns (idx int32 [N,K], scores fp32 [N,K,1], coords fp32 [N,K,2]) on the device."""
+    require_gpu(heatmaps.device)
+    lib = _lib.load()
+    hm = heatmaps.contiguous().float()
+    N, K, H, W = hm.shape
+    idx = torch.empty((N, K), dtype=torch.int32, device=hm.device)
+    score = torch.empty((N, K, 1), dtype=torch.float32, device=hm.device)
+    coords = torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
+    check(lib.ft_heatmap_max_preds(hm.data_ptr(), N, K, H, W, int(bool(adjust_coords)), idx.data_ptr(),
+                                   score.data_ptr(), coords.data_ptr(), current_stream_handle()),
+          "ft_heatmap_max_preds")
+    return idx, score, coords

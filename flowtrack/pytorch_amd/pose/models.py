@@ -1,0 +1,209 @@
+"""Pose network of FlowTrack on MI355X: ResNet-50/101/152 trunk + 3x ConvTranspose(4,2,1) head +
+1x1 heatmap conv, executed as fused HIP launches (libflowtrack_hip.so).
+
+Drop-in surface (reference: lib/pose/models/pose_deconv.py:12-63,166-179, resnet.py:15-55,
+blocks.py:83-120):
+    models.deconv(backbone: str, num_classes: int, pretrained: bool) -> module
+    module.forward(x[B,3,H,W]) -> heatmaps [B,K,H/4,W/4] (fp32)
+    module.state_dict() / load_state_dict() / init_net(path) / .cuda() / .half() / .eval()
+with the reference's parameter names and shapes, so its checkpoints
+(`ckpt['state_dict']`, tools/pose/main.py:176-181) and torchvision-keyed ImageNet backbones
+(`data/pretrained/<backbone>.pth`, loaded strict=False) load unchanged.
+
+What differs by design: eval-mode BatchNorm and ReLU / the residual add are folded into each
+conv's epilogue; activations live in NHWC (fp16 or fp32) HBM buffers allocated once per input
+shape; the ~60 launches of one forward are replayed as a HIP graph.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ..engine import HipModule
+from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, Program, new_act, record_maxpool,
+                       record_pack_input)
+from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
+
+# depth -> blocks per stage; only Bottleneck nets are valid because the head hard-codes 2048
+# input channels (pose_deconv.py:20), see SURVEY §8 P1.
+resnet_dict = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+class Bottleneck(nn.Module):
+    """Parameter layout of blocks.py:83-103 (stride on the 3x3, torchvision-compatible)."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = ConvParams(inplanes, planes, 1, bias=False)
+        self.bn1 = BatchNormParams(planes)
+        self.conv2 = ConvParams(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNormParams(planes)
+        self.conv3 = ConvParams(planes, planes * 4, 1, bias=False)
+        self.bn3 = BatchNormParams(planes * 4)
+        self.relu = ActMarker("relu")
+        if stride != 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(ConvParams(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                            BatchNormParams(planes * 4))
+        else:
+            self.downsample = nn.Sequential()
+
+
+class _PosePlan:
+    def __init__(self, prog, x_static, heatmaps):
+        self.prog, self.x_static, self.heatmaps = prog, x_static, heatmaps
+        self.runs = 0
+
+
+class DeconvResnet(HipModule):
+    def __init__(self, layers: List[int], num_classes: int):
+        super().__init__()
+        self.layers_cfg = list(layers)
+        self.num_classes = num_classes
+        self.inplanes = 64
+        # trunk (resnet.py:19-27)
+        self.conv1 = ConvParams(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNormParams(64)
+        self.relu = ActMarker("relu")
+        self.maxpool = ActMarker("maxpool3x3s2")
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        # head (pose_deconv.py:16-30)
+        self.deconv_bias = False
+        feats = 256
+        self.deconv = nn.Sequential(
+            ConvTransposeParams(2048, feats, bias=False), BatchNormParams(feats), ActMarker("relu"),
+            ConvTransposeParams(feats, feats, bias=False), BatchNormParams(feats), ActMarker("relu"),
+            ConvTransposeParams(feats, feats, bias=False), BatchNormParams(feats), ActMarker("relu"))
+        self.heatmap = ConvParams(feats, num_classes, 1, bias=True)
+
+    def _make_layer(self, planes: int, blocks: int, stride: int = 1) -> nn.Sequential:
+        mods = [Bottleneck(self.inplanes, planes, stride)]
+        self.inplanes = planes * 4
+        mods += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    # -- initialisation / loading (resnet.py:38-49, pose_deconv.py:48-63) ---------------------
+    def init_weights(self, pretrained: str = "") -> None:
+        if os.path.isfile(pretrained):
+            print("=> loading pretrained model {}".format(pretrained))
+            self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=False)
+            return
+        for m in self.modules():
+            if isinstance(m, ConvParams):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, BatchNormParams):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._invalidate()
+
+    def init_net(self, pretrained: str = "") -> None:
+        self.init_weights(pretrained)
+        for m in self.deconv:
+            if isinstance(m, ConvTransposeParams):
+                nn.init.normal_(m.weight, std=0.001)
+            elif isinstance(m, BatchNormParams):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.heatmap.weight, std=0.001)
+        nn.init.constant_(self.heatmap.bias, 0)
+        self._invalidate()
+
+    # -- plan construction ----------------------------------------------------------------------
+    def _build_plan(self, B: int, H: int, W: int, device, dtype) -> _PosePlan:
+        if H % 32 or W % 32:
+            raise FlowtrackHipError(f"input {H}x{W}: height and width must be multiples of 32")
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device)
+        x_static = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
+        a_in = new_act(B, H, W, 3, dtype, device)
+        record_pack_input(prog, x_static, a_in)
+
+        stem = FusedConv(self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(), act="relu", label="conv1", **mk)
+        a1 = new_act(B, H // 2, W // 2, 64, dtype, device)
+        stem.record(prog, a_in, a1)
+        cur = new_act(B, H // 4, W // 4, 64, dtype, device)
+        record_maxpool(prog, a1, cur)
+
+        for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), start=1):
+            for bi, blk in enumerate(layer):
+                name = f"layer{li}.{bi}"
+                planes = blk.conv1.cout
+                s = blk.stride
+                Ho, Wo = cur.H // s, cur.W // s
+                c1 = FusedConv(blk.conv1.weight, bn=blk.bn1.as_dict(), act="relu", label=name + ".conv1", **mk)
+                c2 = FusedConv(blk.conv2.weight, stride=s, pad=1, bn=blk.bn2.as_dict(), act="relu",
+                               label=name + ".conv2", **mk)
+                c3 = FusedConv(blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", label=name + ".conv3", **mk)
+                t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
+                t2 = new_act(B, Ho, Wo, planes, dtype, device)
+                out = new_act(B, Ho, Wo, planes * 4, dtype, device)
+                c1.record(prog, cur, t1)
+                c2.record(prog, t1, t2)
+                if len(blk.downsample):
+                    ds = FusedConv(blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(), act=None,
+                                   label=name + ".downsample", **mk)
+                    res = new_act(B, Ho, Wo, planes * 4, dtype, device)
+                    ds.record(prog, cur, res)
+                else:
+                    res = cur
+                c3.record(prog, t2, out, residual=res)  # relu(bn3(conv3) + residual), blocks.py:114-119
+                cur = out
+
+        for i in (0, 3, 6):
+            dc = FusedConv(self.deconv[i].weight, transposed=True, stride=2, pad=1, bias=self.deconv[i].bias,
+                           bn=self.deconv[i + 1].as_dict(), act="relu", label=f"deconv.{i}", **mk)
+            nxt = new_act(B, cur.H * 2, cur.W * 2, dc.cout, dtype, device)
+            dc.record(prog, cur, nxt)
+            cur = nxt
+
+        hm = FusedConv(self.heatmap.weight, bias=self.heatmap.bias, act=None, label="heatmap", **mk)
+        heatmaps = torch.empty((B, self.num_classes, cur.H, cur.W), dtype=torch.float32, device=device)
+        hm.record(prog, cur, heatmaps)
+        return _PosePlan(prog, x_static, heatmaps)
+
+    def plan_for(self, B: int, H: int, W: int) -> _PosePlan:
+        device, dtype = self._resolve()
+        key = (B, H, W, device, dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            with torch.no_grad():
+                plan = self._build_plan(B, H, W, device, dtype)
+            self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, copy_output: bool = True) -> torch.Tensor:
+        """x: [B,3,H,W] on the model's GPU -> heatmaps [B,K,H/4,W/4] fp32 (pose_deconv.py:32-46)."""
+        self._check_eval()
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise FlowtrackHipError(f"expected [B,3,H,W], got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        plan = self.plan_for(B, H, W)
+        if x.device != plan.x_static.device:
+            raise FlowtrackHipError("input and model are on different devices")
+        plan.x_static.copy_(x)  # dtype cast + staging into the graph's fixed input address
+        self._run_plan(plan.prog, first=plan.runs == 0)
+        plan.runs += 1
+        return plan.heatmaps.clone() if copy_output else plan.heatmaps
+
+
+def deconv(backbone: str, num_classes: int, pretrained: bool) -> DeconvResnet:
+    """Factory with the reference's signature (pose_deconv.py:166-179): backbone 'resnet50' |
+    'resnet101' | 'resnet152'; pretrained=True loads data/pretrained/<backbone>.pth if present."""
+    if not backbone.startswith("resnet"):
+        raise FlowtrackHipError(f"backbone '{backbone}': only the ResNet-50/101/152 + deconv head is on the HIP path")
+    depth = int(backbone[len("resnet"):])
+    if depth not in resnet_dict:
+        raise FlowtrackHipError(f"resnet{depth}: the deconv head needs a Bottleneck trunk (50/101/152)")
+    model = DeconvResnet(resnet_dict[depth], num_classes=num_classes)
+    path = os.path.join("data", "pretrained", "{}.pth".format(backbone)) if pretrained else ""
+    model.init_net(path)
+    return model

@@ -1,0 +1,218 @@
+/*
+ * flowtrack_hip.h — C ABI of libflowtrack_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the two dense-CNN hot paths of FlowTrack
+ * (pose: ResNet + 3x deconv head; flow: FlowNet2-family).  It replaces the
+ * reference's operator FFI — the cffi/THC entry points that the reference
+ * binds through torch.utils.ffi — and the stock torch.nn layers the reference
+ * runs through cuDNN.  Conventions (differences from the reference FFI are
+ * deliberate):
+ *
+ *   - plain device pointers + explicit sizes + a hipStream_t (as void*); no
+ *     torch / THC types, no global THCState;
+ *   - the caller owns every buffer, including outputs and workspaces; nothing
+ *     is resized, zero-filled or freed behind the caller's back
+ *     (reference: correlation_cuda.c:36-42,83-84 resizes + frees scratch);
+ *   - every entry point returns an int status (FT_OK == 0) and never aborts
+ *     (reference: THError("aborting") correlation_cuda.c:87-89; exit(-1)
+ *     roi_pooling_kernel.cu:94-98);
+ *   - all work is enqueued asynchronously on the given stream; entry points
+ *     are re-entrant and hold no global state (one process per GPU).
+ *
+ * Reference paths are relative to /root/reference.
+ */
+#ifndef FLOWTRACK_HIP_H_
+#define FLOWTRACK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+  FT_OK = 0,
+  FT_ERR_INVALID_ARG = 1,   /* bad size / alignment / enum */
+  FT_ERR_UNSUPPORTED = 2,   /* valid but not implemented for this combination */
+  FT_ERR_HIP = 3,           /* a HIP runtime call failed; see ft_last_hip_error */
+  FT_ERR_NO_DEVICE = 4
+};
+
+/* ---- element types / layouts --------------------------------------------- */
+enum { FT_F16 = 0, FT_F32 = 1 };
+enum { FT_ACT_NONE = 0, FT_ACT_RELU = 1, FT_ACT_LEAKY = 2 };
+enum { FT_LAYOUT_NHWC = 0, FT_LAYOUT_NCHW_F32 = 1 };
+
+typedef void* ft_stream_t; /* hipStream_t */
+
+/* ---- runtime ------------------------------------------------------------- */
+int ft_version(void);
+const char* ft_status_string(int status);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char* ft_last_hip_error(void);
+/* name (<= name_len bytes incl. NUL), CU count, HBM bytes of `device` */
+int ft_device_info(int device, char* name, int name_len, int* cu_count,
+                   uint64_t* hbm_bytes);
+
+/* HIP-graph capture of a launch sequence issued on `stream` through this ABI
+ * (replaces per-layer host launches in the hot loop). */
+int ft_graph_begin_capture(ft_stream_t stream);
+int ft_graph_end_capture(ft_stream_t stream, void** graph_exec_out);
+int ft_graph_launch(void* graph_exec, ft_stream_t stream);
+int ft_graph_destroy(void* graph_exec);
+
+/* hipEvent helpers so a host in any language can time work on `stream`
+ * (torch.cuda.Event only sees torch's current stream). */
+int ft_event_create(void** event_out);
+int ft_event_record(void* event, ft_stream_t stream);
+int ft_event_synchronize(void* event);
+int ft_event_elapsed_ms(void* start, void* stop, float* ms_out);
+int ft_event_destroy(void* event);
+int ft_stream_synchronize(ft_stream_t stream);
+
+/* ---- P1-P7 / F1-F3: fused conv / transposed-conv (implicit GEMM on MFMA) ---
+ *
+ * Replaces, on the reference path, the stock layers it runs via torch/cuDNN:
+ *   nn.Conv2d (+BatchNorm2d eval, +ReLU/LeakyReLU, +residual add)
+ *     lib/pose/models/resnet.py:19-23, blocks.py:89-119,
+ *     lib/flownet/networks/submodules.py:7-32
+ *   nn.ConvTranspose2d(k=4, s=2, p=1) (+BN, +ReLU / +bias, +LeakyReLU)
+ *     lib/pose/models/pose_deconv.py:19-28, submodules.py:34-38,
+ *     FlowNetS.py:42-45
+ *
+ *   y[n, oy, ox, co] = act( scale[co] * sum_{tap,ci} x[n, iy, ix, ci] * w[co,tap,ci]
+ *                           + shift[co] (+ residual[n, oy, ox, co]) )
+ *
+ * Activations are NHWC with an explicit channel stride/offset so producers can
+ * write straight into a channel slice of a concat buffer (torch.cat in
+ * FlowNetS.py:73-88 disappears).  Cin is rounded up to a multiple of 8 when
+ * reading: channels [Cin, roundup8(Cin)) of x must exist and be zero.
+ */
+typedef struct ft_conv_desc {
+  int dtype;       /* FT_F16 (fp16 storage, fp32 accumulate) or FT_F32 */
+  int N, Hi, Wi;   /* input batch / spatial size */
+  int Cin;         /* logical input channels */
+  int x_cstride;   /* elements between consecutive input pixels */
+  int x_coff;      /* first channel inside the pixel (multiple of 8) */
+  int Cout;        /* logical output channels */
+  int kh, kw;      /* kernel (transposed: must be 4,4) */
+  int stride, pad; /* conv: any; transposed: must be 2,1 */
+  int transposed;  /* 0 = Conv2d, 1 = ConvTranspose2d(4,2,1) */
+  int Ho, Wo;      /* output spatial size (validated against the formula) */
+  int y_cstride;   /* NHWC: elements between output pixels; NCHW: ignored */
+  int y_coff;      /* NHWC: first output channel inside the pixel (mult of 4) */
+  int out_layout;  /* FT_LAYOUT_NHWC (dtype) or FT_LAYOUT_NCHW_F32 */
+  int has_residual;
+  int res_cstride, res_coff; /* residual is NHWC, output geometry */
+  int act;         /* FT_ACT_* */
+  float slope;     /* LeakyReLU negative slope */
+} ft_conv_desc;
+
+/* Packed-weight geometry for `d`: w_packed is [nphases][Cout_pad][Kpad] of
+ * d->dtype with k = tap * Cin8 + ci (zeros in all padding). nphases is 1 for
+ * conv, 4 for the transposed conv (one 2x2 conv per output parity). */
+int ft_conv_pack_geometry(const ft_conv_desc* d, int* nphases, int* ntaps,
+                          int* cin8, int* cout_pad, int* kpad);
+/* Which original kernel element (ky, kx) tap `tap` of phase `phase` reads. */
+int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int* ky,
+                       int* kx);
+/* scale/shift: float[Cout_pad] or NULL (=> 1 / 0). residual may be NULL. */
+int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
+                  const float* scale, const float* shift, const void* residual,
+                  void* y, ft_stream_t stream);
+/* algorithmic FLOPs (2*MACs, unpadded) of one ft_conv2d_fwd call */
+double ft_conv_flops(const ft_conv_desc* d);
+
+/* ---- layout / pooling helpers -------------------------------------------- */
+/* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,W,cpad] (channels >= C zeroed).
+ * First step of DeconvResnet.forward (pose_deconv.py:32-33). */
+int ft_pack_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W,
+                         int cpad, int dtype, ft_stream_t stream);
+/* NHWC `dtype` (channel stride/offset) -> NCHW fp32 */
+int ft_unpack_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W,
+                           int x_cstride, int x_coff, int dtype,
+                           ft_stream_t stream);
+/* nn.MaxPool2d(3, 2, 1) on NHWC (resnet.py:23); C multiple of 8 */
+int ft_maxpool3x3s2_fwd(const void* x, void* y, int N, int Hi, int Wi, int C,
+                        int dtype, ft_stream_t stream);
+
+/* ---- P8/P9: heatmap -> keypoints ------------------------------------------
+ * max_preds + the adjust_coords nudge of final_preds
+ * (lib/pose/utils/evaluation.py:11-35): per (n,k) map the arg-max over H*W
+ * (first occurrence on ties), x = idx % W, y = idx / W (integer floor, torch
+ * 0.4 semantics), coords zeroed where score <= 0, optional +/-0.25 px nudge.
+ * heatmaps: NCHW fp32 [N,K,H,W]; idx int32 [N*K]; score fp32 [N*K];
+ * coords fp32 [N*K*2] (x,y in heatmap pixels, before transform_preds). */
+int ft_heatmap_max_preds(const float* heatmaps, int N, int K, int H, int W,
+                         int adjust_coords, int32_t* idx, float* score,
+                         float* coords, ft_stream_t stream);
+
+/* ---- F1: FlowNet2* input normalisation ------------------------------------
+ * rgb_mean over (pair,H,W) per (b,colour) then (x - mean) / rgb_max
+ * (lib/flownet/model/models.py:255-257).  inputs: fp32 [B,3,2,H,W].
+ * partial: float workspace [B*3*FT_RGB_MEAN_SPLITS]; mean: float [B*3]. */
+#define FT_RGB_MEAN_SPLITS 64
+int ft_flow_rgb_mean(const float* inputs, int B, int H, int W, float* partial,
+                     float* mean, ft_stream_t stream);
+/* mode 0: y = NHWC [B,H,W,8]   channels (r0,g0,b0,r1,g1,b1,0,0)   (FlowNet2S)
+ * mode 1: y = NHWC [2B,H,W,8]  images 0..B-1 = frame0, B..2B-1 = frame1,
+ *         channels (r,g,b,0...)                      (FlowNetC siamese trunk) */
+int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max,
+                      void* y, int B, int H, int W, int mode, int dtype,
+                      ft_stream_t stream);
+
+/* ---- F7: nn.Upsample(scale_factor=4, mode='bilinear') * mul ----------------
+ * (FlowNetS.py:58, models.py:292; align_corners=False).  NCHW fp32 in/out. */
+int ft_upsample_bilinear4x(const float* x, float* y, int N, int C, int h, int w,
+                           float mul, ft_stream_t stream);
+
+/* ---- F4: Correlation forward ---------------------------------------------
+ * Replaces Correlation_forward_cuda (correlation_package/src/correlation_cuda.c:11-93,
+ * kernels correlation_cuda_kernel.cu:10-106).  Same parameters and output
+ * geometry; no rInput scratch tensors (padding is implicit), NCHW fp32 in/out:
+ *   out[n, tj*D+ti, y, x] = 1/(k*k*C) * sum_{j,i,c} in1[n,c,y1+j,x1+i] * in2[n,c,y2+j,x2+i]
+ * corr_type_multiply must be 1 (the only mode the reference implements). */
+int ft_correlation_out_shape(int C, int H, int W, int pad_size, int kernel_size,
+                             int max_displacement, int stride1, int stride2,
+                             int* out_c, int* out_h, int* out_w);
+int ft_correlation_fwd(const float* in1, const float* in2, float* out, int B,
+                       int C, int H, int W, int pad_size, int kernel_size,
+                       int max_displacement, int stride1, int stride2,
+                       int corr_type_multiply, ft_stream_t stream);
+/* Fused in-network form (FlowNetC.py:86-92): NHWC `dtype` features in, the
+ * LeakyReLU'd cost volume written into channels [y_coff, y_coff+D*D) of an
+ * NHWC concat buffer.  kernel_size=1, stride1=1, pad=max_displacement. */
+int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, int B,
+                            int C, int H, int W, int max_displacement,
+                            int stride2, int f_cstride, int y_cstride,
+                            int y_coff, int act, float slope, int dtype,
+                            ft_stream_t stream);
+
+/* ---- F5: Resample2d forward (flow warp) ------------------------------------
+ * Replaces Resample2d_cuda_forward (resample2d_package/src/Resample2d_cuda.c,
+ * kernel Resample2d_kernel.cu:20-66); kernel_size is fixed at 1 as in
+ * modules/resample2d.py:8.  in1 [B,C,H,W], flow [B,2,H,W], out [B,C,H,W]. */
+int ft_resample2d_fwd(const float* in1, const float* flow, float* out, int B,
+                      int C, int H, int W, ft_stream_t stream);
+
+/* ---- F6: ChannelNorm forward ------------------------------------------------
+ * Replaces ChannelNorm_cuda_forward (channelnorm_package/src/ChannelNorm_cuda.c,
+ * kernel ChannelNorm_kernel.cu:19-51): out[b,0,y,x] = sqrt(sum_c in^2). */
+int ft_channelnorm_fwd(const float* in1, float* out, int B, int C, int H, int W,
+                       ft_stream_t stream);
+
+/* ---- F5+F6 fused stage between stacked FlowNets (models.py:396-403) -------
+ * From x6 = NHWC `dtype` [B,H,W,8] (normalised img0|img1) and flow NCHW fp32
+ * [B,2,H,W] (already multiplied by div_flow) builds the 12-channel input of the
+ * next FlowNetS: (img0, img1, warp(img1,flow), flow/div_flow, |img0-warp|)
+ * as NHWC `dtype` [B,H,W,16] (channels 12..15 zero). */
+int ft_flow_warp_concat(const void* x6, const float* flow, float div_flow,
+                        void* y, int B, int H, int W, int dtype,
+                        ft_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWTRACK_HIP_H_ */

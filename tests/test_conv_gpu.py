@@ -1,0 +1,103 @@
+"""HIP fused conv / transposed conv vs the CPU oracle for the stock layers (torch CPU fp32 functional —
+the arithmetic the reference itself runs for nn.Conv2d / ConvTranspose2d / BatchNorm2d),
+launched through the C ABI (ft_conv2d_fwd).  Shapes are the distinct layer kinds of SURVEY Appendix A."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from flowtrack.pytorch_amd import synth
+from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv
+from util import make_program, nchw_to_view, run_program, view_to_nchw
+
+pytestmark = pytest.mark.gpu
+
+# (name, N, Cin, H, W, Cout, k, stride, pad, transposed, bias, bn, act, residual)
+CASES = [
+    ("1x1_64_256", 2, 64, 16, 12, 256, 1, 1, 0, False, False, True, "relu", False),
+    ("1x1_res_relu", 2, 128, 16, 12, 512, 1, 1, 0, False, False, True, "relu", True),
+    ("1x1_s2_downsample", 2, 256, 16, 12, 512, 1, 2, 0, False, False, True, None, False),
+    ("3x3_s1", 2, 64, 16, 12, 64, 3, 1, 1, False, False, True, "relu", False),
+    ("3x3_s2", 3, 128, 16, 12, 128, 3, 2, 1, False, False, True, "relu", False),
+    ("3x3_ragged_m", 1, 64, 7, 5, 64, 3, 1, 1, False, False, True, "relu", False),
+    ("stem_7x7_cin3", 2, 3, 64, 48, 64, 7, 2, 3, False, False, True, "relu", False),
+    ("flow_7x7_cin6_leaky", 1, 6, 64, 64, 64, 7, 2, 3, False, True, False, "leaky", False),
+    ("flow_5x5_s2", 1, 64, 32, 32, 128, 5, 2, 2, False, True, False, "leaky", False),
+    ("flow_cin12", 1, 12, 32, 32, 64, 7, 2, 3, False, True, False, "leaky", False),
+    ("predict_flow_cin194", 1, 194, 16, 24, 2, 3, 1, 1, False, True, False, None, False),
+    ("conv_cin473", 1, 473, 8, 12, 256, 3, 1, 1, False, True, False, "leaky", False),
+    ("conv_redir_cout32", 1, 256, 8, 12, 32, 1, 1, 0, False, True, False, "leaky", False),
+    ("heatmap_cout17", 2, 256, 16, 12, 17, 1, 1, 0, False, True, False, None, False),
+    ("deconv_256", 2, 256, 8, 6, 256, 4, 2, 1, True, False, True, "relu", False),
+    ("deconv_2048_k8192", 1, 2048, 4, 3, 256, 4, 2, 1, True, False, True, "relu", False),
+    ("deconv_cin1026_bias_leaky", 1, 1026, 4, 6, 256, 4, 2, 1, True, True, False, "leaky", False),
+    ("upflow_2_2", 1, 2, 6, 8, 2, 4, 2, 1, True, False, False, None, False),
+    ("upflow_2_2_bias", 1, 2, 6, 8, 2, 4, 2, 1, True, True, False, None, False),
+    ("3x3_cout1024_k4608", 1, 512, 6, 8, 1024, 3, 2, 1, False, True, False, "leaky", False),
+]
+
+
+def _reference(x, w, bias, bn, stride, pad, transposed, act, res):
+    if transposed:
+        y = F.conv_transpose2d(x, w, bias, stride=stride, padding=pad)
+    else:
+        y = F.conv2d(x, w, bias, stride=stride, padding=pad)
+    if bn is not None:
+        y = F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], training=False, eps=1e-5)
+    if res is not None:
+        y = y + res
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "leaky":
+        y = F.leaky_relu(y, 0.1)
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_oracle(hip_lib, case, dtype):
+    name, N, Cin, H, W, Cout, k, stride, pad, transposed, has_bias, has_bn, act, has_res = case
+    dev = torch.device("cuda:0")
+    seed = 11
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    fan = (Cin * 4) if transposed else Cin * k * k
+    w = synth.normal(seed, name + ".w", wshape, std=(2.0 / fan) ** 0.5)
+    x = synth.normal(seed, name + ".x", (N, Cin, H, W))
+    bias = synth.normal(seed, name + ".b", (Cout,), std=0.2) if has_bias else None
+    bn = None
+    if has_bn:
+        bn = {"weight": synth.uniform(seed, name + ".g", (Cout,), 0.5, 1.5), "bias": synth.normal(seed, name + ".be", (Cout,), 0.1),
+              "running_mean": synth.normal(seed, name + ".m", (Cout,), 0.1), "running_var": synth.uniform(seed, name + ".v", (Cout,), 0.5, 1.5),
+              "eps": 1e-5}
+    if dtype == torch.float16:  # the oracle sees the same fp16-rounded operands, accumulates in fp32
+        w, x = w.half().float(), x.half().float()
+    layer = FusedConv(w, dtype=dtype, device=dev, stride=stride, pad=pad, transposed=transposed, bias=bias, bn=bn, act=act,
+                      slope=0.1, label=name)
+    Ho, Wo = layer.out_hw(H, W)
+    res = None
+    if has_res:
+        res = synth.normal(seed, name + ".r", (N, Cout, Ho, Wo))
+        if dtype == torch.float16:
+            res = res.half().float()
+    want = _reference(x, w, bias, bn, stride, pad, transposed, act, res)
+
+    xv = nchw_to_view(x, dtype, dev)
+    # write into a channel slice of a wider buffer whose other channels must stay untouched
+    ycs = ((Cout + 8 + 7) // 8) * 8 + 8
+    ybuf = torch.full((N, Ho, Wo, ycs), 7.0, dtype=dtype, device=dev)
+    yv = ActView(ybuf, Cout, 8)
+    prog = make_program()
+    layer.record(prog, xv, yv, residual=nchw_to_view(res, dtype, dev) if res is not None else None)
+    # and the NCHW fp32 output form
+    y_nchw = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+    layer.record(prog, xv, y_nchw, residual=nchw_to_view(res, dtype, dev) if res is not None else None)
+    run_program(prog)
+
+    got = view_to_nchw(yv)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    err_nchw = (y_nchw.cpu() - want).abs().max().item()
+    assert err <= tol * scale, f"{name} {dtype}: NHWC max abs err {err:.3e} (scale {scale:.2f})"
+    assert err_nchw <= (2e-4 if dtype == torch.float32 else 2e-3) * scale, f"{name} {dtype}: NCHW max abs err {err_nchw:.3e}"
+    # guard channels around the slice untouched
+    assert torch.all(ybuf[..., :8] == 7.0) and torch.all(ybuf[..., 8 + Cout:] == 7.0), "wrote outside its channel slice"

@@ -1,0 +1,106 @@
+"""Whole pose network on the GPU (through the C ABI) vs the committed goldens written by the imported
+reference (tests/golden/make_golden.py) and vs the CPU oracle run live on the same seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from flowtrack.pytorch_amd import synth
+from flowtrack.pytorch_amd.pose import evaluation, models
+from oracle import keypoints_ref, pose_ref
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(GOLDEN, "pose_golden.npz"))
+SEED = int(G["seed"])
+
+
+def _model(depth, dtype):
+    m = models.deconv(f"resnet{depth}", num_classes=17, pretrained=False)
+    sd = synth.fill_pose_state_dict(m.state_dict(), SEED)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    return m, sd
+
+
+@pytest.mark.parametrize("depth", [50, 101])
+def test_pose_fp32_matches_reference_golden(hip_lib, depth):
+    """north_star bar: <= 1e-3 max-abs on fp32 heatmaps and identical arg-max indices."""
+    B, H, W = (int(v) for v in G[f"r{depth}_shape"])
+    m, sd = _model(depth, torch.float32)
+    x = synth.pose_crops(SEED, B, H, W)
+    hm = m(x.cuda()).cpu()
+    want = pose_ref.pose_forward(sd, x, depth=depth)          # live oracle (pinned == reference)
+    err = (hm - want).abs().max().item()
+    assert err <= 1e-3, f"r{depth} fp32 heatmap max abs err {err:.3e}"
+    if depth == 50:
+        gerr = np.abs(hm[:2].numpy() - G["r50_heatmaps_b2"]).max()
+        assert gerr <= 1e-3, f"vs committed reference heatmaps: {gerr:.3e}"
+    # arg-max bit-exact (integer result), scores within tolerance
+    _, scores, coords = evaluation.heatmap_max_preds(hm.cuda(), adjust_coords=False)
+    idx = (coords[..., 1] * hm.shape[3] + coords[..., 0]).long().cpu().numpy()
+    pos = G[f"r{depth}_scores"][..., 0] > 0
+    assert np.array_equal(idx[pos], G[f"r{depth}_idx"][pos]), "arg-max keypoint indices differ from the reference"
+    assert np.abs(scores.cpu().numpy() - G[f"r{depth}_scores"]).max() <= 1e-3
+    # second call replays the captured HIP graph: identical bits
+    hm2 = m(x.cuda()).cpu()
+    assert torch.equal(hm, hm2)
+
+
+@pytest.mark.parametrize("adjust", [False, True])
+def test_final_preds_device_path(hip_lib, adjust):
+    """ft_heatmap_max_preds + host transform == reference final_preds (0.4 semantics) on reference heatmaps."""
+    hm = torch.from_numpy(G["r50_heatmaps_b2"])
+    center, scale = G["r50_center"][:2], G["r50_scale"][:2]
+    coords, scores = evaluation.final_preds(hm.cuda(), center, scale, adjust_coords=adjust)
+    assert np.allclose(coords, G[f"r50_final_coords_adjust{int(adjust)}"][:2], atol=1e-3)
+    assert np.array_equal(scores, G["r50_scores"][:2])
+    c2, s2 = evaluation.max_preds(hm.cuda())
+    oc, os_, oi = keypoints_ref.max_preds_ref(hm.numpy())
+    assert np.array_equal(c2, oc) and np.array_equal(s2, os_)
+
+
+def test_max_preds_edge_cases(hip_lib):
+    """ties -> first occurrence; all-negative map -> coords zeroed; border maxima get no nudge."""
+    hm = torch.full((1, 4, 8, 6), -1.0)
+    hm[0, 0, 2, 3] = 5.0
+    hm[0, 0, 5, 1] = 5.0            # tie: the row-major first one (2,3) wins
+    hm[0, 2, 0, 0] = 3.0            # border maximum
+    hm[0, 3, 4, 2] = 2.0; hm[0, 3, 4, 3] = 1.0; hm[0, 3, 3, 2] = 1.5   # interior: nudge +x, -y
+    idx, score, coords = evaluation.heatmap_max_preds(hm.cuda(), adjust_coords=True)
+    idx, score, coords = idx.cpu().numpy()[0], score.cpu().numpy()[0, :, 0], coords.cpu().numpy()[0]
+    assert idx[0] == 2 * 6 + 3 and score[0] == 5.0
+    assert score[1] == -1.0 and tuple(coords[1]) == (0.0, 0.0) and idx[1] == 0
+    assert tuple(coords[2]) == (0.0, 0.0) and idx[2] == 0 and score[2] == 3.0
+    assert tuple(coords[3]) == (2.25, 3.75)
+    oc, os_, oi, pre = keypoints_ref.final_preds_ref(hm.numpy(), np.array([[0.0, 0.0]]), np.array([8.0]), adjust_coords=True)
+    assert np.array_equal(pre[0], coords)
+
+
+def test_pose_fp16_vs_fp32_oracle(hip_lib):
+    """fp16 storage / fp32 accumulate (configs C2): report error and arg-max agreement vs the fp32 CPU
+    oracle. Bar: max-abs <= 5e-2 of the heatmap range, >= 90 % identical arg-max, and every mismatch
+    must be a near-tie (reference top-1/top-2 margin below the fp16 error)."""
+    B, H, W = (int(v) for v in G["r50_shape"])
+    m, sd = _model(50, torch.float16)
+    x = synth.pose_crops(SEED, B, H, W)
+    hm = m(x.cuda()).cpu()
+    want = pose_ref.pose_forward(sd, x, depth=50)
+    err = (hm - want).abs().max().item()
+    rng = (want.max() - want.min()).item()
+    assert err <= 5e-2 * rng, f"fp16 heatmap error {err:.3e} vs range {rng:.2f}"
+    oc, os_, oi = keypoints_ref.max_preds_ref(hm.numpy())
+    same = oi == G["r50_idx"]
+    assert same.mean() >= 0.9, f"only {same.mean():.3f} of arg-max indices match"
+    margin = G["r50_margin"]
+    assert np.all(margin[~same] <= 2 * err + 1e-6), "an arg-max flip that is not explained by a near-tie"
+    # mAP@OKS with the CPU-reference keypoints as annotations
+    center, scale = G["r50_center"], G["r50_scale"]
+    coords, scores = evaluation.final_preds(hm.cuda(), center, scale, adjust_coords=True)
+    pred = np.concatenate((coords, scores), axis=2)
+    anno = np.concatenate((G["r50_final_coords_adjust1"], np.ones_like(scores)), axis=2)
+    ap = evaluation.eval_mAP([pred], [anno], [scale * scale], evaluation.COCO_DELTA)
+    print("fp16 max abs err", err, "argmax match", same.mean(), "AP@OKS", ap)
+    assert ap[0] >= 0.99
