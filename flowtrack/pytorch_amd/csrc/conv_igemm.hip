@@ -74,15 +74,19 @@ __device__ __forceinline__ void mma_slice(const uint4_t (&a)[MT_C], const uint4_
 template <int MT_C, int MT_P>
 __device__ __forceinline__ void mma_slice(const uint4_t (&a)[MT_C], const uint4_t (&b)[MT_P],
                                           float16_t (&acc)[MT_C][MT_P], float*) {
+  // whole-vector bit casts: __builtin_bit_cast on a single vector ELEMENT lvalue reads element 0
+  float4_t af[MT_C], bf[MT_P];
+#pragma unroll
+  for (int i = 0; i < MT_C; ++i) af[i] = __builtin_bit_cast(float4_t, a[i]);
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j) bf[j] = __builtin_bit_cast(float4_t, b[j]);
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int i = 0; i < MT_C; ++i)
 #pragma unroll
       for (int j = 0; j < MT_P; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[i][e]),
-                                                         __builtin_bit_cast(float, b[j][e]),
-                                                         acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
 }
 
 __device__ __forceinline__ void store4(half_t* dst, const float (&v)[4]) {

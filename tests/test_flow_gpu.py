@@ -1,0 +1,201 @@
+"""FlowNet2 operators and networks on the GPU (through the C ABI) vs the CPU oracle and the goldens
+written by the imported reference.  Tolerances: fp32 ops 1e-4..1e-3 max-abs (north_star: 1e-3)."""
+import ctypes
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from flowtrack.pytorch_amd import _lib, synth
+from flowtrack.pytorch_amd._lib import check
+from flowtrack.pytorch_amd.flownet import models
+from oracle import flow_ref, ops_ref
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(GOLDEN, "flow_golden.npz"))
+SEED = int(G["seed"])
+ARGS = types.SimpleNamespace(rgb_max=255.0, fp16=False)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+# ---- operators ------------------------------------------------------------------------------------
+CORR_CASES = [
+    # B, C, H, W, pad, k, max_disp, s1, s2
+    (2, 16, 12, 14, 4, 1, 4, 1, 2),      # FlowNetC-like, small
+    (1, 256, 12, 16, 20, 1, 20, 1, 2),   # FlowNetC parameters (FlowNetC.py:31), reduced spatial size
+    (1, 8, 10, 9, 3, 3, 2, 1, 1),        # kernel_size 3
+    (1, 8, 16, 15, 4, 1, 4, 2, 2),       # stride1 2
+    (1, 5, 9, 11, 2, 1, 3, 1, 1),        # pad < max_disp: output smaller than input
+]
+
+
+@pytest.mark.parametrize("case", CORR_CASES, ids=[str(c) for c in CORR_CASES])
+def test_correlation_nchw(hip_lib, oracle_lib, case):
+    B, C, H, W, pad, k, d, s1, s2 = case
+    a = synth.normal(3, "corr_a", (B, C, H, W)).numpy()
+    b = synth.normal(3, "corr_b", (B, C, H, W)).numpy()
+    want = ops_ref.correlation_c(a, b, pad, k, d, s1, s2)
+    oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(hip_lib.ft_correlation_out_shape(C, H, W, pad, k, d, s1, s2, ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow)))
+    assert (B, oc.value, oh.value, ow.value) == want.shape
+    ga, gb = _cuda(a), _cuda(b)
+    out = torch.full(want.shape, 9.0, dtype=torch.float32, device="cuda")
+    check(hip_lib.ft_correlation_fwd(ga.data_ptr(), gb.data_ptr(), out.data_ptr(), B, C, H, W, pad, k, d, s1, s2, 1, _stream()))
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - want).max()
+    assert err <= 1e-5, f"max abs err {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 256, 12, 16), (2, 64, 9, 37)], ids=["c256", "ragged"])
+def test_correlation_nhwc_fused(hip_lib, oracle_lib, dtype, shape):
+    """in-network form: NHWC features -> LeakyReLU'd cost volume in a channel slice of the concat buffer."""
+    B, C, H, W = shape
+    a = synth.normal(4, "corr_a", shape)
+    b = synth.normal(4, "corr_b", shape)
+    if dtype == torch.float16:
+        a, b = a.half().float(), b.half().float()
+    want = ops_ref.correlation_c(a.numpy(), b.numpy(), 20, 1, 20, 1, 2)
+    want = np.where(want > 0, want, 0.1 * want)
+    fa = a.permute(0, 2, 3, 1).contiguous().to("cuda", dtype)
+    fb = b.permute(0, 2, 3, 1).contiguous().to("cuda", dtype)
+    y = torch.full((B, H, W, 480), 5.0, dtype=dtype, device="cuda")
+    check(hip_lib.ft_correlation_nhwc_fwd(fa.data_ptr(), fb.data_ptr(), y.data_ptr(), B, C, H, W, 20, 2, C, 480, 32,
+                                          _lib.FT_ACT_LEAKY, 0.1, _lib.dtype_code(dtype), _stream()))
+    torch.cuda.synchronize()
+    got = y[..., 32:32 + 441].permute(0, 3, 1, 2).float().cpu().numpy()
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert np.abs(got - want).max() <= tol
+    assert torch.all(y[..., :32] == 5.0) and torch.all(y[..., 473:] == 5.0)
+
+
+def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
+    B, C, H, W = 2, 3, 24, 40
+    img = synth.normal(5, "img", (B, C, H, W)).numpy()
+    flow = synth.flow_field(5, B, H, W, magnitude=6.0).numpy()
+    flow[0, :, 0, 0] = (-100.0, 250.0)  # far out of frame: border clamp, weights NOT renormalised
+    flow[1, :, 3, 3] = (0.0, 0.0)
+    want = ops_ref.resample2d_c(img, flow)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device="cuda")
+    check(hip_lib.ft_resample2d_fwd(_cuda(img).data_ptr(), _cuda(flow).data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-5
+    # zero flow is the identity; integer flow is a shift
+    zero = torch.zeros((B, 2, H, W), device="cuda")
+    check(hip_lib.ft_resample2d_fwd(_cuda(img).data_ptr(), zero.data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), img)
+    nrm = torch.empty((B, 1, H, W), dtype=torch.float32, device="cuda")
+    check(hip_lib.ft_channelnorm_fwd(_cuda(img).data_ptr(), nrm.data_ptr(), B, C, H, W, _stream()))
+    torch.cuda.synchronize()
+    assert np.abs(nrm.cpu().numpy() - ops_ref.channelnorm_c(img)).max() <= 1e-6
+
+
+def test_upsample_and_normalise(hip_lib, oracle_lib):
+    x = synth.normal(6, "flow2", (2, 2, 6, 9)).numpy()
+    y = torch.empty((2, 2, 24, 36), dtype=torch.float32, device="cuda")
+    check(hip_lib.ft_upsample_bilinear4x(_cuda(x).data_ptr(), y.data_ptr(), 2, 2, 6, 9, 20.0, _stream()))
+    torch.cuda.synchronize()
+    want = torch.nn.functional.interpolate(torch.from_numpy(x) * 20.0, scale_factor=4, mode="bilinear", align_corners=False).numpy()
+    assert np.abs(y.cpu().numpy() - want).max() <= 1e-5
+    assert np.abs(y.cpu().numpy() - ops_ref.upsample4x_c(x, 20.0)).max() <= 1e-5
+    # rgb mean + (x - mean) / rgb_max, both packings
+    B, H, W = 2, 64, 64
+    pair = synth.frame_pairs(6, B, H, W)
+    gp = pair.cuda()
+    partial = torch.empty(B * 3 * _lib.FT_RGB_MEAN_SPLITS, device="cuda")
+    mean = torch.empty(B * 3, device="cuda")
+    check(hip_lib.ft_flow_rgb_mean(gp.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(), _stream()))
+    want_mean = pair.view(B, 3, -1).mean(-1)
+    torch.cuda.synchronize()
+    assert (mean.cpu().view(B, 3) - want_mean).abs().max() <= 1e-3
+    xn = flow_ref._normalise(pair, 255.0)
+    for mode in (0, 1):
+        n = B if mode == 0 else 2 * B
+        buf = torch.full((n, H, W, 8), 3.0, device="cuda")
+        check(hip_lib.ft_flow_pack_pair(gp.data_ptr(), mean.data_ptr(), 255.0, buf.data_ptr(), B, H, W, mode, _lib.FT_F32, _stream()))
+        torch.cuda.synchronize()
+        got = buf.cpu()
+        if mode == 0:
+            want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 1).permute(0, 2, 3, 1)
+            assert (got[..., :6] - want).abs().max() <= 1e-5 and torch.all(got[..., 6:] == 0)
+        else:
+            want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 0).permute(0, 2, 3, 1)
+            assert (got[..., :3] - want).abs().max() <= 1e-5 and torch.all(got[..., 3:] == 0)
+
+
+# ---- networks -------------------------------------------------------------------------------------
+def _build(cls, seed, dtype, **kw):
+    m = cls(ARGS, **kw)
+    sd = synth.fill_flow_state_dict(m.state_dict(), seed)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    return m, sd
+
+
+def test_flownet2s_fp32_matches_reference_golden(hip_lib):
+    m, sd = _build(models.FlowNet2S, SEED, torch.float32)
+    B, H, W = (int(v) for v in G["synth_shape"])
+    pair = synth.frame_pairs(SEED, B, H, W)
+    flow = m(pair.cuda()).cpu().numpy()
+    err = np.abs(flow - G["synth_flow"]).max()
+    assert err <= 1e-3, f"synthetic pair: max abs err {err:.3e} px"
+    # the reference's real demo pair (centre crop), demo.py:83-90 packing
+    ims = torch.from_numpy(G["sample_pair_u8"][None].transpose(0, 4, 1, 2, 3).astype(np.float32))
+    flow = m(ims.cuda()).cpu().numpy()
+    err = np.abs(flow - G["sample_flow"]).max()
+    assert err <= 1e-3, f"sample pair: max abs err {err:.3e} px"
+
+
+def test_flownet2s_batchnorm_variant(hip_lib):
+    m, sd = _build(models.FlowNet2S, SEED + 1, torch.float32, batchNorm=True)
+    B, H, W = (int(v) for v in G["synth_shape"])
+    flow = m(synth.frame_pairs(SEED, B, H, W).cuda()).cpu().numpy()
+    assert np.abs(flow - G["synth_flow_bn"]).max() <= 2e-3
+
+
+@pytest.mark.parametrize("name", ["FlowNet2C", "FlowNet2CS"])
+def test_flownet2c_cs_fp32_vs_oracle(hip_lib, oracle_lib, name):
+    m, sd = _build(getattr(models, name), SEED + 2, torch.float32)
+    pair = synth.frame_pairs(SEED + 2, 2, 128, 192)
+    flow = m(pair.cuda()).cpu()
+    fwd = flow_ref.flownet2c_forward if name == "FlowNet2C" else flow_ref.flownet2cs_forward
+    want = fwd(sd, pair)
+    err = (flow - want).abs().max().item()
+    print(name, "flow range", want.min().item(), want.max().item(), "err", err)
+    assert err <= 1e-3, f"{name}: max abs err {err:.3e} px"
+
+
+@pytest.mark.parametrize("name", ["FlowNet2S", "FlowNet2C", "FlowNet2CS"])
+def test_flownet_fp16_vs_fp32_oracle(hip_lib, oracle_lib, name):
+    """pseudo-fp16 mode (fp16 storage, fp32 accumulate; tools/flownet/demo.py --fp16): EPE vs the fp32 oracle."""
+    m, sd = _build(getattr(models, name), SEED + 3, torch.float16)
+    pair = synth.frame_pairs(SEED + 3, 1, 128, 192)
+    flow = m(pair.cuda()).cpu()
+    want = {"FlowNet2S": flow_ref.flownet2s_forward, "FlowNet2C": flow_ref.flownet2c_forward,
+            "FlowNet2CS": flow_ref.flownet2cs_forward}[name](sd, pair)
+    e = flow_ref.epe(flow, want)
+    mag = torch.norm(want, dim=1).mean().item()
+    print(name, "fp16 EPE", e, "mean |flow|", mag)
+    assert e <= 0.02 * max(mag, 1.0) + 0.05
+
+
+def test_model_half_is_fp16_mode(hip_lib):
+    """model.half() (demo.py:69-70) selects the fp16 path; output stays fp32 [B,2,H,W]."""
+    m, sd = _build(models.FlowNet2S, SEED, torch.float32)
+    m.compute_dtype = None
+    m = m.half()
+    pair = synth.frame_pairs(SEED, 1, 64, 64)
+    out = m(pair.cuda())
+    assert out.dtype == torch.float32 and tuple(out.shape) == (1, 2, 64, 64) and torch.isfinite(out).all()

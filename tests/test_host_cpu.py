@@ -1,0 +1,121 @@
+"""CPU suite: host-side logic (metrics port, C-ABI surface, weight packing geometry, error behaviour)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from flowtrack.pytorch_amd import _lib
+from flowtrack.pytorch_amd._lib import ConvDesc, FlowtrackHipError
+from flowtrack.pytorch_amd.pose import evaluation
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    header = open(os.path.join(ROOT, "include", "flowtrack_hip.h")).read()
+    declared = set(re.findall(r"\b(ft_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(hip_lib, name), f"{name} declared in flowtrack_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert hip_lib.ft_version() >= 100
+    assert hip_lib.ft_status_string(1) == b"invalid argument"
+
+
+def test_conv_desc_struct_matches_header():
+    header = open(os.path.join(ROOT, "include", "flowtrack_hip.h")).read()
+    body = header[header.index("typedef struct ft_conv_desc {"):header.index("} ft_conv_desc;")]
+    fields = []
+    for line in body.splitlines()[1:]:
+        line = line.split("/*")[0].strip()
+        m = re.match(r"(int|float)\s+(.*);", line)
+        if m:
+            fields += [(n.strip(), m.group(1)) for n in m.group(2).split(",")]
+    assert [f[0] for f in fields] == [f[0] for f in ConvDesc._fields_]
+    assert all((c is ctypes.c_float) == (t == "float") for (_, t), (_, c) in zip(fields, ConvDesc._fields_))
+
+
+def _desc(**kw):
+    d = ConvDesc()
+    base = dict(dtype=0, N=1, Hi=16, Wi=16, Cin=64, x_cstride=64, x_coff=0, Cout=64, kh=3, kw=3, stride=1, pad=1, transposed=0,
+                Ho=16, Wo=16, y_cstride=64, y_coff=0, out_layout=0, act=0)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_pack_geometry_and_tap_table(hip_lib):
+    out = [ctypes.c_int() for _ in range(5)]
+    g = lambda d: (hip_lib.ft_conv_pack_geometry(ctypes.byref(d), *[ctypes.byref(o) for o in out]), [o.value for o in out])
+    st, (nph, ntaps, cin8, cout_pad, kpad) = g(_desc())
+    assert st == 0 and (nph, ntaps, cin8, cout_pad) == (1, 9, 64, 64) and kpad == 9 * 64
+    st, (nph, ntaps, cin8, cout_pad, kpad) = g(_desc(Cin=3, x_cstride=8, kh=7, kw=7, stride=2, pad=3, Ho=8, Wo=8))
+    assert st == 0 and (ntaps, cin8) == (49, 8) and kpad % 32 == 0 and kpad >= 49 * 8
+    st, (nph, ntaps, cin8, cout_pad, kpad) = g(_desc(Cin=1026, x_cstride=1032, Cout=256, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=32, Wo=32, y_cstride=256))
+    assert st == 0 and (nph, ntaps, cin8, cout_pad) == (4, 4, 1032, 256)
+    # transposed tap table: out[2q+p] <- in[q + p - t] * W[k], k = 1+2t (p=0) | 2t (p=1); each (ky,kx) exactly once
+    d = _desc(kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=32, Wo=32)
+    seen = set()
+    ky, kx = ctypes.c_int(), ctypes.c_int()
+    for ph in range(4):
+        for t in range(4):
+            assert hip_lib.ft_conv_tap_source(ctypes.byref(d), ph, t, ctypes.byref(ky), ctypes.byref(kx)) == 0
+            assert (ky.value + 1) % 2 == ph >> 1 and (kx.value + 1) % 2 == ph & 1
+            seen.add((ky.value, kx.value))
+    assert len(seen) == 16
+    assert hip_lib.ft_conv_flops(ctypes.byref(_desc())) == 2.0 * 16 * 16 * 64 * 64 * 9
+
+
+def test_bad_arguments_return_status_not_abort(hip_lib):
+    z = [ctypes.byref(ctypes.c_int()) for _ in range(5)]
+    assert hip_lib.ft_conv_pack_geometry(ctypes.byref(_desc(Ho=15)), *z) == 1          # inconsistent output size
+    assert hip_lib.ft_conv_pack_geometry(ctypes.byref(_desc(x_cstride=60)), *z) == 1   # unaligned channel stride
+    assert hip_lib.ft_conv_pack_geometry(ctypes.byref(_desc(kh=3, kw=3, transposed=1, Ho=32, Wo=32)), *z) == 2
+    assert hip_lib.ft_conv2d_fwd(ctypes.byref(_desc()), None, None, None, None, None, None, None) == 1
+    assert hip_lib.ft_correlation_fwd(None, None, None, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, None) == 1
+    assert hip_lib.ft_resample2d_fwd(None, None, None, 1, 1, 1, 1, None) == 1
+    oc = ctypes.c_int(); oh = ctypes.c_int(); ow = ctypes.c_int()
+    assert hip_lib.ft_correlation_out_shape(256, 48, 64, 20, 1, 20, 1, 2, ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow)) == 0
+    assert (oc.value, oh.value, ow.value) == (441, 48, 64)
+
+
+def test_product_path_fails_loudly_without_gpu(hip_lib):
+    """no CPU fallback: a CPU model / tensor raises instead of silently computing somewhere else."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from flowtrack.pytorch_amd.pose import models
+    m = models.deconv("resnet50", 17, False).eval()
+    with pytest.raises(FlowtrackHipError):
+        m(torch.zeros(1, 3, 256, 192))
+    with pytest.raises(FlowtrackHipError):
+        evaluation.max_preds(torch.zeros(1, 17, 64, 48))
+
+
+def test_training_mode_is_rejected():
+    from flowtrack.pytorch_amd.pose import models
+    m = models.deconv("resnet50", 17, False)
+    with pytest.raises(FlowtrackHipError):
+        m(torch.zeros(1, 3, 256, 192))
+
+
+def test_oks_metric_port_matches_reference_vectors():
+    G = np.load(os.path.join(GOLDEN, "oks_golden.npz"))
+    d = evaluation.COCO_DELTA
+    assert np.allclose(evaluation.compute_oks(G["pred"], G["anno"], G["ref_scale"], d), G["oks"], atol=1e-12)
+    ap = evaluation.eval_mAP([G["pred"][:3], G["pred"][3:]], [G["anno"][:3], G["anno"][3:]], [G["ref_scale"][:3], G["ref_scale"][3:]], d)
+    assert np.allclose(ap, G["ap"])
+    preds = [{"score": float(s), "joints": j, "area": float(a)} for s, j, a in zip(G["nms_scores"], G["nms_joints"], G["nms_areas"])]
+    assert list(evaluation.nms_oks(preds, 0.9, d)) == list(G["nms_keep"])
+
+
+def test_transform_preds_is_inverse_of_crop_affine():
+    c, s, res = np.array([[100.0, 140.0]]), np.array([220.0]), (64, 48)
+    t = evaluation.get_transform(c[0], s[0], res)
+    pts = np.array([[[10.0, 20.0], [0.0, 0.0], [47.0, 63.0]]])
+    img = evaluation.transform_preds(pts.copy(), c, s, res)
+    back = (t @ np.concatenate((img[0], np.ones((3, 1))), 1).T)[:2].T
+    assert np.allclose(back, pts[0])
+    assert np.allclose(evaluation.transform_preds(np.array([[[24.0, 32.0]]]), c, s, res), c)   # heatmap centre -> box centre
