@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the FlowTrack hot path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the pose hot path over one batch that is already resident in HBM:
+NCHW fp32 crops -> NHWC pack -> ResNet-50 + 3x deconv + heatmap conv (HIP graph) -> per-map arg-max /
+sub-pixel nudge (ft_heatmap_max_preds) [-> RCCL all-gather of the keypoint rows when N > 1].
+Workload = BASELINE.json configs[1]: ResNet-50 pose head, fp16, batch 64 x 256x192 per GPU (weak scaling).
+`--workload flow` times FlowNet2S on configs[3]'s 16 x 512x384 frame pairs instead (pairs/s).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from flowtrack.pytorch_amd import parallel, synth  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_pose(device, dtype, seed=1234):
+    from flowtrack.pytorch_amd.pose import models
+    m = models.deconv("resnet50", num_classes=17, pretrained=False)
+    m.load_state_dict(synth.fill_pose_state_dict(m.state_dict(), seed))
+    m = m.to(device).eval()
+    m.compute_dtype = dtype
+    return m
+
+
+def build_flow(device, dtype, seed=1234):
+    from flowtrack.pytorch_amd.flownet import models
+    m = models.FlowNet2S(types.SimpleNamespace(rgb_max=255.0, fp16=dtype == torch.float16))
+    m.load_state_dict(synth.fill_flow_state_dict(m.state_dict(), seed))
+    m = m.to(device).eval()
+    m.compute_dtype = dtype
+    return m
+
+
+def conv_roofline(prog, dtype_name, iters=5):
+    """Per-launch hipEvent timing of the plan on its own stream; aggregates the implicit-GEMM launches."""
+    times = prog.time_calls(iters=iters)
+    conv_ms = sum(ms for name, ms in times if name == "ft_conv2d_fwd")
+    total_ms = sum(ms for _, ms in times)
+    n_conv = sum(1 for name, _ in times if name == "ft_conv2d_fwd")
+    flops = prog.flops
+    achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[dtype_name]
+    per_layer = []
+    for label, call_idx, fl in prog.conv_records:
+        ms = times[call_idx][1]
+        per_layer.append((label, fl, ms))
+    return {
+        "bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations)", "achieved": round(achieved, 2), "peak": peak,
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        "launches_per_step": n_conv, "flop_per_launch_avg": flops / max(n_conv, 1),
+        "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
+        "conv_ms_per_step": round(conv_ms, 4), "all_kernels_ms_per_step_eager_events": round(total_ms, 4),
+    }, per_layer
+
+
+def cpu_baseline_pose(seconds=15.0):
+    """The CPU oracle (the reference's own torch-CPU arithmetic, oracle/pose_ref.py) on this host:
+    ResNet-50 head, batch 4 x 256x192 fp32 (BASELINE configs[0]), all host cores."""
+    from flowtrack.pytorch_amd.pose import models
+    from oracle import pose_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = models.deconv("resnet50", 17, False)
+    sd = synth.fill_pose_state_dict(m.state_dict(), 1234)
+    x = synth.pose_crops(1, 4)
+    pose_ref.pose_forward(sd, x)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        pose_ref.pose_forward(sd, x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": round(4 * n / el, 2), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forwards of batch 4 x 3x256x192 fp32 (BASELINE configs[0]) in {el:.1f} s, torch CPU {torch.__version__}, "
+                      f"{torch.get_num_threads()} threads"}
+
+
+def cpu_baseline_flow(seconds=15.0):
+    from flowtrack.pytorch_amd.flownet import models
+    from oracle import flow_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = models.FlowNet2S(types.SimpleNamespace(rgb_max=255.0, fp16=False))
+    sd = synth.fill_flow_state_dict(m.state_dict(), 1234)
+    x = synth.frame_pairs(1, 1, 384, 512)
+    flow_ref.flownet2s_forward(sd, x)
+    t0, n = time.perf_counter(), 0
+    while True:
+        flow_ref.flownet2s_forward(sd, x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 100:
+            break
+    return {"value": round(n / el, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} FlowNet2S forwards of 1 x 3x2x384x512 fp32 in {el:.1f} s, torch CPU, {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["pose", "flow"], default="pose")
+    ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 crops / 16 pairs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    args = ap.parse_args()
+
+    rank, local_rank, world = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dtype = torch.float16 if args.dtype == "fp16" else torch.float32
+
+    from flowtrack.pytorch_amd.hip_ops import heatmap_max_preds
+
+    if args.workload == "pose":
+        B = args.batch or 64
+        model = build_pose(device, dtype)
+        x = synth.pose_crops(100 + rank, B).to(device)          # resident in HBM before the timed region
+        unit, metric = "crops/s", "pose crops/sec (ResNet-50 + 3-deconv head, 256x192)"
+        kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
+
+        def step():
+            hm = model(x, copy_output=False)
+            _, score, coords = heatmap_max_preds(hm, adjust_coords=True)
+            rows = torch.cat((coords, score), dim=2)            # [B,17,3] keypoint rows
+            rows = parallel.all_gather_rows(rows, B * world) if world > 1 else rows
+            kp_host.copy_(rows[rank * B:(rank + 1) * B] if world > 1 else rows, non_blocking=True)
+            return rows
+        workload = f"ResNet-50 pose head {args.dtype}, batch {B} x 256x192 synthetic crops per GPU (BASELINE.json configs[1])"
+    else:
+        B = args.batch or 16
+        model = build_flow(device, dtype)
+        x = synth.frame_pairs(100 + rank, B).to(device)
+        unit, metric = "pairs/s", "flow frame-pairs/sec (FlowNet2S, 512x384)"
+
+        def step():
+            flow = model(x, copy_output=False)
+            return parallel.all_gather_rows(flow, B * world) if world > 1 else flow
+        workload = f"FlowNet2S {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU (BASELINE.json configs[3])"
+
+    for _ in range(max(args.warmup, 2)):   # >= 2: first run is eager + graph capture, second replays the graph
+        step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+
+    value = B * world * args.steps / elapsed
+    out = {
+        "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (counter-hash crops ~N(0,1) / translated-texture frame pairs, He-scaled random weights)",
+        "config": {"workload": workload, "per_gpu_batch": B,
+                   "parallelism": f"dp{world}: batch sharded, one process per GPU" + (", RCCL all-gather of outputs" if world > 1 else "")},
+    }
+    if rank == 0:
+        plan = next(iter(model._plans.values()))
+        out["gflop_per_unit"] = round(plan.prog.flops / B / 1e9, 3)
+        out["achieved_tflops_end_to_end"] = round(value / world * plan.prog.flops / B / 1e12, 2)
+        if not args.no_roofline:
+            roof, per_layer = conv_roofline(plan.prog, args.dtype)
+            out["roofline"] = roof
+            if args.layers:
+                for label, fl, ms in per_layer:
+                    print(f"  {label:28s} {fl / 1e9:9.2f} GFLOP {ms * 1e3:9.1f} us {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TF/s",
+                          file=sys.stderr)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_pose() if args.workload == "pose" else cpu_baseline_flow()
+        print(json.dumps(out), flush=True)
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main()

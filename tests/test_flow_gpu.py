@@ -87,16 +87,17 @@ def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
     flow[1, :, 3, 3] = (0.0, 0.0)
     want = ops_ref.resample2d_c(img, flow)
     out = torch.empty((B, C, H, W), dtype=torch.float32, device="cuda")
-    check(hip_lib.ft_resample2d_fwd(_cuda(img).data_ptr(), _cuda(flow).data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
+    gimg, gflow = _cuda(img), _cuda(flow)   # keep the device buffers alive across the async launches
+    check(hip_lib.ft_resample2d_fwd(gimg.data_ptr(), gflow.data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - want).max() <= 1e-5
     # zero flow is the identity; integer flow is a shift
     zero = torch.zeros((B, 2, H, W), device="cuda")
-    check(hip_lib.ft_resample2d_fwd(_cuda(img).data_ptr(), zero.data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
+    check(hip_lib.ft_resample2d_fwd(gimg.data_ptr(), zero.data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), img)
     nrm = torch.empty((B, 1, H, W), dtype=torch.float32, device="cuda")
-    check(hip_lib.ft_channelnorm_fwd(_cuda(img).data_ptr(), nrm.data_ptr(), B, C, H, W, _stream()))
+    check(hip_lib.ft_channelnorm_fwd(gimg.data_ptr(), nrm.data_ptr(), B, C, H, W, _stream()))
     torch.cuda.synchronize()
     assert np.abs(nrm.cpu().numpy() - ops_ref.channelnorm_c(img)).max() <= 1e-6
 
@@ -104,7 +105,8 @@ def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
 def test_upsample_and_normalise(hip_lib, oracle_lib):
     x = synth.normal(6, "flow2", (2, 2, 6, 9)).numpy()
     y = torch.empty((2, 2, 24, 36), dtype=torch.float32, device="cuda")
-    check(hip_lib.ft_upsample_bilinear4x(_cuda(x).data_ptr(), y.data_ptr(), 2, 2, 6, 9, 20.0, _stream()))
+    gx = _cuda(x)
+    check(hip_lib.ft_upsample_bilinear4x(gx.data_ptr(), y.data_ptr(), 2, 2, 6, 9, 20.0, _stream()))
     torch.cuda.synchronize()
     want = torch.nn.functional.interpolate(torch.from_numpy(x) * 20.0, scale_factor=4, mode="bilinear", align_corners=False).numpy()
     assert np.abs(y.cpu().numpy() - want).max() <= 1e-5
