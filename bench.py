@@ -71,17 +71,38 @@ def conv_roofline(prog, dtype_name, iters=5):
     }, per_layer
 
 
+def _pick_threads(fn, budget_s=12.0):
+    """Host core count the container may actually use is unknown (cgroup quotas hide behind nproc):
+    try a few thread counts on one forward each and keep the fastest."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail}) or [1]
+    best, best_t, t_start = cands[0], float("inf"), time.perf_counter()
+    for c in cands:
+        torch.set_num_threads(c)
+        fn()  # warm the thread pool
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = c, dt
+        if time.perf_counter() - t_start > budget_s:
+            break
+    torch.set_num_threads(best)
+    return best, avail
+
+
 def cpu_baseline_pose(seconds=15.0):
     """The CPU oracle (the reference's own torch-CPU arithmetic, oracle/pose_ref.py) on this host:
     ResNet-50 head, batch 4 x 256x192 fp32 (BASELINE configs[0]), all host cores."""
     from flowtrack.pytorch_amd.pose import models
     from oracle import pose_ref
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     m = models.deconv("resnet50", 17, False)
     sd = synth.fill_pose_state_dict(m.state_dict(), 1234)
     x = synth.pose_crops(1, 4)
-    pose_ref.pose_forward(sd, x)  # warm-up
+    cores, avail = _pick_threads(lambda: pose_ref.pose_forward(sd, x))
     t0, n = time.perf_counter(), 0
     while True:
         pose_ref.pose_forward(sd, x)
@@ -91,18 +112,16 @@ def cpu_baseline_pose(seconds=15.0):
             break
     return {"value": round(4 * n / el, 2), "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": f"{n} forwards of batch 4 x 3x256x192 fp32 (BASELINE configs[0]) in {el:.1f} s, torch CPU {torch.__version__}, "
-                      f"{torch.get_num_threads()} threads"}
+                      f"{cores} threads (fastest of the tried counts; {avail} logical CPUs visible)"}
 
 
 def cpu_baseline_flow(seconds=15.0):
     from flowtrack.pytorch_amd.flownet import models
     from oracle import flow_ref
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     m = models.FlowNet2S(types.SimpleNamespace(rgb_max=255.0, fp16=False))
     sd = synth.fill_flow_state_dict(m.state_dict(), 1234)
     x = synth.frame_pairs(1, 1, 384, 512)
-    flow_ref.flownet2s_forward(sd, x)
+    cores, avail = _pick_threads(lambda: flow_ref.flownet2s_forward(sd, x))
     t0, n = time.perf_counter(), 0
     while True:
         flow_ref.flownet2s_forward(sd, x)
@@ -111,7 +130,8 @@ def cpu_baseline_flow(seconds=15.0):
         if el >= seconds or n >= 100:
             break
     return {"value": round(n / el, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} FlowNet2S forwards of 1 x 3x2x384x512 fp32 in {el:.1f} s, torch CPU, {torch.get_num_threads()} threads"}
+            "sample": f"{n} FlowNet2S forwards of 1 x 3x2x384x512 fp32 in {el:.1f} s, torch CPU, {cores} threads "
+                      f"(fastest of the tried counts; {avail} logical CPUs visible)"}
 
 
 def main():

@@ -14,11 +14,23 @@
 //   (fp32) channel runs into NHWC, or lane-coalesced rows into NCHW fp32.
 //   A transposed 4x4/s2/p1 conv is 4 output-parity phases, each a 2x2-tap conv:
 //   blockIdx.z = phase, same kernel.
-//   One 256-thread workgroup (4 wave64) computes a BP x BC tile; operands are staged global ->
-//   registers -> LDS (XOR-swizzled 16-byte chunks so the ds_read_b128 fragment reads are
-//   bank-conflict free), double-buffered with one barrier per K-step.  fp16 uses
-//   v_mfma_f32_32x32x16_f16 (fp32 accumulate); fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA
-//   chain) so the parity mode and the fast mode share every line of index arithmetic.
+//   One 256-thread workgroup (4 wave64) computes a BP x BC tile.  Two K-loops share the epilogue:
+//   * conv_igemm_dma_kernel (main path, channel-aligned layers): both operand tiles go HBM/L2 -> LDS
+//     with buffer_load_dwordx4 ... lds (1 KiB per wave instruction, no VGPR round trip), through a
+//     STAGES-deep LDS ring with ONE raw s_barrier per K-step and counted s_waitcnt vmcnt(N) so
+//     STAGES-1 tiles stay in flight.  Padding taps and ragged tiles are out-of-range buffer offsets
+//     (hardware returns 0), the tap offset is a scalar, per-row tap validity is a precomputed bitmask:
+//     ~4 VALU per 16-byte vector instead of a 64-bit address computation.  The LDS image is XOR-
+//     swizzled on the SOURCE side (DMA writes lane-linear) so ds_read_b128 fragment reads are
+//     bank-conflict free.
+//   * conv_igemm_kernel (generic path: Cin = 3/6/12 stems, Cout <= 32 heads): register-staged
+//     global -> VGPR -> LDS, 2 stages, K runs over (tap, channel-group) pairs that may straddle taps.
+//   fp16 uses v_mfma_f32_32x32x16_f16 (fp32 accumulate); fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32
+//   FMA chain) so the parity mode and the fast mode share every line of index arithmetic.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "ft_common.h"
 
 namespace ft {
@@ -39,7 +51,9 @@ struct ConvParams {
   int dmul;         // +1 conv, -1 transposed
   int pad;          // conv padding (unused for transposed)
   int transposed;
-  int cin_groups;   // roundup8(Cin) / VEC
+  int cin_groups;   // generic path: roundup8(Cin) / VEC
+  int kc;           // dma path: K-steps per tap = cin_pad / BK
+  unsigned x_bytes; // dma path: size of the activation buffer (buffer descriptor range)
   int nk;           // K-steps
   int Kpad;         // elements per packed weight row
   int Cout, Cout_pad;
@@ -48,6 +62,8 @@ struct ConvParams {
   int res_cstride, res_coff;
   int act;
   float slope;
+  int npt, nct, nph;  // pixel tiles, output-channel tiles, phases (grid = npt * nct * nph, 1-D)
+  int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
 };
 
 template <typename T> struct Elem;
@@ -106,6 +122,187 @@ __device__ __forceinline__ void load4(const float* src, float (&v)[4]) {
   v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
 }
 
+// ---- shared epilogue -------------------------------------------------------------------------------
+// acc[i][j][reg]: output channel co0 + wc*WT_C + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),
+//                 pixel m0 + wp*WT_P + j*32 + (lane&31)   (32x32 MFMA C/D layout, weights as operand A).
+// smem: at least BP*BC*2 bytes reusable + BP*8 bytes at offset `opix_off` (all K-loop LDS traffic done).
+// Output pixel index of every tile row (or -1 past the end), shared by the residual prefetch and the epilogue.
+template <int BP>
+__device__ __forceinline__ void conv_row_table(const ConvParams& p, long long* s_opix, int m0, int py, int px) {
+  const int tid = threadIdx.x;
+  if (tid < BP) {
+    const int m = m0 + tid;
+    long long o = -1;
+    if (m < p.M) {
+      const int n = m / p.HqWq;
+      const int rem = m - n * p.HqWq;
+      const int qy = rem / p.Wq;
+      const int qx = rem - qy * p.Wq;
+      o = ((long long)n * p.Ho + (qy * p.omul + py)) * p.Wo + (qx * p.omul + px);
+    }
+    s_opix[tid] = o;
+  }
+}
+
+// PRE: the row table is already in LDS and `rpre` holds this thread's residual chunks (issued before the
+// K-loop so their HBM latency overlaps the operand loads); otherwise both are produced here.
+template <typename T, int BP, int BC, int WGP, int WGC, bool PRE = false>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&acc)[BC / WGC / 32][BP / WGP / 32],
+                                              char* smem, int opix_off, int m0, int co0, int py, int px,
+                                              const uint4_t* rpre = nullptr) {
+  constexpr int WT_P = BP / WGP, WT_C = BC / WGC;
+  constexpr int MT_P = WT_P / 32, MT_C = WT_C / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wp = wave % WGP, wc = wave / WGP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // ---- epilogue A (fp16 NHWC fast path): transpose through LDS -> 16-byte coalesced HBM traffic ------
+  if constexpr (sizeof(T) == 2) {
+    if (p.epi_lds) {
+      constexpr int NCH = BC / 8;         // 16-byte chunks per output-tile row
+      constexpr int ROWB = BC * 2;        // bytes per output-tile row
+      char* s_tile = smem;                // the K-loop stages are dead (last loop iteration ended on a barrier)
+      long long* s_opix = reinterpret_cast<long long*>(smem + opix_off);
+      if constexpr (!PRE) {
+        conv_row_table<BP>(p, s_opix, m0, py, px);
+        __syncthreads();
+      }
+      if (p.res) {
+        if constexpr (PRE) {
+#pragma unroll
+          for (int k = 0; k < BP * NCH / 256; ++k) {
+            const int idx = tid + k * 256;
+            const int pl = idx / NCH, ch = idx % NCH;
+            *reinterpret_cast<uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4)) = rpre[k];
+          }
+        } else {
+          const half_t* rbase = reinterpret_cast<const half_t*>(p.res) + p.res_coff + co0;
+          for (int idx = tid; idx < BP * NCH; idx += 256) {
+            const int pl = idx / NCH, ch = idx % NCH;
+            const long long o = s_opix[pl];
+            uint4_t v = {0u, 0u, 0u, 0u};
+            if (o >= 0 && co0 + ch * 8 < p.Cout) v = *reinterpret_cast<const uint4_t*>(rbase + o * p.res_cstride + ch * 8);
+            *reinterpret_cast<uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4)) = v;
+          }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j) {
+        const int pl = wp * WT_P + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MT_C; ++i) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int cl = wc * WT_C + i * 32 + 8 * rg + 4 * lhi;  // channel inside the tile
+            const int cb = co0 + cl;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+            if (p.scale) {
+              const float4_t sc = *reinterpret_cast<const float4_t*>(p.scale + cb);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= sc[e];
+            }
+            if (p.shift) {
+              const float4_t sh = *reinterpret_cast<const float4_t*>(p.shift + cb);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += sh[e];
+            }
+            half_t* sp = reinterpret_cast<half_t*>(s_tile + pl * ROWB + (((cl >> 3) ^ (pl & (NCH - 1))) << 4) + lhi * 8);
+            if (p.res) {
+              float r4[4];
+              load4(sp, r4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += r4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+            store4(sp, v);
+          }
+        }
+      }
+      __syncthreads();
+      half_t* ybase = reinterpret_cast<half_t*>(p.y) + p.y_coff + co0;
+      for (int idx = tid; idx < BP * NCH; idx += 256) {
+        const int pl = idx / NCH, ch = idx % NCH;
+        const long long o = s_opix[pl];
+        if (o >= 0 && co0 + ch * 8 < p.Cout)
+          *reinterpret_cast<uint4_t*>(ybase + o * p.y_cstride + ch * 8) =
+              *reinterpret_cast<const uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4));
+      }
+      return;
+    }
+  }
+
+  // ---- epilogue B (general): scale/shift (+residual) + activation, NHWC runs of 4 or NCHW fp32 ------
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j) {
+    const int m = m0 + wp * WT_P + j * 32 + l31;
+    if (m >= p.M) continue;
+    const int n = m / p.HqWq;
+    const int rem = m - n * p.HqWq;
+    const int qy = rem / p.Wq;
+    const int qx = rem - qy * p.Wq;
+    const int oy = qy * p.omul + py, ox = qx * p.omul + px;
+    const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+    for (int i = 0; i < MT_C; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int cb = co0 + wc * WT_C + i * 32 + 8 * rg + 4 * lhi;
+        if (cb >= p.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+        if (p.scale) {
+          const float4_t s = *reinterpret_cast<const float4_t*>(p.scale + cb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= s[e];
+        }
+        if (p.shift) {
+          const float4_t s = *reinterpret_cast<const float4_t*>(p.shift + cb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += s[e];
+        }
+        const bool full = cb + 3 < p.Cout;
+        if (p.res) {
+          const T* rp = reinterpret_cast<const T*>(p.res) + opix * p.res_cstride + p.res_coff + cb;
+          if (full) {
+            float r4[4];
+            load4(rp, r4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r4[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cb + e < p.Cout) v[e] += (float)rp[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+        if (p.out_layout == FT_LAYOUT_NHWC) {
+          T* yp = reinterpret_cast<T*>(p.y) + opix * p.y_cstride + p.y_coff + cb;
+          if (full) {
+            store4(yp, v);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cb + e < p.Cout) yp[e] = (T)v[e];
+          }
+        } else {
+          float* yp = reinterpret_cast<float*>(p.y);
+          const size_t hw = (size_t)p.Ho * p.Wo;
+          const size_t pix = (size_t)oy * p.Wo + ox;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (cb + e < p.Cout) yp[((size_t)n * p.Cout + cb + e) * hw + pix] = v[e];
+        }
+      }
+    }
+  }
+}
+
 // BP pixels x BC output channels per workgroup, waves arranged WGP x WGC, BKB bytes of K per
 // tile row per K-step (64 -> 32 fp16 / 16 fp32 elements).
 template <typename T, int BP, int BC, int WGP, int WGC, int BKB>
@@ -131,10 +328,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int wp = wave % WGP, wc = wave / WGP;
   const int lrow = tid / CH, chunk = tid % CH;
 
-  const int phase = blockIdx.z;
+  // 1-D grid, XCD-aware: the dispatcher places block b on XCD b % 8 (speed only, never correctness), so
+  // give every XCD one contiguous range of logical tiles.  Logical order = output-channel tile fastest,
+  // then phase, then pixel tile: all blocks that re-read one activation tile (every co tile, every
+  // transposed-conv phase) and the neighbouring halo rows meet in ONE XCD's L2 at about the same time.
+  int ctile, phase, ptile;
+  {
+    const int total = p.npt * p.nct * p.nph;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    ctile = logical % p.nct;
+    const int t = logical / p.nct;
+    phase = t % p.nph;
+    ptile = t / p.nph;
+  }
   const int py = phase >> 1, px = phase & 1;
-  const int m0 = blockIdx.x * BP;
-  const int co0 = blockIdx.y * BC;
+  const int m0 = ptile * BP;
+  const int co0 = ctile * BC;
   const int dbase_y = p.transposed ? py : -p.pad;
   const int dbase_x = p.transposed ? px : -p.pad;
 
@@ -256,87 +467,226 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: scale/shift (+residual) + activation, NHWC runs of 4 or NCHW fp32 ---------
+  conv_epilogue<T, BP, BC, WGP, WGC>(p, acc, smem, 2 * STAGE, m0, co0, py, px);
+}
+
+// ---- main path: direct-to-LDS, STAGES-deep ring, counted vmcnt -----------------------------------------
+// Requirements (checked on the host, else the generic kernel runs): kh*kw <= 32, BC >= 64, every tap's
+// channel run padded to a multiple of BK = BKB/sizeof(T) in BOTH the packed weights and the activation
+// pixel stride (x_cstride >= x_coff + cin_pad, padding channels zero), buffers < 2 GiB.
+template <typename T, int BP, int BC, int WGP, int WGC, int BKB, int STAGES, bool HAS_RES>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only types (__amdgpu_buffer_rsrc_t); the host pass only needs the stub
+  constexpr int NW = 4;
+  constexpr int CH = BKB / 16;              // 16-byte chunks per tile row
+  constexpr int RPI = 64 / CH;              // tile rows filled by one 1-KiB wave load
+  constexpr int NIA = BC / RPI / NW;        // weight-tile loads per wave per stage
+  constexpr int NIB = BP / RPI / NW;        // pixel-tile loads per wave per stage
+  constexpr int NL = NIA + NIB;
+  constexpr int WT_P = BP / WGP, WT_C = BC / WGC;
+  constexpr int MT_P = WT_P / 32, MT_C = WT_C / 32;
+  constexpr int KK = BKB / 32;
+  constexpr int SWZ_DIV = 256 / BKB;
+  constexpr int A_BYTES = BC * BKB, B_BYTES = BP * BKB, STAGE = A_BYTES + B_BYTES;
+  static_assert(WGP * WGC == NW && NIA >= 1 && NIB >= 1, "tile shape");
+  static_assert(BC % (RPI * NW) == 0 && BP % (RPI * NW) == 0, "tile rows must split evenly over the waves");
+  static_assert(NL * (STAGES - 1) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(STAGES >= 3, "ring: one slot computing, one being read ahead, at least one in flight");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave % WGP, wc = wave / WGP;
+
+  int ctile, phase, ptile;
+  {
+    const int total = p.npt * p.nct * p.nph;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    ctile = logical % p.nct;
+    const int t = logical / p.nct;
+    phase = t % p.nph;
+    ptile = t / p.nph;
+  }
+  const int py = phase >> 1, px = phase & 1;
+  const int m0 = ptile * BP;
+  const int co0 = ctile * BC;
+  const int dbase_y = p.transposed ? py : -p.pad;
+  const int dbase_x = p.transposed ? px : -p.pad;
+  constexpr int esz = (int)sizeof(T);
+
+  // buffer descriptors: weights of this (phase, co tile); the whole activation buffer
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.w) + (size_t)(phase * p.Cout_pad + co0) * p.Kpad * esz, 0, BC * p.Kpad * esz, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;    // >= any num_records we accept: the load returns zeros
+
+  // ---- per-lane constants of the loader ---------------------------------------------------------------
+  const int lrow = lane / CH, pos = lane % CH;
+  unsigned a_voff[NIA];
+#pragma unroll
+  for (int t = 0; t < NIA; ++t) {
+    const int r = (wave + NW * t) * RPI + lrow;
+    const int lc = pos ^ ((r / SWZ_DIV) % CH);           // source chunk that lands at LDS position `pos`
+    a_voff[t] = (unsigned)(r * p.Kpad * esz + lc * 16);
+  }
+  int b_base[NIB];
+  unsigned b_mask[NIB];
+#pragma unroll
+  for (int t = 0; t < NIB; ++t) {
+    const int r = (wave + NW * t) * RPI + lrow;
+    const int lc = pos ^ ((r / SWZ_DIV) % CH);
+    const int m = m0 + r;
+    unsigned mask = 0;
+    int base = 0;
+    if (m < p.M) {
+      const int n = m / p.HqWq;
+      const int rem = m - n * p.HqWq;
+      const int qy = rem / p.Wq;
+      const int qx = rem - qy * p.Wq;
+      const int iy0 = qy * p.sy + dbase_y, ix0 = qx * p.sy + dbase_x;
+      base = (((n * p.Hi + iy0) * p.Wi + ix0) * p.x_cstride + p.x_coff) * esz + lc * 16;
+      for (int ky = 0; ky < p.kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx) {
+          const int iy = iy0 + p.dmul * ky, ix = ix0 + p.dmul * kx;
+          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mask |= 1u << (ky * p.kw + kx);
+        }
+    }
+    b_base[t] = base;
+    b_mask[t] = mask;
+  }
+
+  // ---- K position of the NEXT stage to issue (wave-uniform, lives in SGPRs) -----------------------------
+  int i_ky = 0, i_kx = 0, i_cc = 0, i_ks = 0;
+  const int cstride_b = p.x_cstride * esz;
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + A_BYTES;
+    const bool live = i_ks < p.nk;
+    const int a_soff = i_ks * BKB;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(sA + (wave + NW * t) * 1024), 16,
+                                               live ? a_voff[t] : kOOB, live ? a_soff : 0, 0, 0);
+    const int tap = i_ky * p.kw + i_kx;
+    const int delta = ((p.dmul * i_ky) * p.Wi + p.dmul * i_kx) * cstride_b + i_cc * BKB;
+    const unsigned tapbit = live ? (1u << tap) : 0u;
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+      const unsigned voff = (b_mask[t] & tapbit) ? (unsigned)(b_base[t] + delta) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(sB + (wave + NW * t) * 1024), 16, voff, 0, 0, 0);
+    }
+    ++i_ks;
+    if (++i_cc == p.kc) {
+      i_cc = 0;
+      if (++i_kx == p.kw) { i_kx = 0; ++i_ky; }
+    }
+  };
+
+  // ---- per-lane fragment read offsets (stage-relative); kk selects chunk pair via XOR (kk << 5) ----------
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int a_off[MT_C], b_off[MT_P];
+#pragma unroll
+  for (int i = 0; i < MT_C; ++i) {
+    const int r = wc * WT_C + i * 32 + l31;
+    a_off[i] = r * BKB + ((lhi ^ ((r / SWZ_DIV) % CH)) << 4);
+  }
 #pragma unroll
   for (int j = 0; j < MT_P; ++j) {
-    const int m = m0 + wp * WT_P + j * 32 + l31;
-    if (m >= p.M) continue;
-    const int n = m / p.HqWq;
-    const int rem = m - n * p.HqWq;
-    const int qy = rem / p.Wq;
-    const int qx = rem - qy * p.Wq;
-    const int oy = qy * p.omul + py, ox = qx * p.omul + px;
-    const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+    const int r = wp * WT_P + j * 32 + l31;
+    b_off[j] = A_BYTES + r * BKB + ((lhi ^ ((r / SWZ_DIV) % CH)) << 4);
+  }
+
+  float16_t acc[MT_C][MT_P];
 #pragma unroll
-    for (int i = 0; i < MT_C; ++i) {
+  for (int i = 0; i < MT_C; ++i)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int cb = co0 + wc * WT_C + i * 32 + 8 * rg + 4 * lhi;
-        if (cb >= p.Cout) continue;
-        float v[4];
+    for (int j = 0; j < MT_P; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-        if (p.scale) {
-          const float4_t s = *reinterpret_cast<const float4_t*>(p.scale + cb);
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Residual tile: issue its (coalesced, 16-byte) loads NOW so their HBM latency hides under the operand
+  // pipeline instead of sitting between the last MFMA and the store (1x1 bottleneck-exit layers are
+  // bandwidth-bound: what matters is bytes in flight per CU).
+  constexpr bool PRE = HAS_RES && sizeof(T) == 2;
+  constexpr int NPRE = PRE ? BP * (BC / 8) / 256 : 1;
+  uint4_t rpre[NPRE];
+  long long* s_opix = reinterpret_cast<long long*>(smem + STAGES * STAGE);
+  if constexpr (PRE) {
+    conv_row_table<BP>(p, s_opix, m0, py, px);
+    __syncthreads();
+    constexpr int NCH = BC / 8;
+    const half_t* rbase = reinterpret_cast<const half_t*>(p.res) + p.res_coff + co0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= s[e];
-        }
-        if (p.shift) {
-          const float4_t s = *reinterpret_cast<const float4_t*>(p.shift + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += s[e];
-        }
-        const bool full = cb + 3 < p.Cout;
-        if (p.res) {
-          const T* rp = reinterpret_cast<const T*>(p.res) + opix * p.res_cstride + p.res_coff + cb;
-          if (full) {
-            float r4[4];
-            load4(rp, r4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r4[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (cb + e < p.Cout) v[e] += (float)rp[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
-        if (p.out_layout == FT_LAYOUT_NHWC) {
-          T* yp = reinterpret_cast<T*>(p.y) + opix * p.y_cstride + p.y_coff + cb;
-          if (full) {
-            store4(yp, v);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (cb + e < p.Cout) yp[e] = (T)v[e];
-          }
-        } else {
-          float* yp = reinterpret_cast<float*>(p.y);
-          const size_t hw = (size_t)p.Ho * p.Wo;
-          const size_t pix = (size_t)oy * p.Wo + ox;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (cb + e < p.Cout) yp[((size_t)n * p.Cout + cb + e) * hw + pix] = v[e];
-        }
-      }
+    for (int k = 0; k < NPRE; ++k) {
+      const int idx = tid + k * 256;
+      const int pl = idx / NCH, ch = idx % NCH;
+      const long long o = s_opix[pl];
+      uint4_t v = {0u, 0u, 0u, 0u};
+      if (o >= 0 && co0 + ch * 8 < p.Cout) v = *reinterpret_cast<const uint4_t*>(rbase + o * p.res_cstride + ch * 8);
+      rpre[k] = v;
     }
   }
+
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+
+  // Fragment registers are double-buffered: while the MFMAs of K-step ks run from set P, the
+  // ds_read_b128s of K-step ks+1 fill set P^1, so no MFMA ever waits on LDS latency right after a
+  // barrier.  (Static set indices: the loop is unrolled by two through step<P>().)
+  uint4_t fa[2][KK][MT_C], fb[2][KK][MT_P];
+  auto load_frags = [&](auto set, int slot) {
+    constexpr int P = decltype(set)::value;
+    const char* st = smem + slot * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int i = 0; i < MT_C; ++i) fa[P][kk][i] = *reinterpret_cast<const uint4_t*>(st + (a_off[i] ^ (kk << 5)));
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j) fb[P][kk][j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
+    }
+  };
+  int cur = 0, nxt = STAGES - 1;   // ring slot of K-step ks; slot the next issue() fills
+  auto step = [&](auto set) {
+    constexpr int P = decltype(set)::value;
+    const int cur1 = cur + 1 == STAGES ? 0 : cur + 1;
+    // this wave's loads of K-step ks+1 have landed (STAGES-3 younger stages may still be in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 3)) : "memory");
+    // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
+    __builtin_amdgcn_s_barrier();
+    issue(nxt);
+    load_frags(std::integral_constant<int, P ^ 1>{}, cur1);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) mma_slice<MT_C, MT_P>(fa[P][kk], fb[P][kk], acc, (T*)nullptr);
+    cur = cur1;
+    nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+  };
+
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 2)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  load_frags(std::integral_constant<int, 0>{}, 0);
+  int ks = 0;
+  for (; ks + 1 < p.nk; ks += 2) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+  }
+  if (ks < p.nk) step(std::integral_constant<int, 0>{});
+  // drain the (all out-of-range) tail loads before LDS is reused by the epilogue
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_epilogue<T, BP, BC, WGP, WGC, PRE>(p, acc, smem, STAGES * STAGE, m0, co0, py, px, rpre);
+#endif
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-constexpr int kBKB = 64;  // bytes of K per tile row per step (all instantiations)
-constexpr int kBP = 128;
-
-static int pick_bc(int cout) {
-  if (cout <= 32) return 32;
-  if (cout % 128 == 0) return 128;
-  return 64;
-}
-
-struct Geometry {
-  int nphases, ntaps, cin8, cout_pad, kpad, bc, nk, cin_groups, vec;
-};
+constexpr int kBKB = 64;       // generic kernel: bytes of K per tile row per step
+constexpr int kBP = 128;       // generic kernel: pixel tile
+constexpr int kDmaBKB = 64;    // dma kernel: bytes of K per tile row per step (32 fp16 / 16 fp32 channels)
+constexpr int kDmaStages = 4;  // dma kernel: LDS ring depth
 
 static int validate(const ft_conv_desc* d) {
   if (!d) return FT_ERR_INVALID_ARG;
@@ -366,47 +716,92 @@ static int validate(const ft_conv_desc* d) {
   return FT_OK;
 }
 
+// Packed-weight layout + kernel choice. Everything here depends only on (dtype, Cin, Cout, kernel,
+// transposed, x_cstride - x_coff): NOT on the batch / spatial size, so weights are packed once per layer.
+struct Geometry {
+  int nphases, ntaps, cin_pad, cout_pad, kpad;
+  int dma;                        // 1: conv_igemm_dma_kernel, 0: generic conv_igemm_kernel
+  int nk, cin_groups, vec, kc;    // K-loop bookkeeping of the chosen kernel
+};
+
 static int geometry(const ft_conv_desc* d, Geometry* g) {
   int st = validate(d);
   if (st != FT_OK) return st;
-  g->vec = d->dtype == FT_F16 ? 8 : 4;
+  const int esz = d->dtype == FT_F16 ? 2 : 4;
+  g->vec = 16 / esz;
   g->nphases = d->transposed ? 4 : 1;
   g->ntaps = d->transposed ? 4 : d->kh * d->kw;
-  g->cin8 = round_up(d->Cin, 8);
-  g->bc = pick_bc(d->Cout);
-  g->cout_pad = round_up(d->Cout, g->bc);
-  g->cin_groups = g->cin8 / g->vec;
-  const int ch = kBKB / 16;
-  g->nk = ceil_div(g->ntaps * g->cin_groups, ch);
-  g->kpad = g->nk * ch * g->vec;
+  const int bk = kDmaBKB / esz;
+  const int cin_bk = round_up(d->Cin, bk);
+  const long long wbytes = (long long)128 * g->ntaps * cin_bk * esz;  // one co tile of packed weights
+  g->dma = d->Cout > 32 && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
+  if (g->dma) {
+    g->cin_pad = cin_bk;
+    g->cout_pad = round_up(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
+    g->kc = cin_bk / bk;
+    g->nk = g->ntaps * g->kc;
+    g->kpad = g->ntaps * cin_bk;
+    g->cin_groups = 0;
+  } else {
+    g->cin_pad = round_up(d->Cin, 8);
+    const int bc = d->Cout <= 32 ? 32 : (d->Cout % 128 == 0 ? 128 : 64);
+    g->cout_pad = round_up(d->Cout, bc);
+    g->cin_groups = g->cin_pad / g->vec;
+    const int ch = kBKB / 16;
+    g->nk = ceil_div(g->ntaps * g->cin_groups, ch);
+    g->kpad = g->nk * ch * g->vec;
+    g->kc = 0;
+  }
   return FT_OK;
 }
 
 template <typename T, int BC, int WGP, int WGC>
-static void launch(const ConvParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)(BC + kBP) * kBKB;
+static void launch_generic(const ConvParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(BC + kBP) * kBKB + (size_t)kBP * 8;  // 2 stages + per-row output offsets
+  static_assert((size_t)kBP * BC * 2 <= 2 * (size_t)(BC + kBP) * kBKB, "fp16 output tile must fit in the stage buffers");
   hipLaunchKernelGGL((conv_igemm_kernel<T, kBP, BC, WGP, WGC, kBKB>), grid, dim3(256), lds, s, p);
 }
 
-template <typename T>
-static void dispatch(int bc, const ConvParams& p, dim3 grid, hipStream_t s) {
-  if (bc == 128) launch<T, 128, 2, 2>(p, grid, s);
-  else if (bc == 64) launch<T, 64, 2, 2>(p, grid, s);
-  else launch<T, 32, 4, 1>(p, grid, s);
+template <typename T, int BP, int BC, int WGP, int WGC, bool HAS_RES>
+static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)kDmaStages * (BC + BP) * kDmaBKB + (size_t)BP * 8;
+  static_assert((size_t)BP * BC * 2 <= (size_t)kDmaStages * (BC + BP) * kDmaBKB, "fp16 output tile must fit in the ring");
+  auto k = conv_igemm_dma_kernel<T, BP, BC, WGP, WGC, kDmaBKB, kDmaStages, HAS_RES>;
+  if (lds > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  return FT_OK;
+}
+
+template <typename T, int BP, int BC, int WGP, int WGC>
+static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
+  // the residual-prefetch variant exists for the fp16 LDS-transposed epilogue only
+  if (sizeof(T) == 2 && p.res && p.epi_lds) return launch_dma_r<T, BP, BC, WGP, WGC, true>(p, grid, s);
+  return launch_dma_r<T, BP, BC, WGP, WGC, false>(p, grid, s);
+}
+
+static int env_int(const char* name) {  // developer tile overrides (FT_CONV_BP / FT_CONV_BC), 0 = heuristic
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
 }
 
 }  // namespace ft
 
 using namespace ft;
 
-extern "C" int ft_conv_pack_geometry(const ft_conv_desc* d, int* nphases, int* ntaps, int* cin8,
+extern "C" int ft_conv_pack_geometry(const ft_conv_desc* d, int* nphases, int* ntaps, int* cin_pad,
                                      int* cout_pad, int* kpad) {
   Geometry g;
   int st = geometry(d, &g);
   if (st != FT_OK) return st;
   if (nphases) *nphases = g.nphases;
   if (ntaps) *ntaps = g.ntaps;
-  if (cin8) *cin8 = g.cin8;
+  if (cin_pad) *cin_pad = g.cin_pad;
   if (cout_pad) *cout_pad = g.cout_pad;
   if (kpad) *kpad = g.kpad;
   return FT_OK;
@@ -471,6 +866,7 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.pad = d->pad;
   p.transposed = d->transposed;
   p.cin_groups = g.cin_groups;
+  p.kc = g.kc;
   p.nk = g.nk;
   p.Kpad = g.kpad;
   p.Cout = d->Cout;
@@ -485,11 +881,63 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.res_coff = d->res_coff;
   p.act = d->act;
   p.slope = d->slope;
-
-  dim3 grid(ceil_div(p.M, kBP), g.cout_pad / g.bc, g.nphases);
+  p.nph = g.nphases;
+  p.epi_lds = d->dtype == FT_F16 && d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 &&
+              d->y_cstride % 8 == 0 && (!d->has_residual || (d->res_coff % 8 == 0 && d->res_cstride % 8 == 0));
   hipStream_t s = as_stream(stream);
-  if (d->dtype == FT_F16) dispatch<half_t>(g.bc, p, grid, s);
-  else dispatch<float>(g.bc, p, grid, s);
+  const size_t esz = dtype_size(d->dtype);
+  const unsigned long long x_bytes = (unsigned long long)d->N * d->Hi * d->Wi * d->x_cstride * esz;
+
+  if (g.dma && x_bytes < (1ull << 31)) {
+    p.x_bytes = (unsigned)x_bytes;
+    // tile choice (launch-time only; the packed layout does not depend on it): fill the 256 CUs
+    int bc = d->Cout % 128 == 0 ? 128 : 64;
+    int bp = 128;
+    auto blocks = [&](int bp_, int bc_) { return (long long)ceil_div(p.M, bp_) * (g.cout_pad / bc_) * g.nphases; };
+    if (blocks(bp, bc) < 384) bp = 64;
+    if (blocks(bp, bc) < 384 && bc == 128) bc = 64;
+    // short-K layers (1x1 bottleneck exits) are HBM-bound: smaller pixel tiles = more workgroups per CU =
+    // more bytes in flight (measured on MI355X, R50 shapes: 64x128 beats 128x128 by 10-18 % for K <= 512)
+    if (g.ntaps * g.cin_pad <= 512 && bc == 128) bp = 64;
+    static const int force_bp = env_int("FT_CONV_BP"), force_bc = env_int("FT_CONV_BC");
+    if (force_bp == 64 || force_bp == 128) bp = force_bp;
+    if ((force_bc == 64 || force_bc == 128) && g.cout_pad % force_bc == 0) bc = force_bc;
+    p.npt = ceil_div(p.M, bp);
+    p.nct = g.cout_pad / bc;
+    if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+    dim3 grid(p.npt * p.nct * p.nph);
+    int rc;
+    if (d->dtype == FT_F16) {
+      if (bp == 128 && bc == 128) rc = launch_dma<half_t, 128, 128, 2, 2>(p, grid, s);
+      else if (bp == 128) rc = launch_dma<half_t, 128, 64, 2, 2>(p, grid, s);
+      else if (bc == 128) rc = launch_dma<half_t, 64, 128, 2, 2>(p, grid, s);
+      else rc = launch_dma<half_t, 64, 64, 2, 2>(p, grid, s);
+    } else {
+      if (bp == 128 && bc == 128) rc = launch_dma<float, 128, 128, 2, 2>(p, grid, s);
+      else if (bp == 128) rc = launch_dma<float, 128, 64, 2, 2>(p, grid, s);
+      else if (bc == 128) rc = launch_dma<float, 64, 128, 2, 2>(p, grid, s);
+      else rc = launch_dma<float, 64, 64, 2, 2>(p, grid, s);
+    }
+    if (rc != FT_OK) return rc;
+    FT_LAUNCH_CHECK("conv_igemm_dma_kernel");
+    return FT_OK;
+  }
+  if (g.dma) return FT_ERR_UNSUPPORTED;  // packed for the dma layout but the activation buffer is >= 2 GiB
+
+  const int bc = g.cout_pad % 128 == 0 && d->Cout > 64 ? 128 : (d->Cout <= 32 ? 32 : 64);
+  p.npt = ceil_div(p.M, kBP);
+  p.nct = g.cout_pad / bc;
+  if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+  dim3 grid(p.npt * p.nct * p.nph);
+  if (d->dtype == FT_F16) {
+    if (bc == 128) launch_generic<half_t, 128, 2, 2>(p, grid, s);
+    else if (bc == 64) launch_generic<half_t, 64, 2, 2>(p, grid, s);
+    else launch_generic<half_t, 32, 4, 1>(p, grid, s);
+  } else {
+    if (bc == 128) launch_generic<float, 128, 2, 2>(p, grid, s);
+    else if (bc == 64) launch_generic<float, 64, 2, 2>(p, grid, s);
+    else launch_generic<float, 32, 4, 1>(p, grid, s);
+  }
   FT_LAUNCH_CHECK("conv_igemm_kernel");
   return FT_OK;
 }

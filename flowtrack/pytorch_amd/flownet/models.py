@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..engine import HipModule
-from ..hip_ops import ActView, FlowtrackHipError, FusedConv, Program, new_act, record_upsample4x
+from ..hip_ops import ActView, FlowtrackHipError, FusedConv, Program, act_stride, new_act, record_upsample4x
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
 LEAK = 0.1
@@ -151,7 +151,7 @@ def _fu(c: ConvTransposeParams, label: str, mk: dict) -> FusedConv:
 
 def _record_decoder(prog: Program, p: _Decoder, conv6: ActView, cc5, cc4, cc3, cc2, prefix: str, mk: dict):
     """predict_flow6 .. predict_flow2 with concat-free writes (FlowNetS.py:69-89).
-    cc5..cc2: NHWC buffers [B,h,w,1032|776|392|200] whose channel slice 0 already holds the skip
+    cc5..cc2: NHWC buffers [B,h,w,act_stride(1026|770|386|194)] whose channel slice 0 already holds the skip
     feature; returns flow2 as NCHW fp32 [B,2,H/4,W/4]."""
     B, dtype, device = conv6.N, mk["dtype"], mk["device"]
     flow6 = new_act(B, conv6.H, conv6.W, 2, dtype, device)
@@ -185,9 +185,9 @@ def _record_decoder(prog: Program, p: _Decoder, conv6: ActView, cc5, cc4, cc3, c
 
 def _concat_buffers(B: int, H: int, W: int, dtype, device, b2: int = None):
     """cc5, cc4, cc3, cc2 tensors; cc2 may carry a larger batch (siamese FlowNetC trunk)."""
-    z = lambda n, h, w, c: torch.zeros((n, h, w, c), dtype=dtype, device=device)
-    return (z(B, H // 32, W // 32, 1032), z(B, H // 16, W // 16, 776), z(B, H // 8, W // 8, 392),
-            z(b2 or B, H // 4, W // 4, 200))
+    z = lambda n, h, w, c: torch.zeros((n, h, w, act_stride(c)), dtype=dtype, device=device)
+    return (z(B, H // 32, W // 32, 1026), z(B, H // 16, W // 16, 770), z(B, H // 8, W // 8, 386),
+            z(b2 or B, H // 4, W // 4, 194))
 
 
 def record_flownets(prog: Program, p: FlowNetS, x: ActView, prefix: str, mk: dict) -> torch.Tensor:

@@ -54,10 +54,16 @@ class ActView:
         return ActView(self.t[lo:hi], self.C, self.coff)
 
 
+def act_stride(C: int) -> int:
+    """Channel stride of an NHWC buffer that holds C channels: a multiple of 32 once C >= 32 so the
+    direct-to-LDS conv kernel (K-steps of 32 fp16 / 16 fp32 channels) can read it; 8 below that."""
+    return round_up(C, 32) if C >= 32 else round_up(C, 8)
+
+
 def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int] = None) -> ActView:
-    """Zero-filled NHWC buffer; the channel stride is rounded up to 8 (16-byte vectors) and the
-    padding channels stay zero for the buffer's lifetime (the conv reads them against zero weights)."""
-    cs = round_up(C if cstride is None else cstride, 8)
+    """Zero-filled NHWC buffer; the padding channels [C, cstride) stay zero for the buffer's lifetime
+    (the convs read them against zero weights)."""
+    cs = act_stride(C) if cstride is None else cstride
     return ActView(torch.zeros((N, H, W, cs), dtype=dtype, device=device), C, 0)
 
 
@@ -144,44 +150,23 @@ class Program:
 # --------------------------------------------------------------------------------------------
 # fused conv / transposed conv
 # --------------------------------------------------------------------------------------------
-def _probe_desc(dtype_code: int, cin: int, cout: int, k: int, stride: int, pad: int, transposed: bool) -> ConvDesc:
-    """A geometrically consistent dummy descriptor, used only to query the packed-weight layout."""
-    d = ConvDesc()
-    d.dtype = dtype_code
-    d.N, d.Hi, d.Wi = 1, 64, 64
-    d.Cin, d.x_cstride, d.x_coff = cin, round_up(cin, 8), 0
-    d.Cout, d.kh, d.kw, d.stride, d.pad, d.transposed = cout, k, k, stride, pad, int(transposed)
-    if transposed:
-        d.Ho, d.Wo = 128, 128
-    else:
-        d.Ho = d.Wo = (64 + 2 * pad - k) // stride + 1
-    d.y_cstride, d.y_coff, d.out_layout = round_up(cout, 8), 0, FT_LAYOUT_NHWC
-    d.act = FT_ACT_NONE
-    return d
-
-
-def pack_conv_weights(weight: torch.Tensor, *, transposed: bool, stride: int, pad: int, dtype: torch.dtype,
+def pack_conv_weights(weight: torch.Tensor, d: ConvDesc, *, dtype: torch.dtype,
                       device: torch.device) -> Tuple[torch.Tensor, int]:
-    """Re-lay reference weights for the implicit-GEMM kernel.
+    """Re-lay reference weights for the implicit-GEMM kernels, for the layer described by `d`.
 
     weight: Conv2d [Cout, Cin, kh, kw] or ConvTranspose2d [Cin, Cout, 4, 4] (reference layouts,
     SURVEY Appendix B).  Returns ([nphases, Cout_pad, Kpad] tensor of `dtype` on `device`,
-    Cout_pad); k = tap * Cin8 + ci, zeros in all padding.  The tap -> (ky, kx) map comes from the
-    library (ft_conv_tap_source) so packer and kernel cannot disagree."""
+    Cout_pad); k = tap * cin_pad + ci, zeros in all padding.  Both the geometry (which depends on the
+    kernel the library will choose for `d`) and the tap -> (ky, kx) map come from the library
+    (ft_conv_pack_geometry / ft_conv_tap_source), so packer and kernels cannot disagree."""
     lib = _lib.load()
     w = weight.detach().to(torch.float32).cpu()
-    if transposed:
-        cin, cout, kh, kw = w.shape
-    else:
-        cout, cin, kh, kw = w.shape
-    if kh != kw:
-        raise FlowtrackHipError("only square kernels are used by the FlowTrack hot paths")
-    code = _lib.dtype_code(dtype)
-    d = _probe_desc(code, cin, cout, kh, stride, pad, transposed)
-    nph, ntaps, cin8, cout_pad, kpad = (ctypes.c_int() for _ in range(5))
-    check(lib.ft_conv_pack_geometry(ctypes.byref(d), ctypes.byref(nph), ctypes.byref(ntaps), ctypes.byref(cin8),
+    transposed = bool(d.transposed)
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    nph, ntaps, cin_pad, cout_pad, kpad = (ctypes.c_int() for _ in range(5))
+    check(lib.ft_conv_pack_geometry(ctypes.byref(d), ctypes.byref(nph), ctypes.byref(ntaps), ctypes.byref(cin_pad),
                                     ctypes.byref(cout_pad), ctypes.byref(kpad)), "ft_conv_pack_geometry")
-    nph, ntaps, cin8, cout_pad, kpad = nph.value, ntaps.value, cin8.value, cout_pad.value, kpad.value
+    nph, ntaps, cin_pad, cout_pad, kpad = nph.value, ntaps.value, cin_pad.value, cout_pad.value, kpad.value
     packed = torch.zeros((nph, cout_pad, kpad), dtype=torch.float32)
     ky, kx = ctypes.c_int(), ctypes.c_int()
     for ph in range(nph):
@@ -192,7 +177,7 @@ def pack_conv_weights(weight: torch.Tensor, *, transposed: bool, stride: int, pa
                 tap_w = w[:, :, ky.value, kx.value].t()  # [Cout, Cin]
             else:
                 tap_w = w[:, :, ky.value, kx.value]      # [Cout, Cin]
-            packed[ph, :cout, t * cin8:t * cin8 + cin] = tap_w
+            packed[ph, :cout, t * cin_pad:t * cin_pad + cin] = tap_w
     return packed.to(device=device, dtype=dtype).contiguous(), cout_pad
 
 
@@ -241,9 +226,25 @@ class FusedConv:
             self.cout, self.cin, self.k, _ = weight.shape
         self.stride, self.pad = stride, pad
         self.act, self.slope, self.label = ACT_CODES[act], float(slope), label
-        self.w, self.cout_pad = pack_conv_weights(weight, transposed=transposed, stride=stride, pad=pad, dtype=dtype,
-                                                  device=device)
-        self.scale, self.shift = fold_scale_shift(self.cout, self.cout_pad, bias, bn, device)
+        if weight.shape[2] != weight.shape[3]:
+            raise FlowtrackHipError("only square kernels are used by the FlowTrack hot paths")
+        self._weight = weight.detach().to(torch.float32).cpu()
+        self._bias = None if bias is None else bias.detach().to(torch.float32).cpu()
+        self._bn = None if bn is None else {k: (v.detach().to(torch.float32).cpu() if torch.is_tensor(v) else v)
+                                            for k, v in bn.items()}
+        self._packed = {}  # (cin_pad-dependent) geometry key -> (w, cout_pad, scale, shift)
+
+    def _packed_for(self, d: ConvDesc):
+        """Packed weights + folded scale/shift for the kernel the library picks for `d` (cached per layout)."""
+        g = [ctypes.c_int() for _ in range(5)]
+        check(self.lib.ft_conv_pack_geometry(ctypes.byref(d), *[ctypes.byref(v) for v in g]), "ft_conv_pack_geometry")
+        key = tuple(v.value for v in g)
+        hit = self._packed.get(key)
+        if hit is None:
+            w, cout_pad = pack_conv_weights(self._weight, d, dtype=self.dtype, device=self.device)
+            scale, shift = fold_scale_shift(self.cout, cout_pad, self._bias, self._bn, self.device)
+            hit = self._packed[key] = (w, cout_pad, scale, shift)
+        return hit
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         if self.transposed:
@@ -281,13 +282,14 @@ class FusedConv:
             d.has_residual, d.res_cstride, d.res_coff = 1, residual.cstride, residual.coff
             res_ptr = residual.t.data_ptr()
         d.act, d.slope = self.act, self.slope
+        w, _, scale, shift = self._packed_for(d)
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops))
-        prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), self.w.data_ptr(),
-                 self.scale.data_ptr() if self.scale is not None else None,
-                 self.shift.data_ptr() if self.shift is not None else None, res_ptr, yt.data_ptr(),
-                 keep=(d, x.t, yt, self.w, self.scale, self.shift, residual.t if residual is not None else None))
+        prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
+                 scale.data_ptr() if scale is not None else None,
+                 shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(),
+                 keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None))
 
 
 # --------------------------------------------------------------------------------------------

@@ -87,8 +87,9 @@ int ft_stream_synchronize(ft_stream_t stream);
  *
  * Activations are NHWC with an explicit channel stride/offset so producers can
  * write straight into a channel slice of a concat buffer (torch.cat in
- * FlowNetS.py:73-88 disappears).  Cin is rounded up to a multiple of 8 when
- * reading: channels [Cin, roundup8(Cin)) of x must exist and be zero.
+ * FlowNetS.py:73-88 disappears).  Cin is rounded up when reading: channels
+ * [Cin, cin_pad) of every pixel of x (cin_pad from ft_conv_pack_geometry, at
+ * least roundup8(Cin)) must exist inside x_cstride and be zero.
  */
 typedef struct ft_conv_desc {
   int dtype;       /* FT_F16 (fp16 storage, fp32 accumulate) or FT_F32 */
@@ -111,10 +112,15 @@ typedef struct ft_conv_desc {
 } ft_conv_desc;
 
 /* Packed-weight geometry for `d`: w_packed is [nphases][Cout_pad][Kpad] of
- * d->dtype with k = tap * Cin8 + ci (zeros in all padding). nphases is 1 for
- * conv, 4 for the transposed conv (one 2x2 conv per output parity). */
+ * d->dtype with k = tap * cin_pad + ci (zeros in all padding). nphases is 1 for
+ * conv, 4 for the transposed conv (one 2x2 conv per output parity).  The layout
+ * depends only on (dtype, Cin, Cout, kernel, transposed, x_cstride - x_coff):
+ * when the input view has room for cin_pad = roundup(Cin, 32 fp16 / 16 fp32)
+ * channels per pixel (padding channels zero) the direct-to-LDS kernel is used and
+ * every tap's channel run is padded to that multiple; otherwise cin_pad =
+ * roundup(Cin, 8) and the generic kernel runs. */
 int ft_conv_pack_geometry(const ft_conv_desc* d, int* nphases, int* ntaps,
-                          int* cin8, int* cout_pad, int* kpad);
+                          int* cin_pad, int* cout_pad, int* kpad);
 /* Which original kernel element (ky, kx) tap `tap` of phase `phase` reads. */
 int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int* ky,
                        int* kx);

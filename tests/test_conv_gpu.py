@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from flowtrack.pytorch_amd import synth
-from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv
+from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv, act_stride
 from util import make_program, nchw_to_view, run_program, view_to_nchw
 
 pytestmark = pytest.mark.gpu
@@ -33,6 +33,10 @@ CASES = [
     ("upflow_2_2", 1, 2, 6, 8, 2, 4, 2, 1, True, False, False, None, False),
     ("upflow_2_2_bias", 1, 2, 6, 8, 2, 4, 2, 1, True, True, False, None, False),
     ("3x3_cout1024_k4608", 1, 512, 6, 8, 1024, 3, 2, 1, False, True, False, "leaky", False),
+    ("3x3_m_gt_tiles", 5, 64, 24, 20, 192, 3, 1, 1, False, False, True, "relu", True),
+    ("5x5_s2_cin128", 2, 128, 24, 32, 256, 5, 2, 2, False, True, False, "leaky", False),
+    ("1x1_cin2048", 3, 2048, 8, 6, 512, 1, 1, 0, False, False, True, "relu", False),
+    ("deconv_770_cout128", 1, 770, 6, 8, 128, 4, 2, 1, True, True, False, "leaky", False),
 ]
 
 
@@ -52,9 +56,13 @@ def _reference(x, w, bias, bn, stride, pad, transposed, act, res):
     return y
 
 
+@pytest.mark.parametrize("layout", ["wide", "tight"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv_matches_oracle(hip_lib, case, dtype):
+def test_conv_matches_oracle(hip_lib, case, dtype, layout):
+    """layout 'wide': channel stride as the networks allocate it (act_stride: multiples of 32 -> the
+    direct-to-LDS kernel whenever Cout > 32); 'tight': stride roundup8(Cin) -> the generic kernel for
+    ragged channel counts.  Both must agree with the oracle."""
     name, N, Cin, H, W, Cout, k, stride, pad, transposed, has_bias, has_bn, act, has_res = case
     dev = torch.device("cuda:0")
     seed = 11
@@ -80,7 +88,7 @@ def test_conv_matches_oracle(hip_lib, case, dtype):
             res = res.half().float()
     want = _reference(x, w, bias, bn, stride, pad, transposed, act, res)
 
-    xv = nchw_to_view(x, dtype, dev)
+    xv = nchw_to_view(x, dtype, dev, cstride=act_stride(Cin) if layout == "wide" else None)
     # write into a channel slice of a wider buffer whose other channels must stay untouched
     ycs = ((Cout + 8 + 7) // 8) * 8 + 8
     ybuf = torch.full((N, Ho, Wo, ycs), 7.0, dtype=dtype, device=dev)
