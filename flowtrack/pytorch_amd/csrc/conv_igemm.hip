@@ -682,6 +682,128 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
 #endif
 }
 
+// ---- few-output-channel conv (FlowNet predict_flow: Cout = 2, K up to 9 * 1026) -----------------------
+// A GEMM tile would leave 30/32 MFMA columns idle and serialise a 9k-long K loop in a handful of
+// workgroups.  Instead: one wave per group of PIX consecutive output pixels, the 64 lanes split the
+// (tap, channel-group) axis with 16-byte coalesced loads, fp32 dot products (v_dot2_f32_f16 for fp16: no
+// explicit converts), a transpose-reduce butterfly (PIX*NCO values -> one per lane group), the (tiny) weight
+// set in LDS once per workgroup, each weight vector reused for PIX pixels from registers.
+// Uses the generic packed layout [Cout_pad][Kpad].
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dot8(const uint4_t& a, const uint4_t& b, float c, half_t*) {
+  // whole-vector bit casts only (bit_cast of one vector element reads element 0, see mma_slice)
+  const half8_t ah = __builtin_bit_cast(half8_t, a), bh = __builtin_bit_cast(half8_t, b);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const half2_t a2 = {ah[2 * q], ah[2 * q + 1]}, b2 = {bh[2 * q], bh[2 * q + 1]};
+    c = __builtin_amdgcn_fdot2(a2, b2, c, false);
+  }
+  return c;
+}
+__device__ __forceinline__ float dot8(const uint4_t& a, const uint4_t& b, float c, float*) {
+  const float4_t af = __builtin_bit_cast(float4_t, a), bf = __builtin_bit_cast(float4_t, b);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c += af[q] * bf[q];
+  return c;
+}
+
+template <typename T, int NCO, int PIX>
+__global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvParams p, int ppb) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int NV = PIX * NCO;  // partial sums per lane
+  static_assert(NV == 8, "the reduction below folds exactly 8 values over the 64 lanes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = p.kh * p.kw * p.cin_groups;   // 16-byte vectors along K per output pixel
+  for (int i = tid; i < NCO * nvec; i += 256) {
+    const int co = i / nvec, v = i - co * nvec;
+    reinterpret_cast<uint4_t*>(smem)[i] = reinterpret_cast<const uint4_t*>(p.w + (size_t)co * p.Kpad * sizeof(T))[v];
+  }
+  __syncthreads();
+  const uint4_t* sw = reinterpret_cast<const uint4_t*>(smem);
+  const int m_begin = blockIdx.x * ppb;
+  const int m_end = m_begin + ppb < p.M ? m_begin + ppb : p.M;
+  const int tap0 = lane / p.cin_groups;
+  const int cg0 = lane - tap0 * p.cin_groups;
+  for (int m = m_begin + wave * PIX; m < m_end; m += 4 * PIX) {
+    // decode PIX consecutive output pixels (one division pair, then carries)
+    int pn[PIX], py_[PIX], px_[PIX];
+    {
+      int n = m / p.HqWq;
+      const int rem = m - n * p.HqWq;
+      int oy = rem / p.Wq;
+      int ox = rem - oy * p.Wq;
+#pragma unroll
+      for (int i = 0; i < PIX; ++i) {
+        pn[i] = n; py_[i] = oy; px_[i] = ox;
+        if (++ox == p.Wq) { ox = 0; if (++oy * p.Wq == p.HqWq) { oy = 0; ++n; } }
+      }
+    }
+    float acc[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) acc[c] = 0.f;
+    int tap = tap0, cg = cg0;
+    for (int v = lane; v < nvec; v += 64) {
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      uint4_t wv[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) wv[c] = sw[c * nvec + v];
+#pragma unroll
+      for (int i = 0; i < PIX; ++i) {
+        const int iy = py_[i] * p.sy - p.pad + ky, ix = px_[i] * p.sy - p.pad + kx;
+        uint4_t xv = {0u, 0u, 0u, 0u};
+        if (m + i < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+          const size_t off = ((size_t)(pn[i] * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff + cg * VEC;
+          xv = *reinterpret_cast<const uint4_t*>(p.x + off * sizeof(T));
+        }
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) acc[i * NCO + c] = dot8(xv, wv[c], acc[i * NCO + c], (T*)nullptr);
+      }
+      cg += 64;
+      while (cg >= p.cin_groups) { cg -= p.cin_groups; ++tap; }
+    }
+    // transpose-reduce: 8 values x 64 lanes -> value j summed over all lanes, held by lanes with (lane>>3)==j
+    float r4[4], r2[2], r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // offset 32: lower half keeps values 0..3, upper half 4..7
+      const float keep = lane & 32 ? acc[4 + j] : acc[j];
+      const float send = lane & 32 ? acc[j] : acc[4 + j];
+      r4[j] = keep + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {   // offset 16
+      const float keep = lane & 16 ? r4[2 + j] : r4[j];
+      const float send = lane & 16 ? r4[j] : r4[2 + j];
+      r2[j] = keep + __shfl_xor(send, 16);
+    }
+    {
+      const float keep = lane & 8 ? r2[1] : r2[0];
+      const float send = lane & 8 ? r2[0] : r2[1];
+      r1 = keep + __shfl_xor(send, 8);
+    }
+    r1 += __shfl_xor(r1, 4);
+    r1 += __shfl_xor(r1, 2);
+    r1 += __shfl_xor(r1, 1);
+    if ((lane & 7) == 0) {
+      const int vi = lane >> 3;            // which of the 8 values this lane group holds
+      const int i = vi / NCO, c = vi - i * NCO;
+      if (m + i < m_end && c < p.Cout) {
+        const size_t opix = ((size_t)pn[i] * p.Ho + py_[i]) * p.Wo + px_[i];
+        float v = r1;
+        if (p.scale) v *= p.scale[c];
+        if (p.shift) v += p.shift[c];
+        if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[opix * p.res_cstride + p.res_coff + c];
+        v = apply_act(v, p.act, p.slope);
+        if (p.out_layout == FT_LAYOUT_NHWC)
+          reinterpret_cast<T*>(p.y)[opix * p.y_cstride + p.y_coff + c] = (T)v;
+        else
+          reinterpret_cast<float*>(p.y)[((size_t)pn[i] * p.Cout + c) * p.Ho * p.Wo + (size_t)py_[i] * p.Wo + px_[i]] = v;
+      }
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 constexpr int kBKB = 64;       // generic kernel: bytes of K per tile row per step
 constexpr int kBP = 128;       // generic kernel: pixel tile
@@ -923,6 +1045,30 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     return FT_OK;
   }
   if (g.dma) return FT_ERR_UNSUPPORTED;  // packed for the dma layout but the activation buffer is >= 2 GiB
+
+  if (!d->transposed && d->Cout <= 4) {
+    const int nco = d->Cout <= 2 ? 2 : 4;
+    const size_t lds = (size_t)nco * g.ntaps * g.cin_groups * 16;
+    if (lds <= 160 * 1024) {
+      // pixels per workgroup: enough workgroups to fill the chip, enough pixels to amortise the weight staging
+      int ppb = ceil_div(p.M, 2048);
+      ppb = ppb < 16 ? 16 : (ppb > 128 ? 128 : ppb);
+      ppb = round_up(ppb, 16);
+      dim3 grid(ceil_div(p.M, ppb));
+#define FT_FEWOUT(T, N, P)                                                                                    \
+  do {                                                                                                       \
+    auto k = conv_fewout_kernel<T, N, P>;                                                                    \
+    if (lds > 64 * 1024)                                                                                     \
+      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p, ppb);                                                  \
+  } while (0)
+      if (d->dtype == FT_F16) { if (nco == 2) FT_FEWOUT(half_t, 2, 4); else FT_FEWOUT(half_t, 4, 2); }
+      else { if (nco == 2) FT_FEWOUT(float, 2, 4); else FT_FEWOUT(float, 4, 2); }
+#undef FT_FEWOUT
+      FT_LAUNCH_CHECK("conv_fewout_kernel");
+      return FT_OK;
+    }
+  }
 
   const int bc = g.cout_pad % 128 == 0 && d->Cout > 64 ? 128 : (d->Cout <= 32 ? 32 : 64);
   p.npt = ceil_div(p.M, kBP);

@@ -37,6 +37,9 @@ CASES = [
     ("5x5_s2_cin128", 2, 128, 24, 32, 256, 5, 2, 2, False, True, False, "leaky", False),
     ("1x1_cin2048", 3, 2048, 8, 6, 512, 1, 1, 0, False, False, True, "relu", False),
     ("deconv_770_cout128", 1, 770, 6, 8, 128, 4, 2, 1, True, True, False, "leaky", False),
+    ("predict_flow_cin1026", 2, 1026, 6, 8, 2, 3, 1, 1, False, True, False, None, False),
+    ("fewout_cout3_5x5_s2", 1, 40, 11, 9, 3, 5, 2, 2, False, True, False, "leaky", False),
+    ("fewout_cout4_1x1_res", 2, 64, 7, 5, 4, 1, 1, 0, False, False, True, "relu", True),
 ]
 
 
