@@ -119,3 +119,38 @@ def test_transform_preds_is_inverse_of_crop_affine():
     back = (t @ np.concatenate((img[0], np.ones((3, 1))), 1).T)[:2].T
     assert np.allclose(back, pts[0])
     assert np.allclose(evaluation.transform_preds(np.array([[[24.0, 32.0]]]), c, s, res), c)   # heatmap centre -> box centre
+
+
+def test_flow_io_and_arg_reflection(tmp_path):
+    import argparse
+    from flowtrack.pytorch_amd.flownet import models, tools
+    f = np.arange(5 * 7 * 2, dtype=np.float32).reshape(5, 7, 2)
+    path = str(tmp_path / "x.flo")
+    tools.write_flow(f, path)
+    raw = open(path, "rb").read()
+    assert len(raw) == 12 + f.nbytes and np.frombuffer(raw[:4], np.float32)[0] == np.float32(202021.25)
+    assert tuple(np.frombuffer(raw[4:12], np.int32)) == (7, 5)           # width, height (flowlib.py:139-148)
+    assert np.array_equal(tools.read_flow(path), f)
+    img = tools.flow_to_image(np.stack(np.meshgrid(np.linspace(-3, 3, 9), np.linspace(-2, 2, 6)), -1).astype(np.float32))
+    assert img.shape == (6, 9, 3) and img.dtype == np.uint8
+    parser = argparse.ArgumentParser()
+    import sys
+    old = sys.argv
+    sys.argv = ["demo", "--model", "FlowNet2CS"]
+    try:
+        tools.add_arguments_for_module(parser, models, "model", default="FlowNet2S", choices=["FlowNet2S", "FlowNet2C", "FlowNet2CS"])
+        args = parser.parse_args(["--model", "FlowNet2CS", "--model_div_flow", "10.0"])
+    finally:
+        sys.argv = old
+    assert tools.kwargs_from_args(args, "model") == {"batchNorm": False, "div_flow": 10.0}
+    assert tools.module_to_dict(models)["FlowNet2CS"] is models.FlowNet2CS
+
+
+def test_pose_config_parse_warns_on_unknown():
+    import warnings
+    from tools.pose.config import DefaultConfig
+    o = DefaultConfig()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        o.parse({"backbone": "resnet101", "not_an_option": 1})
+    assert o.backbone == "resnet101" and any("not_an_option" in str(x.message) for x in w)

@@ -1,0 +1,94 @@
+"""FlowNet demo entry point on the HIP path — same CLI as the reference's tools/flownet/demo.py:22-99.
+
+    python tools/flownet/demo.py --model FlowNet2S --resume CKPT.pth.tar -i img0.ppm -p img1.ppm -s results [--fp16] [-ng 1]
+
+Builds `models.<model>(args, **model_kwargs)` through the same argument reflection (`--model_<kw>` flags),
+loads `checkpoint['state_dict']`, packs the pair as [1,3,2,H,W] RGB 0..255, runs the HIP forward and writes
+`<save>/output.flo` + `<save>/flow.png`.  Differences: images are read with PIL (scipy.misc.imread is gone);
+frames whose size is not a multiple of 64 are zero-padded bottom/right and the flow cropped back;
+`--random_weights` allows a run without a checkpoint (the reference quits, demo.py:57-59);
+`--number_gpus > 1` is accepted but the single pair runs on one GPU (multi-GPU = one process per GPU, bench.py).
+"""
+from __future__ import absolute_import, division, print_function
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from flowtrack.pytorch_amd.flownet import models, tools   # noqa: E402
+
+MODEL_CHOICES = ['FlowNet2S', 'FlowNet2C', 'FlowNet2CS']
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--input1', '-i', default='samples/img0.ppm', type=str, help='first input image')
+    parser.add_argument('--input2', '-p', default='samples/img1.ppm', type=str, help='second input image')
+    parser.add_argument('--save', '-s', default='results', type=str, help='directory for saving')
+    parser.add_argument('--resume', default='', type=str, metavar='PATH', help='path to latest checkpoint (default: none)')
+    parser.add_argument('--number_gpus', '-ng', type=int, default=1, help='number of GPUs to use')
+    parser.add_argument('--fp16', action='store_true', help='Run model in pseudo-fp16 mode (fp16 storage fp32 math).')
+    parser.add_argument('--rgb_max', type=float, default=255.)
+    parser.add_argument('--random_weights', action='store_true', help='run without a checkpoint (results are meaningless)')
+    tools.add_arguments_for_module(parser, models, argument_for_class='model', default='FlowNet2S', choices=MODEL_CHOICES)
+    return parser
+
+
+def load_image(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))
+
+
+def run_pair(model, im1, im2):
+    """im1, im2: HxWx3 uint8/float RGB -> flow HxWx2 fp32 (pixels)."""
+    H, W = im1.shape[:2]
+    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
+    ims = np.zeros((1, 3, 2, Hp, Wp), dtype=np.float32)
+    ims[0, :, 0, :H, :W] = np.asarray(im1, dtype=np.float32).transpose(2, 0, 1)
+    ims[0, :, 1, :H, :W] = np.asarray(im2, dtype=np.float32).transpose(2, 0, 1)
+    with torch.no_grad():
+        flow = model(torch.from_numpy(ims).cuda()).cpu()
+    return flow[0, :, :H, :W].numpy().transpose(1, 2, 0)
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    args.model_class = tools.module_to_dict(models)[args.model]
+    kwargs = tools.kwargs_from_args(args, 'model')
+    model = args.model_class(args, **kwargs)
+    print('Building {} model: {} parameters'.format(args.model, sum(p.numel() for p in model.parameters())))
+    if args.resume and os.path.isfile(args.resume):
+        print("Loading checkpoint '{}'".format(args.resume))
+        checkpoint = torch.load(args.resume, map_location='cpu')
+        model.load_state_dict(checkpoint['state_dict'])
+        print("Loaded checkpoint '{}' (at epoch {}, best_EPE {})".format(args.resume, checkpoint.get('epoch'), checkpoint.get('best_EPE')))
+    elif args.random_weights:
+        print('No checkpoint: running with randomly initialised weights (--random_weights)')
+    else:
+        print("No checkpoint found at '{}'".format(args.resume))
+        return 1
+    os.makedirs(args.save, exist_ok=True)
+    if args.number_gpus < 1:
+        raise SystemExit('the HIP path needs a GPU (--number_gpus >= 1)')
+    model = model.cuda()
+    if args.fp16:
+        model = model.half()
+    model.eval()
+    flow = run_pair(model, load_image(args.input1), load_image(args.input2))
+    tools.write_flow(flow, os.path.join(args.save, 'output.flo'))
+    from PIL import Image
+    Image.fromarray(tools.flow_to_image(flow)).save(os.path.join(args.save, 'flow.png'))
+    print('wrote {0}/output.flo and {0}/flow.png ({1}x{2})'.format(args.save, flow.shape[1], flow.shape[0]))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

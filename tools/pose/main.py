@@ -1,0 +1,124 @@
+# -*- coding:utf-8 -*-
+"""Pose entry point on the HIP path — inference subset of the reference's tools/pose/main.py.
+
+    from tools.pose.main import main
+    out = main(model='deconv', backbone='resnet50', dataset='coco', input_res=(256, 192),
+               resume='deconv_resnet50_best.pth', flip_test=True)
+
+Same protocol as the reference (main.py:42-198): kwargs -> opt.parse, `getattr(models, opt.model)(opt.backbone,
+num_classes=..., pretrained=...)`, `.cuda()`, optional resume of `<checkpoint_path>/<dataset>/<exp_id>/<resume>`
+(`checkpoint['state_dict']`), then `validate` (main.py:254-372): forward, optional flip test, final_preds.
+Datasets, training, losses and tensorboard are out of scope: crops come from a caller-supplied
+iterable of (inputs[B,3,H,W], meta) or, by default, from the synthetic generator.  The flip test runs on the
+device (flip + left/right channel swap) instead of the reference's numpy round trip (main.py:289-299).
+"""
+from __future__ import print_function, absolute_import
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from flowtrack.pytorch_amd import synth                      # noqa: E402
+from flowtrack.pytorch_amd.pose import evaluation, models    # noqa: E402
+from tools.pose.config import opt                            # noqa: E402
+
+num_joints = {'mpii': 16, 'aic': 14, 'coco': 17}
+# COCO left/right keypoint pairs (lib/pose/utils/transforms.py flip helpers)
+COCO_FLIP_PAIRS = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16)]
+
+
+def _flip_back(hm, pairs):
+    """Undo a horizontal flip of the INPUT on the heatmaps: mirror x and swap left/right channels."""
+    hm = torch.flip(hm, dims=[3])
+    idx = list(range(hm.shape[1]))
+    for a, b in pairs:
+        if a < len(idx) and b < len(idx):
+            idx[a], idx[b] = idx[b], idx[a]
+    return hm[:, idx]
+
+
+def synthetic_batches(n, batch, res, seed):
+    """(inputs, meta) batches of N(0,1) crops with box centre / scale metadata (coco.py:110-113 geometry)."""
+    H, W = res
+    done = 0
+    while done < n:
+        b = min(batch, n - done)
+        x = synth.pose_crops(seed + done, b, H, W)
+        center = np.stack([np.array([W / 2.0 + 3 * i, H / 2.0 + 2 * i]) for i in range(b)])
+        scale = np.array([max(H, W * H / W) * 1.25 for _ in range(b)], dtype=np.float64)
+        yield x, {'center': center, 'scale': scale, 'index': np.arange(done, done + b)}
+        done += b
+
+
+def validate(model, batches, flip_test=False, adjust_coords=True, flip_pairs=COCO_FLIP_PAIRS):
+    """Inference loop of main.py:254-372 (eval mode, forward, flip test, final_preds). Returns dict of arrays."""
+    model.eval()
+    all_preds, all_scores, all_idx = [], [], []
+    n, t0 = 0, time.time()
+    for inputs, meta in batches:
+        inputs = inputs.cuda(non_blocking=True)
+        output = model(inputs)
+        if flip_test:
+            flipped = _flip_back(model(torch.flip(inputs, dims=[3])), flip_pairs)
+            output = (output + flipped) * 0.5
+        preds, scores = evaluation.final_preds(output, meta['center'], meta['scale'], adjust_coords)
+        all_preds.append(preds)
+        all_scores.append(scores)
+        all_idx.append(meta['index'])
+        n += inputs.shape[0]
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print('validate: {} crops in {:.3f} s ({:.1f} crops/s incl. host post-processing)'.format(n, dt, n / max(dt, 1e-9)))
+    return {'preds': np.concatenate(all_preds), 'scores': np.concatenate(all_scores), 'index': np.concatenate(all_idx),
+            'seconds': dt}
+
+
+def main(**kwargs):
+    opt.parse(kwargs)
+    opt.work_dir = os.path.join(opt.checkpoint_path, opt.dataset, opt.exp_id)
+    num_classes = num_joints[opt.dataset] + (1 if opt.with_bg else 0)
+    print("==> creating model '{}', backbone = {}".format(opt.model, opt.backbone))
+    if opt.model != 'deconv':
+        raise ValueError("only model='deconv' (ResNet + 3-deconv head) is on the HIP path; got '{}'".format(opt.model))
+    model = getattr(models, opt.model)(opt.backbone, num_classes=num_classes, pretrained=opt.pretrained)
+    opt.model_name = '{}_{}'.format(opt.model, opt.backbone)
+    if not opt.use_gpu:
+        raise ValueError('the HIP path needs use_gpu=True (CPU reference results: oracle/)')
+    model = model.cuda()
+    if opt.resume:
+        model_path = os.path.join(opt.work_dir, opt.resume)
+        if os.path.exists(model_path):
+            print("=> loading checkpoint '{}'".format(opt.resume))
+            checkpoint = torch.load(model_path, map_location='cpu')
+            model.load_state_dict(checkpoint['state_dict'])
+            print("=> loaded checkpoint '{}' (epoch {})".format(opt.resume, checkpoint.get('epoch')))
+        else:
+            print("=> no checkpoint found at '{}'".format(opt.resume))
+    print('    Total params: %.4fM' % (sum(p.numel() for p in model.parameters()) / 1000000.0))
+    if opt.fp16:
+        model.compute_dtype = torch.float16
+    if 'valid' not in opt.run_type and 'test' not in opt.run_type:
+        raise ValueError("run_type '{}': training is out of scope of the HIP path (use 'valid')".format(opt.run_type))
+    batches = kwargs.get('batches') or synthetic_batches(opt.num_samples, opt.test_batch_size, opt.input_res, opt.seed)
+    out = validate(model, batches, flip_test=opt.flip_test, adjust_coords=opt.adjust_coords)
+    out['model'] = model
+    return out
+
+
+if __name__ == '__main__':
+    import ast
+    kw = {}
+    for a in sys.argv[1:]:
+        k, v = a.lstrip('-').split('=', 1)
+        try:
+            kw[k] = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            kw[k] = v
+    main(**kw)
