@@ -158,6 +158,108 @@ __global__ __launch_bounds__(NT) void correlation_nhwc_kernel(const T* __restric
   }
 }
 
+// ---- Correlation on the matrix cores (fp16 features, kernel 1, stride1 1, stride2 2) ------------------
+// stride2 = 2 means an output pixel only ever meets f2 pixels of ITS OWN column parity, so per image row y,
+// displaced row y2 = y + 2*dy and parity p the whole cost-volume slice is one small GEMM
+//     G[x', x2'] = sum_c f1[y, 2x'+p, c] * f2[y2, 2x2'+p, c],      out[y, 2x'+p, (dy, dx)] = G[x', x'+dx] / C
+// of which the band |dx| <= drad is kept.  Workgroup = (image, row, 64-pixel column chunk); wave = (parity,
+// 32-column tile of the f2 window).  The f1 fragments (32 pixels x C channels) live in REGISTERS for all D
+// displaced rows; each f2 row window (64 + 4*drad pixels) is DMA'd into a 2-slot LDS ring
+// (buffer_load ... lds, out-of-image pixels / rows are out-of-range offsets -> zeros) and consumed by
+// KS = C/16 back-to-back v_mfma_f32_32x32x16_f16.  MFMA does 64/(2*drad+1) ~ 3x the useful MACs but at
+// ~16x the fp32 VALU rate; the band leaves as runs of up to D contiguous channels per pixel.
+template <int KS>
+__global__ __launch_bounds__(256) void correlation_mfma_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
+                                                               half_t* __restrict__ y, int H, int W, int drad,
+                                                               unsigned f2_bytes, int f_cstride, int y_cstride,
+                                                               int y_coff, int act, float slope) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = KS * 16;
+  constexpr int ROWB = C * 2;               // bytes per window pixel in LDS
+  constexpr int RPI = 1024 / ROWB;          // window pixels per 1-KiB wave load
+  constexpr int CHUNKS = ROWB / 16;
+  static_assert(ROWB <= 1024 && CHUNKS >= 16, "C in {128, 256, 512}");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = wave & 1, jt = wave >> 1;
+  const int c = lane & 31, h = lane >> 5;
+  const int x0 = blockIdx.x * 64, yrow = blockIdx.y, n = blockIdx.z;
+  const int D = 2 * drad + 1;
+  const int wrows = 64 + 4 * drad;          // f2 window: pixels x0 - 2*drad ... x0 + 63 + 2*drad
+  const int stage = ((wrows * ROWB + 1023) / 1024) * 1024;
+  const float inv_c = 1.0f / (float)C;
+
+  // f1 fragments (operand A: row = f1 pixel of this parity, k = channel)
+  uint4_t a[KS];
+  {
+    const int x = x0 + 2 * c + par;
+    const half_t* src = f1 + ((size_t)(n * H + yrow) * W + x) * f_cstride + h * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint4_t v = {0u, 0u, 0u, 0u};
+      if (x < W) v = *reinterpret_cast<const uint4_t*>(src + s * 16);
+      a[s] = v;
+    }
+  }
+  // operand B: column = window pixel 64*jt + 2*c + par (clamped: columns past the window are never in the band)
+  int wr = 64 * jt + 2 * c + par;
+  wr = wr < wrows ? wr : wrows - 1;
+  const int b_base = wr * ROWB;
+  const int b_key = (wr >> 1) & 15;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(f2), 0, f2_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+  const int ninstr = stage / 1024;
+  auto issue = [&](int dyi, int slot) {
+    const int y2 = yrow + 2 * (dyi - drad);
+    const bool row_ok = dyi < D && (unsigned)y2 < (unsigned)H;
+    for (int i = wave; i < ninstr; i += 4) {
+      const int row = i * RPI + lane / CHUNKS, pos = lane % CHUNKS;
+      const int lc = pos ^ ((row >> 1) & 15);
+      const int x2 = x0 - 2 * drad + row;
+      const bool ok = row_ok && row < wrows && (unsigned)x2 < (unsigned)W;
+      const unsigned voff = ok ? (unsigned)((((n * H + y2) * W + x2) * f_cstride) * 2 + lc * 16) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + slot * stage + i * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  for (int dyi = 0; dyi < D; ++dyi) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of row dyi has landed (and its last stores left)
+    __builtin_amdgcn_s_barrier();                       // everyone's has; everyone is done reading the other slot
+    issue(dyi + 1, (dyi + 1) & 1);
+    const int y2 = yrow + 2 * (dyi - drad);
+    float16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if ((unsigned)y2 < (unsigned)H) {
+      const char* st = smem + (dyi & 1) * stage + b_base;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4_t b = *reinterpret_cast<const uint4_t*>(st + (((2 * s + h) ^ b_key) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[s]), __builtin_bit_cast(half8_t, b), acc, 0, 0, 0);
+      }
+    }
+    // band extraction: accumulator row r = f1 pixel x' (this parity), column c = window column -> dx index c + 32*jt - r
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int r = (g & 3) + 8 * (g >> 2) + 4 * h;
+      const int x = x0 + 2 * r + par;
+      const int dxi = c + 32 * jt - r;
+      if (x < W && (unsigned)dxi < (unsigned)D) {
+        float v = acc[g] * inv_c;
+        if (act == FT_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == FT_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+        y[((size_t)(n * H + yrow) * W + x) * y_cstride + y_coff + dyi * D + dxi] = (half_t)v;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (all out-of-range) look-ahead load of the last iteration
+#endif
+}
+
 // ---- Resample2d: backward bilinear warp with border clamp -----------------------------------------
 // Weights from the UNclamped floor, neighbour indices clamped, no renormalisation
 // (Resample2d_kernel.cu:42-59).  Thread = output pixel, all channels (flow read once).
@@ -325,6 +427,24 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
   const int D = (max_displacement / stride2) * 2 + 1;
   if (y_coff < 0 || y_cstride < y_coff + D * D) return FT_ERR_INVALID_ARG;
   const size_t esz = dtype_size(dtype);
+  const unsigned long long f_bytes = (unsigned long long)B * H * W * f_cstride * esz;
+  if (dtype == FT_F16 && stride2 == 2 && max_displacement % 2 == 0 && max_displacement <= 32 && C == 256 &&
+      f_bytes < (1ull << 31)) {
+    const int drad = max_displacement / 2;
+    const size_t stage = ((size_t)(64 + 4 * drad) * C * 2 + 1023) / 1024 * 1024;
+    const size_t lds2 = 2 * stage;
+    auto k = correlation_mfma_kernel<16>;
+    static thread_local bool raised = false;
+    if (!raised) {
+      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+    hipLaunchKernelGGL(k, dim3(ceil_div(W, 64), H, B), dim3(256), lds2, as_stream(stream), static_cast<const half_t*>(f1),
+                       static_cast<const half_t*>(f2), static_cast<half_t*>(y), H, W, drad, (unsigned)f_bytes, f_cstride,
+                       y_cstride, y_coff, act, slope);
+    FT_LAUNCH_CHECK("correlation_mfma_kernel");
+    return FT_OK;
+  }
   const size_t pstride = C * esz + 16;
   // fp16: 32-pixel tiles / 256 threads; fp32 (parity mode): 16-pixel tiles / 128 threads (LDS budget)
   const int tx = dtype == FT_F16 ? 32 : 16;
