@@ -12,7 +12,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libflowtrack_hip.so")
+LIB_PATH = os.environ.get("FT_LIB_PATH") or os.path.join(HERE, "libflowtrack_hip.so")  # FT_LIB_PATH: developer A/B builds
 
 FT_OK = 0
 FT_F16, FT_F32 = 0, 1

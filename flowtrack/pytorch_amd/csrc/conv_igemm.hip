@@ -33,6 +33,15 @@
 
 #include "ft_common.h"
 
+#ifndef FT_DMA_FRAGDB
+#define FT_DMA_FRAGDB 0   // 1: double-buffer the MFMA fragments in registers across K-steps (+32 VGPRs)
+#endif
+#ifndef FT_DMA_BKB
+#define FT_DMA_BKB 64
+#endif
+#ifndef FT_DMA_STAGES
+#define FT_DMA_STAGES 3   // measured on R50 B=64: 2 -> 1.88 ms, 3 -> 1.90, 4 -> 1.98, 5 -> 2.22 (occupancy beats ring depth)
+#endif
 namespace ft {
 
 struct ConvParams {
@@ -64,6 +73,7 @@ struct ConvParams {
   float slope;
   int npt, nct, nph;  // pixel tiles, output-channel tiles, phases (grid = npt * nct * nph, 1-D)
   int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
+  int dbg;            // developer ablation (FT_CONV_DBG): 1 = no MFMA, 2 = no operand loads, 4 = no epilogue; 0 in production
 };
 
 template <typename T> struct Elem;
@@ -474,8 +484,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // Requirements (checked on the host, else the generic kernel runs): kh*kw <= 32, BC >= 64, every tap's
 // channel run padded to a multiple of BK = BKB/sizeof(T) in BOTH the packed weights and the activation
 // pixel stride (x_cstride >= x_coff + cin_pad, padding channels zero), buffers < 2 GiB.
+// Occupancy target (waves per SIMD) the register allocator must respect: the K-loop is latency-bound per
+// workgroup (one barrier per K-step), so co-resident workgroups are what keeps the MFMA pipe fed.
+#ifndef FT_DMA_WAVES_BIG
+#define FT_DMA_WAVES_BIG 3   // 128x128 tile: 64 accumulator + <= 104 other registers
+#endif
 template <typename T, int BP, int BC, int WGP, int WGC, int BKB, int STAGES, bool HAS_RES>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4)) void conv_igemm_dma_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only types (__amdgpu_buffer_rsrc_t); the host pass only needs the stub
   constexpr int NW = 4;
   constexpr int CH = BKB / 16;              // 16-byte chunks per tile row
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   static_assert(WGP * WGC == NW && NIA >= 1 && NIB >= 1, "tile shape");
   static_assert(BC % (RPI * NW) == 0 && BP % (RPI * NW) == 0, "tile rows must split evenly over the waves");
   static_assert(NL * (STAGES - 1) <= 63, "vmcnt is a 6-bit counter");
-  static_assert(STAGES >= 3, "ring: one slot computing, one being read ahead, at least one in flight");
+  static_assert(STAGES >= (FT_DMA_FRAGDB ? 3 : 2), "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -632,9 +647,24 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     }
   }
 
+  // experiment: break the phase lock between co-resident workgroups (all start together and would otherwise
+  // hit their load / MFMA / store phases at the same time)
+  if (p.dbg & 24) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;   // HW_ID.WAVE_ID
+    if (p.dbg & 8) {
+      if ((slot % 3) == 1) __builtin_amdgcn_s_sleep(12);
+      else if ((slot % 3) == 2) __builtin_amdgcn_s_sleep(24);
+    }
+    if (p.dbg & 16) {
+      if (slot & 1) __builtin_amdgcn_s_setprio(1);
+    }
+  }
+
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s);
 
+  int cur = 0, nxt = STAGES - 1;   // ring slot of K-step ks; slot the next issue() fills
+#if FT_DMA_FRAGDB
   // Fragment registers are double-buffered: while the MFMAs of K-step ks run from set P, the
   // ds_read_b128s of K-step ks+1 fill set P^1, so no MFMA ever waits on LDS latency right after a
   // barrier.  (Static set indices: the loop is unrolled by two through step<P>().)
@@ -650,7 +680,6 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
       for (int j = 0; j < MT_P; ++j) fb[P][kk][j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
     }
   };
-  int cur = 0, nxt = STAGES - 1;   // ring slot of K-step ks; slot the next issue() fills
   auto step = [&](auto set) {
     constexpr int P = decltype(set)::value;
     const int cur1 = cur + 1 == STAGES ? 0 : cur + 1;
@@ -675,9 +704,41 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     step(std::integral_constant<int, 1>{});
   }
   if (ks < p.nk) step(std::integral_constant<int, 0>{});
+#else
+  for (int ks = 0; ks < p.nk; ++ks) {
+    // this wave's loads of K-step ks have landed (STAGES-2 younger stages may still be in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 2)) : "memory");
+    // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
+    __builtin_amdgcn_s_barrier();
+    if (!(p.dbg & 2)) issue(nxt);
+    const char* st = smem + cur * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      uint4_t a[MT_C], b[MT_P];
+#pragma unroll
+      for (int i = 0; i < MT_C; ++i) a[i] = *reinterpret_cast<const uint4_t*>(st + (a_off[i] ^ (kk << 5)));
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j) b[j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
+      if (p.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < MT_C; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j) asm volatile("" ::"v"(b[j]));
+      } else {
+        mma_slice<MT_C, MT_P>(a, b, acc, (T*)nullptr);
+      }
+    }
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+    nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+  }
+#endif
   // drain the (all out-of-range) tail loads before LDS is reused by the epilogue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (p.dbg & 4) {
+    if (acc[0][0][0] == 12345.678f) p.y[0] = 1;   // keep the accumulators live
+    return;
+  }
   conv_epilogue<T, BP, BC, WGP, WGC, PRE>(p, acc, smem, STAGES * STAGE, m0, co0, py, px, rpre);
 #endif
 }
@@ -807,8 +868,8 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvParams p, in
 // ---- host side ---------------------------------------------------------------------------------
 constexpr int kBKB = 64;       // generic kernel: bytes of K per tile row per step
 constexpr int kBP = 128;       // generic kernel: pixel tile
-constexpr int kDmaBKB = 64;    // dma kernel: bytes of K per tile row per step (32 fp16 / 16 fp32 channels)
-constexpr int kDmaStages = 4;  // dma kernel: LDS ring depth
+constexpr int kDmaBKB = FT_DMA_BKB;        // dma kernel: bytes of K per tile row per step (64 -> 32 fp16 / 16 fp32 channels)
+constexpr int kDmaStages = FT_DMA_STAGES;  // dma kernel: LDS ring depth
 
 static int validate(const ft_conv_desc* d) {
   if (!d) return FT_ERR_INVALID_ARG;
@@ -1004,6 +1065,8 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.act = d->act;
   p.slope = d->slope;
   p.nph = g.nphases;
+  static const int dbg = env_int("FT_CONV_DBG");
+  p.dbg = dbg;
   p.epi_lds = d->dtype == FT_F16 && d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 &&
               d->y_cstride % 8 == 0 && (!d->has_residual || (d->res_coff % 8 == 0 && d->res_cstride % 8 == 0));
   hipStream_t s = as_stream(stream);
