@@ -34,7 +34,18 @@ class ConvDesc(ctypes.Structure):
         ("stride", c_int), ("pad", c_int), ("transposed", c_int), ("Ho", c_int), ("Wo", c_int),
         ("y_cstride", c_int), ("y_coff", c_int), ("out_layout", c_int), ("has_residual", c_int),
         ("res_cstride", c_int), ("res_coff", c_int), ("act", c_int), ("slope", c_float),
+        ("x_lpad", c_int), ("x_wpitch", c_int),
     ]
+
+
+class ConvGeometry(ctypes.Structure):
+    """Mirror of `ft_conv_geometry`."""
+
+    _fields_ = [("nphases", c_int), ("ntaps", c_int), ("cin_pad", c_int), ("cout_pad", c_int), ("kpad", c_int),
+                ("run_taps", c_int), ("run_cpad", c_int)]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
 
 
 _PROTOTYPES = {
@@ -53,27 +64,26 @@ _PROTOTYPES = {
     "ft_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "ft_event_destroy": (c_int, [c_void_p]),
     "ft_stream_synchronize": (c_int, [c_void_p]),
-    "ft_conv_pack_geometry": (c_int, [POINTER(ConvDesc)] + [POINTER(c_int)] * 5),
-    "ft_conv_tap_source": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "ft_conv_pack_geometry": (c_int, [POINTER(ConvDesc), POINTER(ConvGeometry)]),
+    "ft_conv_tap_source": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "ft_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "ft_conv_flops": (c_double, [POINTER(ConvDesc)]),
-    "ft_pack_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_pack_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ft_unpack_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     "ft_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ft_heatmap_max_preds": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
     "ft_flow_rgb_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "ft_flow_pack_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                  c_void_p]),
+    "ft_flow_pack_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 7 + [c_void_p]),
     "ft_upsample_bilinear4x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ft_correlation_out_shape": (c_int, [c_int] * 8 + [POINTER(c_int)] * 3),
     "ft_correlation_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "ft_correlation_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_int, c_void_p]),
     "ft_resample2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ft_channelnorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -21,6 +21,15 @@ template <> __device__ __forceinline__ void store8<float>(float* dst, const floa
   reinterpret_cast<float4_t*>(dst)[0] = a;
   reinterpret_cast<float4_t*>(dst)[1] = b;
 }
+template <typename T> __device__ __forceinline__ void store4c(T* dst, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4c<half_t>(half_t* dst, const float (&v)[4]) {
+  half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  *reinterpret_cast<half4_t*>(dst) = h;
+}
+template <> __device__ __forceinline__ void store4c<float>(float* dst, const float (&v)[4]) {
+  float4_t f = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<float4_t*>(dst) = f;
+}
 template <typename T> __device__ __forceinline__ void load8(const T* src, float (&v)[8]);
 template <> __device__ __forceinline__ void load8<half_t>(const half_t* src, float (&v)[8]) {
   half8_t h = *reinterpret_cast<const half8_t*>(src);
@@ -33,19 +42,26 @@ template <> __device__ __forceinline__ void load8<float>(const float* src, float
   v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
 
-// ---- NCHW fp32 -> NHWC T (channel-padded) ----------------------------------------------------
+// ---- NCHW fp32 -> NHWC T (channel-padded, optionally column-padded "row-packed" layout) ----------------
+// one thread per PHYSICAL pixel (n, y, xp): xp in [lpad, lpad + W) carries data, every other column is zero
 template <typename T>
 __global__ __launch_bounds__(256) void pack_nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y,
-                                                                int C, size_t HW, size_t total, int cpad) {
+                                                                int C, int H, int W, int cpad, int lpad, int wpitch,
+                                                                size_t total) {
+  const size_t HW = (size_t)H * W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = i / HW, pix = i - n * HW;
-    const float* xp = x + n * C * HW + pix;
+    const int xp = (int)(i % wpitch);
+    const size_t row = i / wpitch;          // n * H + yy
+    const size_t n = row / H, yy = row - n * H;
+    const int xx = xp - lpad;
+    const bool live = (unsigned)xx < (unsigned)W;
+    const float* xp_ = x + n * C * HW + yy * W + (live ? xx : 0);
     T* yp = y + i * cpad;
-    for (int c0 = 0; c0 < cpad; c0 += 8) {
-      float v[8];
+    for (int c0 = 0; c0 < cpad; c0 += 4) {
+      float v[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? xp[(size_t)(c0 + e) * HW] : 0.f;
-      store8<T>(yp + c0, v);
+      for (int e = 0; e < 4; ++e) v[e] = (live && c0 + e < C) ? xp_[(size_t)(c0 + e) * HW] : 0.f;
+      store4c<T>(yp + c0, v);
     }
   }
 }
@@ -170,19 +186,25 @@ __global__ __launch_bounds__(64) void rgb_mean_finish_kernel(const float* __rest
   if (threadIdx.x == 0) mean[bc] = s * inv_L;
 }
 
-// ---- (x - mean) / rgb_max and NHWC packing of the frame pair ------------------------------------
+// ---- (x - mean) / rgb_max and NHWC packing of the frame pair (optionally row-packed) ---------------------
 template <typename T>
 __global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __restrict__ in, const float* __restrict__ mean,
-                                                             float rgb_max, T* __restrict__ y, int B, size_t HW,
-                                                             size_t total, int mode) {
+                                                             float rgb_max, T* __restrict__ y, int B, int H, int W,
+                                                             int lpad, int wpitch, size_t total, int mode) {
+  const size_t HW = (size_t)H * W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t b = i / HW, pix = i - b * HW;
+    const int xp = (int)(i % wpitch);
+    const size_t row = i / wpitch;          // b * H + yy
+    const size_t b = row / H, yy = row - b * H;
+    const int xx = xp - lpad;
+    const bool live = (unsigned)xx < (unsigned)W;
+    const size_t pix = yy * W + (live ? xx : 0);
     float v[2][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float m = mean[b * 3 + c];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) v[f][c] = (in[((b * 3 + c) * 2 + f) * HW + pix] - m) / rgb_max;
+      for (int f = 0; f < 2; ++f) v[f][c] = live ? (in[((b * 3 + c) * 2 + f) * HW + pix] - m) / rgb_max : 0.f;
     }
     if (mode == 0) {
       const float o[8] = {v[0][0], v[0][1], v[0][2], v[1][0], v[1][1], v[1][2], 0.f, 0.f};
@@ -190,8 +212,8 @@ __global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __rest
     } else {
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        const float o[8] = {v[f][0], v[f][1], v[f][2], 0.f, 0.f, 0.f, 0.f, 0.f};
-        store8<T>(y + (((size_t)f * B + b) * HW + pix) * 8, o);
+        const float o[4] = {v[f][0], v[f][1], v[f][2], 0.f};
+        store4c<T>(y + (((size_t)f * B + b) * H * wpitch + yy * wpitch + xp) * 4, o);
       }
     }
   }
@@ -230,17 +252,18 @@ static inline int grid_for(size_t total) {
 
 using namespace ft;
 
-extern "C" int ft_pack_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int cpad, int dtype,
-                                    ft_stream_t stream) {
-  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cpad < C || cpad % 8) return FT_ERR_INVALID_ARG;
+extern "C" int ft_pack_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int cpad, int lpad, int wpitch,
+                                    int dtype, ft_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cpad < C || cpad % 4) return FT_ERR_INVALID_ARG;
+  if (lpad < 0 || wpitch < lpad + W) return FT_ERR_INVALID_ARG;
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
-  const size_t HW = (size_t)H * W, total = (size_t)N * HW;
+  const size_t total = (size_t)N * H * wpitch;
   if (dtype == FT_F16)
     hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,
-                       static_cast<half_t*>(y), C, HW, total, cpad);
+                       static_cast<half_t*>(y), C, H, W, cpad, lpad, wpitch, total);
   else
     hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,
-                       static_cast<float*>(y), C, HW, total, cpad);
+                       static_cast<float*>(y), C, H, W, cpad, lpad, wpitch, total);
   FT_LAUNCH_CHECK("pack_nchw_to_nhwc_kernel");
   return FT_OK;
 }
@@ -298,17 +321,18 @@ extern "C" int ft_flow_rgb_mean(const float* inputs, int B, int H, int W, float*
 }
 
 extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max, void* y, int B, int H, int W,
-                                 int mode, int dtype, ft_stream_t stream) {
+                                 int mode, int lpad, int wpitch, int dtype, ft_stream_t stream) {
   if (!inputs || !mean || !y || B <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1) || rgb_max == 0.f)
     return FT_ERR_INVALID_ARG;
+  if (lpad < 0 || wpitch < lpad + W) return FT_ERR_INVALID_ARG;
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
-  const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+  const size_t total = (size_t)B * H * wpitch;
   if (dtype == FT_F16)
     hipLaunchKernelGGL(flow_pack_pair_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,
-                       rgb_max, static_cast<half_t*>(y), B, HW, total, mode);
+                       rgb_max, static_cast<half_t*>(y), B, H, W, lpad, wpitch, total, mode);
   else
     hipLaunchKernelGGL(flow_pack_pair_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,
-                       rgb_max, static_cast<float*>(y), B, HW, total, mode);
+                       rgb_max, static_cast<float*>(y), B, H, W, lpad, wpitch, total, mode);
   FT_LAUNCH_CHECK("flow_pack_pair_kernel");
   return FT_OK;
 }

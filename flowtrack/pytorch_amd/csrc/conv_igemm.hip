@@ -58,7 +58,8 @@ struct ConvParams {
   int x_cstride, x_coff;
   int kh, kw;       // taps per phase (2x2 for transposed)
   int dmul;         // +1 conv, -1 transposed
-  int pad;          // conv padding (unused for transposed)
+  int pad;          // conv padding, rows (unused for transposed)
+  int pad_x;        // conv padding, columns (row-packed inputs: pad - x_lpad <= 0, the buffer holds the zeros)
   int transposed;
   int cin_groups;   // generic path: roundup8(Cin) / VEC
   int kc;           // dma path: K-steps per tap = cin_pad / BK
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int m0 = ptile * BP;
   const int co0 = ctile * BC;
   const int dbase_y = p.transposed ? py : -p.pad;
-  const int dbase_x = p.transposed ? px : -p.pad;
+  const int dbase_x = p.transposed ? px : -p.pad_x;
 
   // ---- per-thread loader state -------------------------------------------------------------
   int b_row[NB], b_iy0[NB], b_ix0[NB];
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   const int m0 = ptile * BP;
   const int co0 = ctile * BC;
   const int dbase_y = p.transposed ? py : -p.pad;
-  const int dbase_x = p.transposed ? px : -p.pad;
+  const int dbase_x = p.transposed ? px : -p.pad_x;
   constexpr int esz = (int)sizeof(T);
 
   // buffer descriptors: weights of this (phase, co tile); the whole activation buffer
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvParams p, in
       for (int c = 0; c < NCO; ++c) wv[c] = sw[c * nvec + v];
 #pragma unroll
       for (int i = 0; i < PIX; ++i) {
-        const int iy = py_[i] * p.sy - p.pad + ky, ix = px_[i] * p.sy - p.pad + kx;
+        const int iy = py_[i] * p.sy - p.pad + ky, ix = px_[i] * p.sy - p.pad_x + kx;
         uint4_t xv = {0u, 0u, 0u, 0u};
         if (m + i < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
           const size_t off = ((size_t)(pn[i] * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff + cg * VEC;
@@ -875,8 +876,14 @@ static int validate(const ft_conv_desc* d) {
   if (!d) return FT_ERR_INVALID_ARG;
   if (d->dtype != FT_F16 && d->dtype != FT_F32) return FT_ERR_INVALID_ARG;
   if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Cin <= 0 || d->Cout <= 0) return FT_ERR_INVALID_ARG;
-  if (d->x_cstride % 8 || d->x_coff % 8 || d->x_coff < 0) return FT_ERR_INVALID_ARG;
-  if (d->x_cstride < d->x_coff + round_up(d->Cin, 8)) return FT_ERR_INVALID_ARG;
+  if (d->x_wpitch > 0) {  // row-packed input
+    if (d->transposed || d->x_coff != 0 || d->x_cstride % 4 || d->x_cstride < d->Cin) return FT_ERR_INVALID_ARG;
+    if (d->x_lpad < d->pad || d->x_wpitch < d->x_lpad + d->Wi) return FT_ERR_INVALID_ARG;
+  } else {
+    if (d->x_wpitch < 0 || d->x_lpad != 0) return FT_ERR_INVALID_ARG;
+    if (d->x_cstride % 8 || d->x_coff % 8 || d->x_coff < 0) return FT_ERR_INVALID_ARG;
+    if (d->x_cstride < d->x_coff + round_up(d->Cin, 8)) return FT_ERR_INVALID_ARG;
+  }
   if (d->transposed) {
     if (d->kh != 4 || d->kw != 4 || d->stride != 2 || d->pad != 1) return FT_ERR_UNSUPPORTED;
     if (d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi) return FT_ERR_INVALID_ARG;
@@ -903,7 +910,9 @@ static int validate(const ft_conv_desc* d) {
 // transposed, x_cstride - x_coff): NOT on the batch / spatial size, so weights are packed once per layer.
 struct Geometry {
   int nphases, ntaps, cin_pad, cout_pad, kpad;
+  int run_taps, run_cpad;         // row-packed: kernel columns per K-run and their channel stride; else 1, cin_pad
   int dma;                        // 1: conv_igemm_dma_kernel, 0: generic conv_igemm_kernel
+  int rowpack;
   int nk, cin_groups, vec, kc;    // K-loop bookkeeping of the chosen kernel
 };
 
@@ -915,6 +924,24 @@ static int geometry(const ft_conv_desc* d, Geometry* g) {
   g->nphases = d->transposed ? 4 : 1;
   g->ntaps = d->transposed ? 4 : d->kh * d->kw;
   const int bk = kDmaBKB / esz;
+  g->rowpack = 0;
+  if (d->x_wpitch > 0) {
+    // one K-run = one kernel row: kw taps x x_cstride channels, padded to whole K-steps with zero weights
+    if (d->Cout <= 32 || d->kh > 32) return FT_ERR_UNSUPPORTED;
+    const int run = round_up(d->kw * d->x_cstride, bk);
+    if ((long long)128 * d->kh * run * esz >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
+    g->rowpack = g->dma = 1;
+    g->ntaps = d->kh;
+    g->cin_pad = run;
+    g->cout_pad = round_up(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
+    g->kc = run / bk;
+    g->nk = g->ntaps * g->kc;
+    g->kpad = g->ntaps * run;
+    g->cin_groups = 0;
+    g->run_taps = d->kw;
+    g->run_cpad = d->x_cstride;
+    return FT_OK;
+  }
   const int cin_bk = round_up(d->Cin, bk);
   const long long wbytes = (long long)128 * g->ntaps * cin_bk * esz;  // one co tile of packed weights
   g->dma = d->Cout > 32 && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
@@ -935,6 +962,8 @@ static int geometry(const ft_conv_desc* d, Geometry* g) {
     g->kpad = g->nk * ch * g->vec;
     g->kc = 0;
   }
+  g->run_taps = 1;
+  g->run_cpad = g->cin_pad;
   return FT_OK;
 }
 
@@ -977,25 +1006,31 @@ static int env_int(const char* name) {  // developer tile overrides (FT_CONV_BP 
 
 using namespace ft;
 
-extern "C" int ft_conv_pack_geometry(const ft_conv_desc* d, int* nphases, int* ntaps, int* cin_pad,
-                                     int* cout_pad, int* kpad) {
+extern "C" int ft_conv_pack_geometry(const ft_conv_desc* d, ft_conv_geometry* out) {
   Geometry g;
   int st = geometry(d, &g);
   if (st != FT_OK) return st;
-  if (nphases) *nphases = g.nphases;
-  if (ntaps) *ntaps = g.ntaps;
-  if (cin_pad) *cin_pad = g.cin_pad;
-  if (cout_pad) *cout_pad = g.cout_pad;
-  if (kpad) *kpad = g.kpad;
+  if (!out) return FT_ERR_INVALID_ARG;
+  out->nphases = g.nphases;
+  out->ntaps = g.ntaps;
+  out->cin_pad = g.cin_pad;
+  out->cout_pad = g.cout_pad;
+  out->kpad = g.kpad;
+  out->run_taps = g.run_taps;
+  out->run_cpad = g.run_cpad;
   return FT_OK;
 }
 
-extern "C" int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int* ky, int* kx) {
+extern "C" int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int sub, int* ky, int* kx) {
   Geometry g;
   int st = geometry(d, &g);
   if (st != FT_OK) return st;
-  if (phase < 0 || phase >= g.nphases || tap < 0 || tap >= g.ntaps || !ky || !kx) return FT_ERR_INVALID_ARG;
-  if (d->transposed) {
+  if (phase < 0 || phase >= g.nphases || tap < 0 || tap >= g.ntaps || sub < 0 || sub >= g.run_taps || !ky || !kx)
+    return FT_ERR_INVALID_ARG;
+  if (g.rowpack) {
+    *ky = tap;
+    *kx = sub;
+  } else if (d->transposed) {
     // out[2q+p] takes in[q + p - t] * W[k],  k = (p == 0) ? 1 + 2t : 2t   
     const int py = phase >> 1, px = phase & 1, ty = tap >> 1, tx = tap & 1;
     *ky = py == 0 ? 1 + 2 * ty : 2 * ty;
@@ -1047,7 +1082,13 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.kw = d->transposed ? 2 : d->kw;
   p.dmul = d->transposed ? -1 : 1;
   p.pad = d->pad;
+  p.pad_x = d->pad;
   p.transposed = d->transposed;
+  if (g.rowpack) {      // the kernel sees a (kh x 1)-tap conv over the physically padded rows
+    p.kw = 1;
+    p.Wi = d->x_wpitch;
+    p.pad_x = d->pad - d->x_lpad;
+  }
   p.cin_groups = g.cin_groups;
   p.kc = g.kc;
   p.nk = g.nk;
@@ -1071,7 +1112,8 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
               d->y_cstride % 8 == 0 && (!d->has_residual || (d->res_coff % 8 == 0 && d->res_cstride % 8 == 0));
   hipStream_t s = as_stream(stream);
   const size_t esz = dtype_size(d->dtype);
-  const unsigned long long x_bytes = (unsigned long long)d->N * d->Hi * d->Wi * d->x_cstride * esz;
+  const unsigned long long x_bytes =
+      (unsigned long long)d->N * d->Hi * (d->x_wpitch > 0 ? d->x_wpitch : d->Wi) * d->x_cstride * esz;
 
   if (g.dma && x_bytes < (1ull << 31)) {
     p.x_bytes = (unsigned)x_bytes;

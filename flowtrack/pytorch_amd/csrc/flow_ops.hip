@@ -331,42 +331,50 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v
 
 template <typename T>
 __global__ __launch_bounds__(256) void flow_warp_concat_kernel(const T* __restrict__ x6, const float* __restrict__ flow,
-                                                               float div_flow, T* __restrict__ y, int H, int W,
-                                                               size_t total) {
+                                                               float div_flow, T* __restrict__ y, int H, int W, int xl,
+                                                               int xp, int yl, int yp, size_t total) {
+  // one thread per PHYSICAL output pixel (b, yy, col): col in [yl, yl + W) carries data, the rest is zero
   const size_t HW = (size_t)H * W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t b = i / HW, pix = i - b * HW;
-    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
-    const float dx = flow[(b * 2 + 0) * HW + pix], dy = flow[(b * 2 + 1) * HW + pix];
-    const float xf = (float)xx + dx, yf = (float)yy + dy;
-    const float fx = floorf(xf), fy = floorf(yf);
-    const float alpha = xf - fx, beta = yf - fy;
-    const int xL = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
-    const int xR = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
-    const int yT = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
-    const int yB = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
-    const float w00 = (1.f - alpha) * (1.f - beta), w01 = alpha * (1.f - beta);
-    const float w10 = (1.f - alpha) * beta, w11 = alpha * beta;
-    const T* img = x6 + b * HW * 8;
-    float c[8], tl[8], tr[8], bl[8], br[8];
-    ld8<T>(img + pix * 8, c);
-    ld8<T>(img + ((size_t)yT * W + xL) * 8, tl);
-    ld8<T>(img + ((size_t)yT * W + xR) * 8, tr);
-    ld8<T>(img + ((size_t)yB * W + xL) * 8, bl);
-    ld8<T>(img + ((size_t)yB * W + xR) * 8, br);
-    float warp[3], nrm = 0.f;
+    const int col = (int)(i % yp);
+    const size_t row = i / yp;
+    const size_t b = row / H;
+    const int yy = (int)(row - b * H);
+    const int xx = col - yl;
+    float lo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)xx < (unsigned)W) {
+      const size_t pix = (size_t)yy * W + xx;
+      const float dx = flow[(b * 2 + 0) * HW + pix], dy = flow[(b * 2 + 1) * HW + pix];
+      const float xf = (float)xx + dx, yf = (float)yy + dy;
+      const float fx = floorf(xf), fy = floorf(yf);
+      const float alpha = xf - fx, beta = yf - fy;
+      const int xL = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
+      const int xR = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
+      const int yT = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
+      const int yB = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
+      const float w00 = (1.f - alpha) * (1.f - beta), w01 = alpha * (1.f - beta);
+      const float w10 = (1.f - alpha) * beta, w11 = alpha * beta;
+      const T* img = x6 + b * (size_t)H * xp * 8;
+      float c[8], tl[8], tr[8], bl[8], br[8];
+      ld8<T>(img + ((size_t)yy * xp + xl + xx) * 8, c);
+      ld8<T>(img + ((size_t)yT * xp + xl + xL) * 8, tl);
+      ld8<T>(img + ((size_t)yT * xp + xl + xR) * 8, tr);
+      ld8<T>(img + ((size_t)yB * xp + xl + xL) * 8, bl);
+      ld8<T>(img + ((size_t)yB * xp + xl + xR) * 8, br);
+      float warp[3], nrm = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float v = w00 * tl[3 + k];
-      v += w01 * tr[3 + k];
-      v += w10 * bl[3 + k];
-      v += w11 * br[3 + k];
-      warp[k] = v;
-      const float d = c[k] - v;
-      nrm += d * d;
+      for (int k = 0; k < 3; ++k) {
+        float v = w00 * tl[3 + k];
+        v += w01 * tr[3 + k];
+        v += w10 * bl[3 + k];
+        v += w11 * br[3 + k];
+        warp[k] = v;
+        const float d = c[k] - v;
+        nrm += d * d;
+      }
+      lo[0] = c[0]; lo[1] = c[1]; lo[2] = c[2]; lo[3] = c[3]; lo[4] = c[4]; lo[5] = c[5]; lo[6] = warp[0]; lo[7] = warp[1];
+      hi[0] = warp[2]; hi[1] = dx / div_flow; hi[2] = dy / div_flow; hi[3] = sqrtf(nrm);
     }
-    const float lo[8] = {c[0], c[1], c[2], c[3], c[4], c[5], warp[0], warp[1]};
-    const float hi[8] = {warp[2], dx / div_flow, dy / div_flow, sqrtf(nrm), 0.f, 0.f, 0.f, 0.f};
     st8<T>(y + i * 16, lo);
     st8<T>(y + i * 16 + 8, hi);
   }
@@ -487,16 +495,19 @@ extern "C" int ft_channelnorm_fwd(const float* in1, float* out, int B, int C, in
 }
 
 extern "C" int ft_flow_warp_concat(const void* x6, const float* flow, float div_flow, void* y, int B, int H, int W,
-                                   int dtype, ft_stream_t stream) {
+                                   int x_lpad, int x_wpitch, int y_lpad, int y_wpitch, int dtype, ft_stream_t stream) {
   if (!x6 || !flow || !y || B <= 0 || H <= 0 || W <= 0 || div_flow == 0.f) return FT_ERR_INVALID_ARG;
+  if (x_lpad < 0 || y_lpad < 0 || x_wpitch < x_lpad + W || y_wpitch < y_lpad + W) return FT_ERR_INVALID_ARG;
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
-  const size_t total = (size_t)B * H * W;
+  const size_t total = (size_t)B * H * y_wpitch;
   if (dtype == FT_F16)
     hipLaunchKernelGGL(flow_warp_concat_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                       static_cast<const half_t*>(x6), flow, div_flow, static_cast<half_t*>(y), H, W, total);
+                       static_cast<const half_t*>(x6), flow, div_flow, static_cast<half_t*>(y), H, W, x_lpad, x_wpitch,
+                       y_lpad, y_wpitch, total);
   else
     hipLaunchKernelGGL(flow_warp_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                       static_cast<const float*>(x6), flow, div_flow, static_cast<float*>(y), H, W, total);
+                       static_cast<const float*>(x6), flow, div_flow, static_cast<float*>(y), H, W, x_lpad, x_wpitch,
+                       y_lpad, y_wpitch, total);
   FT_LAUNCH_CHECK("flow_warp_concat_kernel");
   return FT_OK;
 }

@@ -24,7 +24,8 @@ import torch.nn as nn
 
 from .. import _lib
 from ..engine import HipModule
-from ..hip_ops import ActView, FlowtrackHipError, FusedConv, Program, act_stride, new_act, record_upsample4x
+from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, Program, act_stride, new_act, new_rowpacked_act,
+                       record_upsample4x)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
 LEAK = 0.1
@@ -214,7 +215,7 @@ def record_flownets(prog: Program, p: FlowNetS, x: ActView, prefix: str, mk: dic
 
 
 def record_flownetc(prog: Program, p: FlowNetC, x2b: ActView, prefix: str, mk: dict) -> torch.Tensor:
-    """FlowNetC.forward (FlowNetC.py:71-128). x2b: [2B,H,W,8] view with 3 channels, images
+    """FlowNetC.forward (FlowNetC.py:71-128). x2b: row-packed [2B,H,W+6,4] view with 3 channels, images
     0..B-1 = frame 0 and B..2B-1 = frame 1 (the siamese conv1-3 run once on the 2B batch)."""
     B2, H, W, dtype, device = x2b.N, x2b.H, x2b.W, mk["dtype"], mk["device"]
     B = B2 // 2
@@ -257,7 +258,8 @@ class _FlowBase(HipModule):
     div_flow: float = 20.0
 
     def _record_normalise(self, prog: Program, x_static: torch.Tensor, modes, dtype, device):
-        """rgb_mean + (x-mean)/rgb_max (models.py:255-257); returns one NHWC buffer per mode."""
+        """rgb_mean + (x-mean)/rgb_max (models.py:255-257); returns one row-packed NHWC view per mode
+        (mode 0: [B,H,W+6,8] with 6 channels; mode 1: [2B,H,W+6,4] with 3 channels; conv1 is 7x7/s2/p3)."""
         B, _, _, H, W = x_static.shape
         partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
         mean = torch.empty((B * 3,), dtype=torch.float32, device=device)
@@ -265,11 +267,10 @@ class _FlowBase(HipModule):
                  keep=(x_static, partial, mean))
         outs = []
         for mode in modes:
-            n = B if mode == 0 else 2 * B
-            buf = torch.zeros((n, H, W, 8), dtype=dtype, device=device)
+            view = new_rowpacked_act(B if mode == 0 else 2 * B, H, W, 6 if mode == 0 else 3, 3, dtype, device)
             prog.add("ft_flow_pack_pair", x_static.data_ptr(), mean.data_ptr(), ctypes.c_float(self.rgb_max),
-                     buf.data_ptr(), B, H, W, mode, _lib.dtype_code(dtype), keep=(buf,))
-            outs.append(buf)
+                     view.t.data_ptr(), B, H, W, mode, view.lpad, view.wpitch, _lib.dtype_code(dtype), keep=(view.t,))
+            outs.append(view)
         return outs
 
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:  # pragma: no cover - abstract
@@ -315,7 +316,7 @@ class FlowNet2S(FlowNetS, _FlowBase):
         mk = dict(dtype=dtype, device=device)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
         (x6,) = self._record_normalise(prog, x_static, (0,), dtype, device)
-        flow2 = record_flownets(prog, self, ActView(x6, 6, 0), "", mk)
+        flow2 = record_flownets(prog, self, x6, "", mk)
         out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
         record_upsample4x(prog, flow2, out, self.div_flow)  # upsample1(flow2 * div_flow), models.py:292
         return _FlowPlan(prog, x_static, out)
@@ -333,7 +334,7 @@ class FlowNet2C(FlowNetC, _FlowBase):
         mk = dict(dtype=dtype, device=device)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
         (x2b,) = self._record_normalise(prog, x_static, (1,), dtype, device)
-        flow2 = record_flownetc(prog, self, ActView(x2b, 3, 0), "", mk)
+        flow2 = record_flownetc(prog, self, x2b, "", mk)
         out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
         record_upsample4x(prog, flow2, out, self.div_flow)
         return _FlowPlan(prog, x_static, out)
@@ -358,13 +359,14 @@ class FlowNet2CS(_FlowBase):
         mk = dict(dtype=dtype, device=device)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
         x6, x2b = self._record_normalise(prog, x_static, (0, 1), dtype, device)
-        flow2c = record_flownetc(prog, self.flownetc, ActView(x2b, 3, 0), "flownetc.", mk)
+        flow2c = record_flownetc(prog, self.flownetc, x2b, "flownetc.", mk)
         flowc = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
         record_upsample4x(prog, flow2c, flowc, self.div_flow)           # models.py:393-394
-        concat1 = torch.zeros((B, H, W, 16), dtype=dtype, device=device)
-        prog.add("ft_flow_warp_concat", x6.data_ptr(), flowc.data_ptr(), ctypes.c_float(self.div_flow),
-                 concat1.data_ptr(), B, H, W, _lib.dtype_code(dtype), keep=(x6, flowc, concat1))  # models.py:396-403
-        flow2s = record_flownets(prog, self.flownets_1, ActView(concat1, 12, 0), "flownets_1.", mk)
+        concat1 = new_rowpacked_act(B, H, W, 12, 3, dtype, device)
+        prog.add("ft_flow_warp_concat", x6.t.data_ptr(), flowc.data_ptr(), ctypes.c_float(self.div_flow),
+                 concat1.t.data_ptr(), B, H, W, x6.lpad, x6.wpitch, concat1.lpad, concat1.wpitch,
+                 _lib.dtype_code(dtype), keep=(x6.t, flowc, concat1.t))                           # models.py:396-403
+        flow2s = record_flownets(prog, self.flownets_1, concat1, "flownets_1.", mk)
         out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
         record_upsample4x(prog, flow2s, out, self.div_flow)             # models.py:406-407
         return _FlowPlan(prog, x_static, out)

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from ._lib import (FT_ACT_LEAKY, FT_ACT_NONE, FT_ACT_RELU, FT_LAYOUT_NCHW_F32, FT_LAYOUT_NHWC,
-                   ConvDesc, FlowtrackHipError, check)
+                   ConvDesc, ConvGeometry, FlowtrackHipError, check)
 
 ACT_CODES = {None: FT_ACT_NONE, "none": FT_ACT_NONE, "relu": FT_ACT_RELU, "leaky": FT_ACT_LEAKY}
 
@@ -36,28 +36,46 @@ def round_up(x: int, m: int) -> int:
 
 @dataclass
 class ActView:
-    """Channel window [coff, coff+C) of an NHWC buffer t = [N, H, W, cstride]."""
+    """Channel window [coff, coff+C) of an NHWC buffer t = [N, H, wpitch, cstride].
+
+    Plain buffers have wpitch == W.  *Row-packed* buffers (inputs of the small-Cin 7x7 stems) carry
+    `lpad` zero columns left of pixel 0 and zero columns up to `wpitch` on the right, so a whole kernel
+    row is one contiguous K-run for the direct-to-LDS conv kernel (include/flowtrack_hip.h, x_wpitch)."""
     t: torch.Tensor
     C: int
     coff: int = 0
+    lpad: int = 0
+    width: Optional[int] = None   # logical W of a row-packed buffer
 
     @property
     def N(self): return self.t.shape[0]
     @property
     def H(self): return self.t.shape[1]
     @property
-    def W(self): return self.t.shape[2]
+    def W(self): return self.width if self.width is not None else self.t.shape[2]
+    @property
+    def wpitch(self): return self.t.shape[2]
+    @property
+    def rowpacked(self): return self.width is not None
     @property
     def cstride(self): return self.t.shape[3]
 
     def batch_slice(self, lo: int, hi: int) -> "ActView":
-        return ActView(self.t[lo:hi], self.C, self.coff)
+        return ActView(self.t[lo:hi], self.C, self.coff, self.lpad, self.width)
 
 
 def act_stride(C: int) -> int:
     """Channel stride of an NHWC buffer that holds C channels: a multiple of 32 once C >= 32 so the
     direct-to-LDS conv kernel (K-steps of 32 fp16 / 16 fp32 channels) can read it; 8 below that."""
     return round_up(C, 32) if C >= 32 else round_up(C, 8)
+
+
+def new_rowpacked_act(N: int, H: int, W: int, C: int, pad: int, dtype, device) -> ActView:
+    """Zero-filled row-packed input buffer for a stem conv with padding `pad`: channels padded to 4
+    (C <= 4) or a multiple of 8, `pad` zero columns on each side (pitch rounded up to even)."""
+    cpad = 4 if C <= 4 else round_up(C, 8)
+    wpitch = round_up(W + 2 * pad, 2)
+    return ActView(torch.zeros((N, H, wpitch, cpad), dtype=dtype, device=device), C, 0, pad, W)
 
 
 def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int] = None) -> ActView:
@@ -150,35 +168,39 @@ class Program:
 # --------------------------------------------------------------------------------------------
 # fused conv / transposed conv
 # --------------------------------------------------------------------------------------------
+def conv_geometry(d: ConvDesc) -> ConvGeometry:
+    g = ConvGeometry()
+    check(_lib.load().ft_conv_pack_geometry(ctypes.byref(d), ctypes.byref(g)), "ft_conv_pack_geometry")
+    return g
+
+
 def pack_conv_weights(weight: torch.Tensor, d: ConvDesc, *, dtype: torch.dtype,
                       device: torch.device) -> Tuple[torch.Tensor, int]:
     """Re-lay reference weights for the implicit-GEMM kernels, for the layer described by `d`.
 
     weight: Conv2d [Cout, Cin, kh, kw] or ConvTranspose2d [Cin, Cout, 4, 4] (reference layouts,
     SURVEY Appendix B).  Returns ([nphases, Cout_pad, Kpad] tensor of `dtype` on `device`,
-    Cout_pad); k = tap * cin_pad + ci, zeros in all padding.  Both the geometry (which depends on the
-    kernel the library will choose for `d`) and the tap -> (ky, kx) map come from the library
-    (ft_conv_pack_geometry / ft_conv_tap_source), so packer and kernels cannot disagree."""
+    Cout_pad); k = tap * cin_pad + sub * run_cpad + ci, zeros in all padding.  Both the geometry (which
+    depends on the kernel the library will choose for `d`) and the (tap, sub) -> (ky, kx) map come from
+    the library (ft_conv_pack_geometry / ft_conv_tap_source), so packer and kernels cannot disagree."""
     lib = _lib.load()
     w = weight.detach().to(torch.float32).cpu()
     transposed = bool(d.transposed)
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-    nph, ntaps, cin_pad, cout_pad, kpad = (ctypes.c_int() for _ in range(5))
-    check(lib.ft_conv_pack_geometry(ctypes.byref(d), ctypes.byref(nph), ctypes.byref(ntaps), ctypes.byref(cin_pad),
-                                    ctypes.byref(cout_pad), ctypes.byref(kpad)), "ft_conv_pack_geometry")
-    nph, ntaps, cin_pad, cout_pad, kpad = nph.value, ntaps.value, cin_pad.value, cout_pad.value, kpad.value
-    packed = torch.zeros((nph, cout_pad, kpad), dtype=torch.float32)
+    g = conv_geometry(d)
+    packed = torch.zeros((g.nphases, g.cout_pad, g.kpad), dtype=torch.float32)
     ky, kx = ctypes.c_int(), ctypes.c_int()
-    for ph in range(nph):
-        for t in range(ntaps):
-            check(lib.ft_conv_tap_source(ctypes.byref(d), ph, t, ctypes.byref(ky), ctypes.byref(kx)),
-                  "ft_conv_tap_source")
-            if transposed:
-                tap_w = w[:, :, ky.value, kx.value].t()  # [Cout, Cin]
-            else:
-                tap_w = w[:, :, ky.value, kx.value]      # [Cout, Cin]
-            packed[ph, :cout, t * cin_pad:t * cin_pad + cin] = tap_w
-    return packed.to(device=device, dtype=dtype).contiguous(), cout_pad
+    for ph in range(g.nphases):
+        for t in range(g.ntaps):
+            for sub in range(g.run_taps):
+                check(lib.ft_conv_tap_source(ctypes.byref(d), ph, t, sub, ctypes.byref(ky), ctypes.byref(kx)),
+                      "ft_conv_tap_source")
+                tap_w = w[:, :, ky.value, kx.value]
+                if transposed:
+                    tap_w = tap_w.t()                     # [Cout, Cin]
+                k0 = t * g.cin_pad + sub * g.run_cpad
+                packed[ph, :cout, k0:k0 + cin] = tap_w
+    return packed.to(device=device, dtype=dtype).contiguous(), g.cout_pad
 
 
 def fold_scale_shift(cout: int, cout_pad: int, bias: Optional[torch.Tensor], bn: Optional[dict],
@@ -236,9 +258,7 @@ class FusedConv:
 
     def _packed_for(self, d: ConvDesc):
         """Packed weights + folded scale/shift for the kernel the library picks for `d` (cached per layout)."""
-        g = [ctypes.c_int() for _ in range(5)]
-        check(self.lib.ft_conv_pack_geometry(ctypes.byref(d), *[ctypes.byref(v) for v in g]), "ft_conv_pack_geometry")
-        key = tuple(v.value for v in g)
+        key = conv_geometry(d).key()
         hit = self._packed.get(key)
         if hit is None:
             w, cout_pad = pack_conv_weights(self._weight, d, dtype=self.dtype, device=self.device)
@@ -262,6 +282,8 @@ class FusedConv:
         d.dtype = self.code
         d.N, d.Hi, d.Wi = x.N, x.H, x.W
         d.Cin, d.x_cstride, d.x_coff = self.cin, x.cstride, x.coff
+        if x.rowpacked:
+            d.x_lpad, d.x_wpitch = x.lpad, x.wpitch
         d.Cout, d.kh, d.kw = self.cout, self.k, self.k
         d.stride, d.pad, d.transposed = self.stride, self.pad, int(self.transposed)
         d.Ho, d.Wo = Ho, Wo
@@ -297,7 +319,7 @@ class FusedConv:
 # --------------------------------------------------------------------------------------------
 def record_pack_input(prog: Program, x_nchw: torch.Tensor, y: ActView) -> None:
     N, C, H, W = x_nchw.shape
-    prog.add("ft_pack_nchw_to_nhwc", x_nchw.data_ptr(), y.t.data_ptr(), N, C, H, W, y.cstride,
+    prog.add("ft_pack_nchw_to_nhwc", x_nchw.data_ptr(), y.t.data_ptr(), N, C, H, W, y.cstride, y.lpad, y.wpitch,
              _lib.dtype_code(y.t.dtype), keep=(x_nchw, y.t))
 
 

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from ..engine import HipModule
-from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, Program, new_act, record_maxpool,
+from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, Program, new_act, new_rowpacked_act, record_maxpool,
                        record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -123,7 +123,7 @@ class DeconvResnet(HipModule):
         prog = Program(self._side_stream(device))
         mk = dict(dtype=dtype, device=device)
         x_static = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
-        a_in = new_act(B, H, W, 3, dtype, device)
+        a_in = new_rowpacked_act(B, H, W, 3, 3, dtype, device)   # 7x7/s2/p3 stem: one kernel row = one K-run
         record_pack_input(prog, x_static, a_in)
 
         stem = FusedConv(self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(), act="relu", label="conv1", **mk)

@@ -109,21 +109,34 @@ typedef struct ft_conv_desc {
   int res_cstride, res_coff; /* residual is NHWC, output geometry */
   int act;         /* FT_ACT_* */
   float slope;     /* LeakyReLU negative slope */
+  /* Row-packed input (small-Cin stem layers, e.g. the 7x7/s2 convs on 3/6/12 channels): when
+   * x_wpitch > 0 the input buffer is [N, Hi, x_wpitch, x_cstride] with x_lpad >= pad zero columns
+   * physically present left of pixel 0 and zero columns on the right up to x_wpitch.  A whole kernel
+   * ROW (kw taps x x_cstride channels, contiguous in memory) then is one K-run, so the direct-to-LDS
+   * kernel applies although Cin is tiny.  0 = plain NHWC. */
+  int x_lpad, x_wpitch;
 } ft_conv_desc;
 
-/* Packed-weight geometry for `d`: w_packed is [nphases][Cout_pad][Kpad] of
- * d->dtype with k = tap * cin_pad + ci (zeros in all padding). nphases is 1 for
- * conv, 4 for the transposed conv (one 2x2 conv per output parity).  The layout
- * depends only on (dtype, Cin, Cout, kernel, transposed, x_cstride - x_coff):
- * when the input view has room for cin_pad = roundup(Cin, 32 fp16 / 16 fp32)
- * channels per pixel (padding channels zero) the direct-to-LDS kernel is used and
- * every tap's channel run is padded to that multiple; otherwise cin_pad =
- * roundup(Cin, 8) and the generic kernel runs. */
-int ft_conv_pack_geometry(const ft_conv_desc* d, int* nphases, int* ntaps,
-                          int* cin_pad, int* cout_pad, int* kpad);
-/* Which original kernel element (ky, kx) tap `tap` of phase `phase` reads. */
-int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int* ky,
-                       int* kx);
+/* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,
+ * zeros in all padding, and the element for (tap, sub, ci) sits at k = tap*cin_pad + sub*run_cpad + ci.
+ * Plain layers: run_taps = 1 (sub = 0), tap = kernel element.  Row-packed layers: tap = kernel row,
+ * sub = kernel column (run_taps = kw, run_cpad = x_cstride). ft_conv_tap_source maps (phase,tap,sub)
+ * to the reference kernel element (ky,kx). */
+typedef struct ft_conv_geometry {
+  int nphases;   /* 1 conv, 4 transposed conv (one 2x2 conv per output parity) */
+  int ntaps;     /* K-runs per phase */
+  int cin_pad;   /* elements per K-run (channels padded; row-packed: roundup(kw * x_cstride)) */
+  int cout_pad, kpad;
+  int run_taps, run_cpad;
+} ft_conv_geometry;
+
+/* The layout depends only on (dtype, Cin, Cout, kernel, transposed, x_cstride - x_coff, row-packing):
+ * when the input view has room for roundup(Cin, 32 fp16 / 16 fp32) channels per pixel (padding
+ * channels zero) - or is row-packed - the direct-to-LDS kernel is used and every K-run is padded to
+ * that multiple; otherwise cin_pad = roundup(Cin, 8) and the generic kernel runs. */
+int ft_conv_pack_geometry(const ft_conv_desc* d, ft_conv_geometry* out);
+/* Which original kernel element (ky, kx) element `sub` of K-run `tap` of phase `phase` reads. */
+int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int sub, int* ky, int* kx);
 /* scale/shift: float[Cout_pad] or NULL (=> 1 / 0). residual may be NULL. */
 int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
                   const float* scale, const float* shift, const void* residual,
@@ -132,10 +145,12 @@ int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
 double ft_conv_flops(const ft_conv_desc* d);
 
 /* ---- layout / pooling helpers -------------------------------------------- */
-/* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,W,cpad] (channels >= C zeroed).
+/* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,wpitch,cpad]: pixel x lands in column lpad + x, channels
+ * >= C and all other columns are zeroed (wpitch = W, lpad = 0: plain NHWC; cpad multiple of 4).
  * First step of DeconvResnet.forward (pose_deconv.py:32-33). */
 int ft_pack_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W,
-                         int cpad, int dtype, ft_stream_t stream);
+                         int cpad, int lpad, int wpitch, int dtype,
+                         ft_stream_t stream);
 /* NHWC `dtype` (channel stride/offset) -> NCHW fp32 */
 int ft_unpack_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W,
                            int x_cstride, int x_coff, int dtype,
@@ -162,12 +177,13 @@ int ft_heatmap_max_preds(const float* heatmaps, int N, int K, int H, int W,
 #define FT_RGB_MEAN_SPLITS 64
 int ft_flow_rgb_mean(const float* inputs, int B, int H, int W, float* partial,
                      float* mean, ft_stream_t stream);
-/* mode 0: y = NHWC [B,H,W,8]   channels (r0,g0,b0,r1,g1,b1,0,0)   (FlowNet2S)
- * mode 1: y = NHWC [2B,H,W,8]  images 0..B-1 = frame0, B..2B-1 = frame1,
- *         channels (r,g,b,0...)                      (FlowNetC siamese trunk) */
+/* mode 0: y = NHWC [B,H,wpitch,8]   channels (r0,g0,b0,r1,g1,b1,0,0)   (FlowNet2S)
+ * mode 1: y = NHWC [2B,H,wpitch,4]  images 0..B-1 = frame0, B..2B-1 = frame1,
+ *         channels (r,g,b,0)                           (FlowNetC siamese trunk)
+ * pixel x lands in column lpad + x; the other columns are zeroed (wpitch = W, lpad = 0: plain). */
 int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max,
-                      void* y, int B, int H, int W, int mode, int dtype,
-                      ft_stream_t stream);
+                      void* y, int B, int H, int W, int mode, int lpad,
+                      int wpitch, int dtype, ft_stream_t stream);
 
 /* ---- F7: nn.Upsample(scale_factor=4, mode='bilinear') * mul ----------------
  * (FlowNetS.py:58, models.py:292; align_corners=False).  NCHW fp32 in/out. */
@@ -210,13 +226,13 @@ int ft_channelnorm_fwd(const float* in1, float* out, int B, int C, int H, int W,
                        ft_stream_t stream);
 
 /* ---- F5+F6 fused stage between stacked FlowNets (models.py:396-403) -------
- * From x6 = NHWC `dtype` [B,H,W,8] (normalised img0|img1) and flow NCHW fp32
- * [B,2,H,W] (already multiplied by div_flow) builds the 12-channel input of the
+ * From x6 = NHWC `dtype` [B,H,x_wpitch,8] (normalised img0|img1, pixel x in column x_lpad + x) and
+ * flow NCHW fp32 [B,2,H,W] (already multiplied by div_flow) builds the 12-channel input of the
  * next FlowNetS: (img0, img1, warp(img1,flow), flow/div_flow, |img0-warp|)
- * as NHWC `dtype` [B,H,W,16] (channels 12..15 zero). */
+ * as NHWC `dtype` [B,H,y_wpitch,16] (channels 12..15 and the padding columns zero). */
 int ft_flow_warp_concat(const void* x6, const float* flow, float div_flow,
-                        void* y, int B, int H, int W, int dtype,
-                        ft_stream_t stream);
+                        void* y, int B, int H, int W, int x_lpad, int x_wpitch,
+                        int y_lpad, int y_wpitch, int dtype, ft_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -112,3 +112,51 @@ def test_conv_matches_oracle(hip_lib, case, dtype, layout):
     assert err_nchw <= (2e-4 if dtype == torch.float32 else 2e-3) * scale, f"{name} {dtype}: NCHW max abs err {err_nchw:.3e}"
     # guard channels around the slice untouched
     assert torch.all(ybuf[..., :8] == 7.0) and torch.all(ybuf[..., 8 + Cout:] == 7.0), "wrote outside its channel slice"
+
+
+# ---- row-packed small-Cin stems (7x7/s2 on 3/6/12 channels): whole kernel rows as K-runs -----------------
+ROWPACK = [
+    # name, N, Cin, H, W, Cout, k, stride, pad, bias, bn, act
+    ("pose_stem_3", 2, 3, 64, 48, 64, 7, 2, 3, False, True, "relu"),
+    ("flow_conv1_6", 1, 6, 64, 64, 64, 7, 2, 3, True, False, "leaky"),
+    ("flow_conv1_12", 1, 12, 32, 64, 64, 7, 2, 3, True, False, "leaky"),
+    ("ragged_5x5_s1", 2, 3, 9, 11, 128, 5, 1, 2, True, False, None),
+    ("stem_3x3_s2_cin4", 1, 4, 10, 14, 40, 3, 2, 1, False, True, "relu"),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", ROWPACK, ids=[c[0] for c in ROWPACK])
+def test_rowpacked_conv_matches_oracle(hip_lib, case, dtype):
+    from flowtrack.pytorch_amd.hip_ops import new_rowpacked_act
+    name, N, Cin, H, W, Cout, k, stride, pad, has_bias, has_bn, act = case
+    dev = torch.device("cuda:0")
+    seed = 17
+    w = synth.normal(seed, name + ".w", (Cout, Cin, k, k), std=(2.0 / (Cin * k * k)) ** 0.5)
+    x = synth.normal(seed, name + ".x", (N, Cin, H, W))
+    bias = synth.normal(seed, name + ".b", (Cout,), std=0.2) if has_bias else None
+    bn = None
+    if has_bn:
+        bn = {"weight": synth.uniform(seed, name + ".g", (Cout,), 0.5, 1.5), "bias": synth.normal(seed, name + ".be", (Cout,), 0.1),
+              "running_mean": synth.normal(seed, name + ".m", (Cout,), 0.1), "running_var": synth.uniform(seed, name + ".v", (Cout,), 0.5, 1.5),
+              "eps": 1e-5}
+    if dtype == torch.float16:
+        w, x = w.half().float(), x.half().float()
+    want = _reference(x, w, bias, bn, stride, pad, False, act, None)
+    layer = FusedConv(w, dtype=dtype, device=dev, stride=stride, pad=pad, bias=bias, bn=bn, act=act, slope=0.1, label=name)
+    xv = new_rowpacked_act(N, H, W, Cin, pad, dtype, dev)
+    prog = make_program()
+    # fill through the library's own packer (ft_pack_nchw_to_nhwc with lpad / wpitch), as the networks do
+    from flowtrack.pytorch_amd.hip_ops import record_pack_input
+    gx = x.to(dev)
+    record_pack_input(prog, gx, xv)
+    Ho, Wo = layer.out_hw(H, W)
+    yv = ActView(torch.zeros((N, Ho, Wo, act_stride(Cout)), dtype=dtype, device=dev), Cout, 0)
+    layer.record(prog, xv, yv)
+    run_program(prog)
+    assert torch.all(xv.t[:, :, :xv.lpad] == 0) and torch.all(xv.t[:, :, xv.lpad + W:] == 0) and torch.all(xv.t[..., Cin:] == 0)
+    got = view_to_nchw(yv)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{name} {dtype}: max abs err {err:.3e} (scale {scale:.2f})"

@@ -124,17 +124,21 @@ def test_upsample_and_normalise(hip_lib, oracle_lib):
     assert (mean.cpu().view(B, 3) - want_mean).abs().max() <= 1e-3
     xn = flow_ref._normalise(pair, 255.0)
     for mode in (0, 1):
-        n = B if mode == 0 else 2 * B
-        buf = torch.full((n, H, W, 8), 3.0, device="cuda")
-        check(hip_lib.ft_flow_pack_pair(gp.data_ptr(), mean.data_ptr(), 255.0, buf.data_ptr(), B, H, W, mode, _lib.FT_F32, _stream()))
-        torch.cuda.synchronize()
-        got = buf.cpu()
-        if mode == 0:
-            want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 1).permute(0, 2, 3, 1)
-            assert (got[..., :6] - want).abs().max() <= 1e-5 and torch.all(got[..., 6:] == 0)
-        else:
-            want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 0).permute(0, 2, 3, 1)
-            assert (got[..., :3] - want).abs().max() <= 1e-5 and torch.all(got[..., 3:] == 0)
+        for lpad, wpitch in ((0, W), (3, W + 6)):          # plain NHWC and the row-packed stem layout
+            n, cp = (B, 8) if mode == 0 else (2 * B, 4)
+            buf = torch.full((n, H, wpitch, cp), 3.0, device="cuda")
+            check(hip_lib.ft_flow_pack_pair(gp.data_ptr(), mean.data_ptr(), 255.0, buf.data_ptr(), B, H, W, mode, lpad, wpitch,
+                                            _lib.FT_F32, _stream()))
+            torch.cuda.synchronize()
+            got = buf.cpu()
+            live = got[:, :, lpad:lpad + W]
+            if mode == 0:
+                want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 1).permute(0, 2, 3, 1)
+                assert (live[..., :6] - want).abs().max() <= 1e-5 and torch.all(live[..., 6:] == 0)
+            else:
+                want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 0).permute(0, 2, 3, 1)
+                assert (live[..., :3] - want).abs().max() <= 1e-5 and torch.all(live[..., 3:] == 0)
+            assert torch.all(got[:, :, :lpad] == 0) and torch.all(got[:, :, lpad + W:] == 0)
 
 
 # ---- networks -------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ import torch
 
 from conftest import GOLDEN, ROOT
 from flowtrack.pytorch_amd import _lib
-from flowtrack.pytorch_amd._lib import ConvDesc, FlowtrackHipError
+from flowtrack.pytorch_amd._lib import ConvDesc, ConvGeometry, FlowtrackHipError
 from flowtrack.pytorch_amd.pose import evaluation
 
 
@@ -47,22 +47,35 @@ def _desc(**kw):
     return d
 
 
+def _geom(hip_lib, d):
+    g = ConvGeometry()
+    return hip_lib.ft_conv_pack_geometry(ctypes.byref(d), ctypes.byref(g)), g
+
+
 def test_pack_geometry_and_tap_table(hip_lib):
-    out = [ctypes.c_int() for _ in range(5)]
-    g = lambda d: (hip_lib.ft_conv_pack_geometry(ctypes.byref(d), *[ctypes.byref(o) for o in out]), [o.value for o in out])
-    st, (nph, ntaps, cin8, cout_pad, kpad) = g(_desc())
-    assert st == 0 and (nph, ntaps, cin8, cout_pad) == (1, 9, 64, 64) and kpad == 9 * 64
-    st, (nph, ntaps, cin8, cout_pad, kpad) = g(_desc(Cin=3, x_cstride=8, kh=7, kw=7, stride=2, pad=3, Ho=8, Wo=8))
-    assert st == 0 and (ntaps, cin8) == (49, 8) and kpad % 32 == 0 and kpad >= 49 * 8
-    st, (nph, ntaps, cin8, cout_pad, kpad) = g(_desc(Cin=1026, x_cstride=1032, Cout=256, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=32, Wo=32, y_cstride=256))
-    assert st == 0 and (nph, ntaps, cin8, cout_pad) == (4, 4, 1032, 256)
+    st, g = _geom(hip_lib, _desc())                                  # channel-aligned 3x3: direct-to-LDS layout
+    assert st == 0 and (g.nphases, g.ntaps, g.cin_pad, g.cout_pad, g.kpad, g.run_taps) == (1, 9, 64, 64, 9 * 64, 1)
+    st, g = _geom(hip_lib, _desc(Cin=3, x_cstride=8, kh=7, kw=7, stride=2, pad=3, Ho=8, Wo=8))   # plain stem: generic layout
+    assert st == 0 and (g.ntaps, g.cin_pad) == (49, 8) and g.kpad % 32 == 0 and g.kpad >= 49 * 8
+    st, g = _geom(hip_lib, _desc(Cin=1026, x_cstride=1032, Cout=256, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=32, Wo=32, y_cstride=256))
+    assert st == 0 and (g.nphases, g.ntaps, g.cin_pad, g.cout_pad) == (4, 4, 1032, 256)      # narrow stride: generic
+    st, g = _geom(hip_lib, _desc(Cin=1026, x_cstride=1056, Cout=256, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=32, Wo=32, y_cstride=256))
+    assert st == 0 and g.cin_pad == 1056 and g.kpad == 4 * 1056                               # act_stride: K-runs of 32
+    # row-packed stem: one K-run per kernel ROW = 7 taps x 4 channels padded to 32 fp16 elements
+    rp = _desc(Cin=3, x_cstride=4, kh=7, kw=7, stride=2, pad=3, Ho=8, Wo=8, x_lpad=3, x_wpitch=22)
+    st, g = _geom(hip_lib, rp)
+    assert st == 0 and (g.ntaps, g.cin_pad, g.kpad, g.run_taps, g.run_cpad) == (7, 32, 7 * 32, 7, 4)
+    ky, kx = ctypes.c_int(), ctypes.c_int()
+    assert hip_lib.ft_conv_tap_source(ctypes.byref(rp), 0, 5, 6, ctypes.byref(ky), ctypes.byref(kx)) == 0
+    assert (ky.value, kx.value) == (5, 6)
+    assert hip_lib.ft_conv_tap_source(ctypes.byref(rp), 0, 5, 7, ctypes.byref(ky), ctypes.byref(kx)) == 1
+    assert _geom(hip_lib, _desc(Cin=3, x_cstride=4, kh=7, kw=7, stride=2, pad=3, Ho=8, Wo=8, x_lpad=2, x_wpitch=22))[0] == 1  # lpad < pad
     # transposed tap table: out[2q+p] <- in[q + p - t] * W[k], k = 1+2t (p=0) | 2t (p=1); each (ky,kx) exactly once
     d = _desc(kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=32, Wo=32)
     seen = set()
-    ky, kx = ctypes.c_int(), ctypes.c_int()
     for ph in range(4):
         for t in range(4):
-            assert hip_lib.ft_conv_tap_source(ctypes.byref(d), ph, t, ctypes.byref(ky), ctypes.byref(kx)) == 0
+            assert hip_lib.ft_conv_tap_source(ctypes.byref(d), ph, t, 0, ctypes.byref(ky), ctypes.byref(kx)) == 0
             assert (ky.value + 1) % 2 == ph >> 1 and (kx.value + 1) % 2 == ph & 1
             seen.add((ky.value, kx.value))
     assert len(seen) == 16
@@ -70,10 +83,9 @@ def test_pack_geometry_and_tap_table(hip_lib):
 
 
 def test_bad_arguments_return_status_not_abort(hip_lib):
-    z = [ctypes.byref(ctypes.c_int()) for _ in range(5)]
-    assert hip_lib.ft_conv_pack_geometry(ctypes.byref(_desc(Ho=15)), *z) == 1          # inconsistent output size
-    assert hip_lib.ft_conv_pack_geometry(ctypes.byref(_desc(x_cstride=60)), *z) == 1   # unaligned channel stride
-    assert hip_lib.ft_conv_pack_geometry(ctypes.byref(_desc(kh=3, kw=3, transposed=1, Ho=32, Wo=32)), *z) == 2
+    assert _geom(hip_lib, _desc(Ho=15))[0] == 1          # inconsistent output size
+    assert _geom(hip_lib, _desc(x_cstride=60))[0] == 1   # unaligned channel stride
+    assert _geom(hip_lib, _desc(kh=3, kw=3, transposed=1, Ho=32, Wo=32))[0] == 2
     assert hip_lib.ft_conv2d_fwd(ctypes.byref(_desc()), None, None, None, None, None, None, None) == 1
     assert hip_lib.ft_correlation_fwd(None, None, None, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, None) == 1
     assert hip_lib.ft_resample2d_fwd(None, None, None, 1, 1, 1, 1, None) == 1
