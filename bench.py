@@ -49,6 +49,17 @@ def build_flow(device, dtype, seed=1234):
     return m
 
 
+def pmc_traffic(workload):
+    """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; tools/dev/prof_traffic.sh + pmc_traffic.py on this same command). None if not measured."""
+    path = os.path.join(ROOT, "profiles", f"r01_{workload}_hbm_traffic_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["conv_kernels"]["hbm_bytes_per_launch_avg"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def conv_roofline(prog, dtype_name, iters=5):
     """Per-launch hipEvent timing of the plan on its own stream; aggregates the implicit-GEMM launches."""
     times = prog.time_calls(iters=iters)
@@ -210,6 +221,9 @@ def main():
         out["achieved_tflops_end_to_end"] = round(value / world * plan.prog.flops / B / 1e12, 2)
         if not args.no_roofline:
             roof, per_layer = conv_roofline(plan.prog, args.dtype)
+            if args.dtype == "fp16" and not args.batch:   # the committed PMC run is this exact default workload
+                roof["traffic"] = pmc_traffic(args.workload)
+                roof["traffic_unit"] = "HBM bytes per conv launch (avg), rocprofv3 PMC, profiles/"
             out["roofline"] = roof
             if args.layers:
                 for label, fl, ms in per_layer:

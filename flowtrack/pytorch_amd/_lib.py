@@ -83,6 +83,8 @@ _PROTOTYPES = {
     "ft_correlation_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_int, c_void_p]),
     "ft_resample2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ft_channelnorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_crop_affine_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_void_p]),
     "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]),
 }
 

@@ -24,11 +24,23 @@ class HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._plans: Dict[tuple, object] = {}
+        self._layers: Dict[tuple, object] = {}   # (label, dtype, device) -> FusedConv: packed weights shared by all plans
         self._stream: Optional[torch.cuda.Stream] = None
 
     # -- parameter changes invalidate packed weights ------------------------------------------
     def _invalidate(self):
         self._plans = {}
+        self._layers = {}
+
+    def fused(self, label: str, weight, *, dtype, device, **kw):
+        """FusedConv for `label`, built once per (dtype, device) and shared by every plan (input shape) of this
+        module — weight packing / BN folding is per layer, not per plan."""
+        from .hip_ops import FusedConv
+        key = (label, dtype, str(device))
+        layer = self._layers.get(key)
+        if layer is None:
+            layer = self._layers[key] = FusedConv(weight, dtype=dtype, device=device, label=label, **kw)
+        return layer
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)

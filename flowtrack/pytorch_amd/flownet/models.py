@@ -130,24 +130,30 @@ CORR_CH = (2 * (CORR_MAX_DISP // CORR_STRIDE2) + 1) ** 2  # 441
 
 
 # ---- plan builders ----------------------------------------------------------------------------
+# `mk` carries dtype, device and the owning HipModule (mk["owner"].fused caches packed layers across plans)
+def _mk(mk: dict) -> dict:
+    return {k: v for k, v in mk.items() if k != "owner"}
+
+
 def _fc(seq: nn.Sequential, label: str, mk: dict) -> FusedConv:
     c = seq[0]
     bn = seq[1].as_dict() if isinstance(seq[1], BatchNormParams) else None
-    return FusedConv(c.weight, stride=c.stride, pad=c.padding, bias=c.bias, bn=bn, act="leaky", slope=LEAK,
-                     label=label, **mk)
+    return mk["owner"].fused(label, c.weight, stride=c.stride, pad=c.padding, bias=c.bias, bn=bn, act="leaky", slope=LEAK,
+                             **_mk(mk))
 
 
 def _fd(seq: nn.Sequential, label: str, mk: dict) -> FusedConv:
     c = seq[0]
-    return FusedConv(c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act="leaky", slope=LEAK, label=label, **mk)
+    return mk["owner"].fused(label, c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act="leaky", slope=LEAK,
+                             **_mk(mk))
 
 
 def _fp(c: ConvParams, label: str, mk: dict) -> FusedConv:
-    return FusedConv(c.weight, stride=1, pad=1, bias=c.bias, act=None, label=label, **mk)
+    return mk["owner"].fused(label, c.weight, stride=1, pad=1, bias=c.bias, act=None, **_mk(mk))
 
 
 def _fu(c: ConvTransposeParams, label: str, mk: dict) -> FusedConv:
-    return FusedConv(c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act=None, label=label, **mk)
+    return mk["owner"].fused(label, c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act=None, **_mk(mk))
 
 
 def _record_decoder(prog: Program, p: _Decoder, conv6: ActView, cc5, cc4, cc3, cc2, prefix: str, mk: dict):
@@ -313,7 +319,7 @@ class FlowNet2S(FlowNetS, _FlowBase):
 
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
         prog = Program(self._side_stream(device))
-        mk = dict(dtype=dtype, device=device)
+        mk = dict(dtype=dtype, device=device, owner=self)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
         (x6,) = self._record_normalise(prog, x_static, (0,), dtype, device)
         flow2 = record_flownets(prog, self, x6, "", mk)
@@ -331,7 +337,7 @@ class FlowNet2C(FlowNetC, _FlowBase):
 
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
         prog = Program(self._side_stream(device))
-        mk = dict(dtype=dtype, device=device)
+        mk = dict(dtype=dtype, device=device, owner=self)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
         (x2b,) = self._record_normalise(prog, x_static, (1,), dtype, device)
         flow2 = record_flownetc(prog, self, x2b, "", mk)
@@ -356,7 +362,7 @@ class FlowNet2CS(_FlowBase):
 
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
         prog = Program(self._side_stream(device))
-        mk = dict(dtype=dtype, device=device)
+        mk = dict(dtype=dtype, device=device, owner=self)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
         x6, x2b = self._record_normalise(prog, x_static, (0, 1), dtype, device)
         flow2c = record_flownetc(prog, self.flownetc, x2b, "flownetc.", mk)

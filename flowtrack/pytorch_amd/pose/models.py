@@ -126,7 +126,7 @@ class DeconvResnet(HipModule):
         a_in = new_rowpacked_act(B, H, W, 3, 3, dtype, device)   # 7x7/s2/p3 stem: one kernel row = one K-run
         record_pack_input(prog, x_static, a_in)
 
-        stem = FusedConv(self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(), act="relu", label="conv1", **mk)
+        stem = self.fused("conv1", self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(), act="relu", **mk)
         a1 = new_act(B, H // 2, W // 2, 64, dtype, device)
         stem.record(prog, a_in, a1)
         cur = new_act(B, H // 4, W // 4, 64, dtype, device)
@@ -138,18 +138,17 @@ class DeconvResnet(HipModule):
                 planes = blk.conv1.cout
                 s = blk.stride
                 Ho, Wo = cur.H // s, cur.W // s
-                c1 = FusedConv(blk.conv1.weight, bn=blk.bn1.as_dict(), act="relu", label=name + ".conv1", **mk)
-                c2 = FusedConv(blk.conv2.weight, stride=s, pad=1, bn=blk.bn2.as_dict(), act="relu",
-                               label=name + ".conv2", **mk)
-                c3 = FusedConv(blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", label=name + ".conv3", **mk)
+                c1 = self.fused(name + ".conv1", blk.conv1.weight, bn=blk.bn1.as_dict(), act="relu", **mk)
+                c2 = self.fused(name + ".conv2", blk.conv2.weight, stride=s, pad=1, bn=blk.bn2.as_dict(), act="relu", **mk)
+                c3 = self.fused(name + ".conv3", blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", **mk)
                 t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
                 t2 = new_act(B, Ho, Wo, planes, dtype, device)
                 out = new_act(B, Ho, Wo, planes * 4, dtype, device)
                 c1.record(prog, cur, t1)
                 c2.record(prog, t1, t2)
                 if len(blk.downsample):
-                    ds = FusedConv(blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(), act=None,
-                                   label=name + ".downsample", **mk)
+                    ds = self.fused(name + ".downsample", blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(),
+                                    act=None, **mk)
                     res = new_act(B, Ho, Wo, planes * 4, dtype, device)
                     ds.record(prog, cur, res)
                 else:
@@ -158,13 +157,13 @@ class DeconvResnet(HipModule):
                 cur = out
 
         for i in (0, 3, 6):
-            dc = FusedConv(self.deconv[i].weight, transposed=True, stride=2, pad=1, bias=self.deconv[i].bias,
-                           bn=self.deconv[i + 1].as_dict(), act="relu", label=f"deconv.{i}", **mk)
+            dc = self.fused(f"deconv.{i}", self.deconv[i].weight, transposed=True, stride=2, pad=1, bias=self.deconv[i].bias,
+                            bn=self.deconv[i + 1].as_dict(), act="relu", **mk)
             nxt = new_act(B, cur.H * 2, cur.W * 2, dc.cout, dtype, device)
             dc.record(prog, cur, nxt)
             cur = nxt
 
-        hm = FusedConv(self.heatmap.weight, bias=self.heatmap.bias, act=None, label="heatmap", **mk)
+        hm = self.fused("heatmap", self.heatmap.weight, bias=self.heatmap.bias, act=None, **mk)
         heatmaps = torch.empty((B, self.num_classes, cur.H, cur.W), dtype=torch.float32, device=device)
         hm.record(prog, cur, heatmaps)
         return _PosePlan(prog, x_static, heatmaps)

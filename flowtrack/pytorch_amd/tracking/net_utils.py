@@ -1,0 +1,103 @@
+"""Per-frame glue between the detector boxes, the pose net and the flow net.
+
+Mirrors lib/tracking/net_utils.py (detect :14-34, pose_est :36-71, flow_est :73-92) with its intended
+semantics; what the reference gets wrong is fixed, not copied: `end = max(num_boxes, ...)` (:61) is a `min`,
+crops are normalised before the net (the reference feeds raw 0..255 BGR, :52-63, while its training pipeline
+normalises, lib/pose/datasets/mpii.py:149), the non-existent `transfrom_image` import (:11) is the GPU crop.
+The person DETECTOR is out of scope: `detect` takes the detector's person boxes as input
+and does the part the glue owns — union with the flow-propagated boxes and box NMS.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check
+from ..hip_ops import current_stream_handle, require_gpu
+from ..pose.evaluation import final_preds
+from .flow_utils import nms
+
+# BGR ImageNet statistics on the 0..1 scale (lib/pose/datasets/mpii.py:53-54)
+BGR_MEAN = (0.406, 0.456, 0.485)
+BGR_STD = (0.225, 0.224, 0.229)
+
+
+def detect(person_dets: np.ndarray, thresh: float = 0.3, prop_dets: np.ndarray = None) -> np.ndarray:
+    """Union of detector boxes [n,5] and propagated boxes [m,5], then box NMS (net_utils.py:28-32)."""
+    dets = np.asarray(person_dets, dtype=np.float32).reshape(-1, 5)
+    if prop_dets is not None and len(prop_dets):
+        dets = np.concatenate((dets, np.asarray(prop_dets, dtype=np.float32).reshape(-1, 5)), axis=0)
+    return dets[nms(dets, thresh)]
+
+
+def boxes_to_center_scale(boxes: np.ndarray, inp_res=(256, 192)):
+    """Box -> (center, scale) of the pose crop: aspect-corrected box height (net_utils.py:47-48; the datasets
+    additionally pad by 1.25, lib/pose/datasets/coco.py:110-113 — pass pad=1.25 to crop_boxes for that)."""
+    boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    centers = np.stack((boxes[:, [0, 2]].mean(1), boxes[:, [1, 3]].mean(1)), axis=1)
+    scales = np.maximum(boxes[:, 3] - boxes[:, 1], (boxes[:, 2] - boxes[:, 0]) / inp_res[1] * inp_res[0])
+    return centers, scales
+
+
+def crop_boxes(frame_dev: torch.Tensor, centers: np.ndarray, scales: np.ndarray, inp_res=(256, 192), normalize=True):
+    """frame_dev: uint8 [H,W,3] (BGR) on the GPU -> crops [N,3,h,w] fp32 on the GPU in one launch
+    (ft_crop_affine_fwd; replaces N x cv2.warpAffine + N H2D copies, net_utils.py:49-57)."""
+    require_gpu(frame_dev.device)
+    if frame_dev.dtype != torch.uint8 or frame_dev.dim() != 3 or not frame_dev.is_contiguous():
+        raise ValueError("frame must be a contiguous uint8 [H,W,C] device tensor")
+    lib = _lib.load()
+    H, W, C = frame_dev.shape
+    n = len(scales)
+    params = torch.from_numpy(np.concatenate((np.asarray(centers, np.float32).reshape(n, 2),
+                                              np.asarray(scales, np.float32).reshape(n, 1)), axis=1)).to(frame_dev.device)
+    out = torch.empty((n, C, inp_res[0], inp_res[1]), dtype=torch.float32, device=frame_dev.device)
+    mean = inv_std = None
+    pre = 1.0
+    if normalize:
+        mean = torch.tensor(BGR_MEAN[:C], dtype=torch.float32, device=frame_dev.device)
+        inv_std = torch.tensor([1.0 / s for s in BGR_STD[:C]], dtype=torch.float32, device=frame_dev.device)
+        pre = 1.0 / 255.0
+    check(lib.ft_crop_affine_fwd(frame_dev.data_ptr(), H, W, C, params.data_ptr(), n, inp_res[0], inp_res[1],
+                                 mean.data_ptr() if mean is not None else None,
+                                 inv_std.data_ptr() if inv_std is not None else None, pre, out.data_ptr(),
+                                 current_stream_handle()), "ft_crop_affine_fwd")
+    return out
+
+
+def pose_est(net, frame_dev: torch.Tensor, boxes: np.ndarray, inp_res=(256, 192), max_batch=32, normalize=True):
+    """Single-person pose for every box of a frame -> keypoints [N,K,3] (x, y, score) in image pixels."""
+    boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0, 17, 3), dtype=np.float32)
+    centers, scales = boxes_to_center_scale(boxes, inp_res)
+    crops = crop_boxes(frame_dev, centers, scales, inp_res, normalize)
+    out_c, out_s = [], []
+    for lo in range(0, n, max_batch):
+        hi = min(n, lo + max_batch)                         # the reference's max() here is a bug (net_utils.py:61)
+        m = hi - lo
+        bucket = next(b for b in (4, 8, 16, 32, 64, 128, 1 << 30) if b >= m or b >= max_batch)
+        bucket = min(bucket, max(max_batch, m))             # one cached plan (HIP graph) per bucket, not per count
+        batch = crops[lo:hi]
+        if bucket > m:
+            batch = torch.cat((batch, batch.new_zeros((bucket - m,) + tuple(batch.shape[1:]))), 0)
+        hm = net(batch)[:m]
+        c, s = final_preds(hm, centers[lo:hi], scales[lo:hi], adjust_coords=True)
+        out_c.append(c)
+        out_s.append(s)
+    return np.concatenate((np.concatenate(out_c), np.concatenate(out_s)), axis=2).astype(np.float32)
+
+
+def flow_est(net, prev_frame: torch.Tensor, cur_frame: torch.Tensor) -> np.ndarray:
+    """prev / cur: uint8 [H,W,3] BGR (device or host) -> flow [2,H,W] fp32 numpy (net_utils.py:73-92):
+    BGR -> RGB, pack [1,3,2,H,W] float 0..255, pad to a multiple of 64, crop the flow back."""
+    dev = next(net.parameters()).device
+    pair = torch.stack((torch.as_tensor(prev_frame).to(dev), torch.as_tensor(cur_frame).to(dev)))   # [2,H,W,3]
+    H, W = pair.shape[1:3]
+    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
+    ims = torch.zeros((1, 3, 2, Hp, Wp), dtype=torch.float32, device=dev)
+    ims[0, :, :, :H, :W] = pair.flip(-1).permute(3, 0, 1, 2).float()
+    return net(ims)[0, :, :H, :W].cpu().numpy()

@@ -234,6 +234,16 @@ int ft_flow_warp_concat(const void* x6, const float* flow, float div_flow,
                         void* y, int B, int H, int W, int x_lpad, int x_wpitch,
                         int y_lpad, int y_wpitch, int dtype, ft_stream_t stream);
 
+/* ---- N2: person crops for the pose net --------------------------------------
+ * Replaces the per-box host loop `transform_image` = cv2.warpAffine(img, t[:2], (res_w, res_h))
+ * (lib/pose/utils/transforms.py:231-240, geometry :173-184; caller lib/tracking/net_utils.py:49-57).
+ * img: HWC uint8 frame on the device (C <= 4); boxes: float[nb*3] = (center_x, center_y, scale) per crop;
+ * out: NCHW fp32 [nb, C, rh, rw] = (bilinear(img) * pre_scale - mean[c]) * inv_std[c] (mean / inv_std may be
+ * NULL), constant-0 border, fp32 interpolation weights (cv2's 1/32-px weight quantisation is not reproduced). */
+int ft_crop_affine_fwd(const uint8_t* img, int H, int W, int C, const float* boxes, int nb, int rh, int rw,
+                       const float* mean, const float* inv_std, float pre_scale, float* out,
+                       ft_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

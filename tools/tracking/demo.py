@@ -1,0 +1,187 @@
+"""FlowTrack video pipeline on the HIP path — the driver the reference left unfinished (tools/tracking/demo.py:35-42
+defines process_frame but never calls it; README.md:14).  BASELINE.json configs[4]: detector boxes -> pose crops +
+FlowNet box propagation on a synthetic clip.
+
+    python tools/tracking/demo.py --frames 300 [--pose_backbone 50] [--flow_net FlowNet2S] [--fp16]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/tracking/demo.py --frames 300
+
+Per frame (process_frame, demo.py:35-42): flow(prev, cur) -> propagate previous keypoints' boxes -> union with the
+detector's boxes + box NMS -> pose for every kept box -> flow-based greedy id assignment.
+Multi-GPU decomposition (one process per GPU): the two embarrassingly parallel parts are sharded —
+  phase 1: optical flow of every (t-1, t) pair, pairs sharded by index, flows gathered to rank 0;
+  phase 2: pose of the DETECTOR boxes of every frame, frames sharded by index, keypoints all-gathered;
+  phase 3 (rank 0, sequential in t as the method requires): propagation, union + NMS, pose of the propagated-only
+           boxes that survive NMS, tracking ids.
+The person detector itself is out of scope: boxes come from the synthetic clip generator
+(ground truth + jitter) or from --dets FILE.npz.  Checkpoints: --pose_model / --flow_model in the reference formats;
+without them deterministic synthetic weights are used (outputs are then only structurally meaningful).
+"""
+from __future__ import absolute_import, division, print_function
+
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from flowtrack.pytorch_amd import parallel, synth                                  # noqa: E402
+from flowtrack.pytorch_amd.flownet import models as flow_models                     # noqa: E402
+from flowtrack.pytorch_amd.pose import models as pose_models                        # noqa: E402
+from flowtrack.pytorch_amd.tracking import FlowTracker, box_propagation, detect, flow_est, pose_est  # noqa: E402
+
+
+def synthetic_clip(n_frames, H=384, W=512, n_people=5, seed=0):
+    """Textured rectangles ("people") moving with constant velocity over a textured background.
+    Returns frames uint8 [T,H,W,3] (BGR) and per-frame detector boxes [n,5] = ground truth + U(-3,3) px jitter."""
+    u = lambda name, shape: synth.uniform01(seed, name, shape)
+    bg = (u("bg", (H // 8 + 1, W // 8 + 1, 3)).repeat(8, 0).repeat(8, 1)[:H, :W] * 120 + 40)
+    size = np.stack((40 + 50 * u("pw", (n_people,)), 90 + 90 * u("ph", (n_people,))), 1)          # w, h
+    pos0 = np.stack((u("px", (n_people,)) * (W - 140) + 20, u("py", (n_people,)) * (H - 200) + 10), 1)
+    vel = (u("vel", (n_people, 2)) - 0.5) * 6.0
+    tex = [u("tex%d" % i, (int(size[i, 1]), int(size[i, 0]), 3)) * 200 + 30 for i in range(n_people)]
+    frames = np.empty((n_frames, H, W, 3), dtype=np.uint8)
+    dets = []
+    for t in range(n_frames):
+        img = bg.copy()
+        boxes = []
+        for i in range(n_people):
+            x0, y0 = pos0[i] + vel[i] * t
+            x0 = float(np.clip(x0, 0, W - size[i, 0] - 1))
+            y0 = float(np.clip(y0, 0, H - size[i, 1] - 1))
+            xi, yi = int(x0), int(y0)
+            h, w = tex[i].shape[:2]
+            img[yi:yi + h, xi:xi + w] = tex[i]
+            jit = (synth.uniform01(seed, "jit%d_%d" % (t, i), (4,)) - 0.5) * 6.0
+            score = 0.5 + 0.5 * float(synth.uniform01(seed, "score%d_%d" % (t, i), (1,))[0])
+            boxes.append([x0 + jit[0], y0 + jit[1], x0 + w - 1 + jit[2], y0 + h - 1 + jit[3], score])
+        frames[t] = img.astype(np.uint8)
+        dets.append(np.asarray(boxes, dtype=np.float32))
+    return frames, dets
+
+
+def build_nets(args, device):
+    pose = pose_models.deconv("resnet%d" % args.pose_backbone, num_classes=17, pretrained=False)
+    if args.pose_model:
+        pose.load_state_dict(torch.load(args.pose_model, map_location="cpu")["state_dict"])
+    else:
+        pose.load_state_dict(synth.fill_pose_state_dict(pose.state_dict(), 11))
+    fargs = types.SimpleNamespace(rgb_max=255.0, fp16=args.fp16)
+    flow = getattr(flow_models, args.flow_net)(fargs)
+    if args.flow_model:
+        flow.load_state_dict(torch.load(args.flow_model, map_location="cpu")["state_dict"])
+    else:
+        flow.load_state_dict(synth.fill_flow_state_dict(flow.state_dict(), 11))
+    pose, flow = pose.to(device).eval(), flow.to(device).eval()
+    if args.fp16:
+        pose.compute_dtype = flow.compute_dtype = torch.float16
+    return pose, flow
+
+
+def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow_batch=4):
+    """Returns (per-frame dict list on rank 0 | None elsewhere, timing dict)."""
+    T = len(frames)
+    dev = next(pose_net.parameters()).device
+    fr = torch.from_numpy(frames).to(dev)                                     # clip resident in HBM
+    tm = {}
+    # ---- phase 1: flows of pairs (t-1, t), sharded by pair index ---------------------------------------
+    t0 = time.perf_counter()
+    lo, hi = parallel.shard_range(T - 1, rank, world)
+    H, W = frames.shape[1:3]
+    local = torch.empty((hi - lo, 2, H, W), dtype=torch.float32, device=dev)
+    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
+    for b0 in range(lo, hi, flow_batch):
+        b1 = min(hi, b0 + flow_batch)
+        ims = torch.zeros((b1 - b0, 3, 2, Hp, Wp), dtype=torch.float32, device=dev)
+        ims[:, :, 0, :H, :W] = fr[b0:b1].flip(-1).permute(0, 3, 1, 2).float()             # BGR -> RGB (net_utils.py:83-87)
+        ims[:, :, 1, :H, :W] = fr[b0 + 1:b1 + 1].flip(-1).permute(0, 3, 1, 2).float()
+        local[b0 - lo:b1 - lo] = flow_net(ims)[:, :, :H, :W]
+    flows = parallel.all_gather_rows(local, T - 1)
+    torch.cuda.synchronize()
+    tm["flow_s"] = time.perf_counter() - t0
+    # ---- phase 2: pose of the detector boxes, frames sharded by index -----------------------------------
+    t0 = time.perf_counter()
+    lo, hi = parallel.shard_range(T, rank, world)
+    nmax = max(len(d) for d in dets)
+    kp_local = torch.zeros((hi - lo, nmax, 17, 3), dtype=torch.float32, device=dev)
+    for t in range(lo, hi):
+        kp = pose_est(pose_net, fr[t], dets[t][:, :4])
+        kp_local[t - lo, :len(kp)] = torch.from_numpy(kp).to(dev)
+    kp_all = parallel.all_gather_rows(kp_local, T).cpu().numpy()
+    torch.cuda.synchronize()
+    tm["pose_s"] = time.perf_counter() - t0
+    if rank != 0:
+        return None, tm
+    # ---- phase 3: sequential tracking pass ----------------------------------------------------------------
+    t0 = time.perf_counter()
+    flows_np = flows.cpu().numpy()
+    tracker = FlowTracker()
+    out, prev_kp, prev_dets = [], None, None
+    for t in range(T):
+        det_kp = kp_all[t, :len(dets[t])]
+        cur = np.asarray(dets[t], dtype=np.float32)
+        src = np.arange(len(cur))
+        if prev_kp is not None and len(prev_kp):
+            flow = flows_np[t - 1]
+            prop = box_propagation(prev_kp, flow)                                         # flow_utils.py:7-35
+            prop_dets = np.concatenate((prop, prev_dets[:, 4:5]), axis=1).astype(np.float32)  # demo.py:38
+            allb = np.concatenate((cur, prop_dets), 0)
+            from flowtrack.pytorch_amd.tracking.flow_utils import nms
+            keep = nms(allb, thresh)
+            cur, src = allb[keep], keep
+        else:
+            flow = None
+        kps = np.zeros((len(cur), 17, 3), dtype=np.float32)
+        from_det = src < len(dets[t])
+        kps[from_det] = det_kp[src[from_det]]
+        if (~from_det).any():                                                            # propagated-only boxes
+            kps[~from_det] = pose_est(pose_net, fr[t], cur[~from_det, :4])
+        ids = tracker.update(kps, cur, flow)
+        out.append({"boxes": cur, "keypoints": kps, "ids": ids})
+        prev_kp, prev_dets = kps, cur
+    tm["track_s"] = time.perf_counter() - t0
+    return out, tm
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Pose estimation + flow-based tracking in video (HIP path)")
+    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--people", type=int, default=5)
+    ap.add_argument("--pose_backbone", default=50, type=int, help="50, 101, 152")
+    ap.add_argument("--pose_model", type=str, default="", help="pose checkpoint (ckpt['state_dict'])")
+    ap.add_argument("--flow_net", type=str, default="FlowNet2S", help="FlowNet2S, FlowNet2C, FlowNet2CS")
+    ap.add_argument("--flow_model", type=str, default="", help="optical flow checkpoint (ckpt['state_dict'])")
+    ap.add_argument("--fp16", action="store_true")
+    ap.add_argument("--save", type=str, default="")
+    args = ap.parse_args(argv)
+    rank, local_rank, world = parallel.init_from_env()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    pose_net, flow_net = build_nets(args, device)
+    frames, dets = synthetic_clip(args.frames, n_people=args.people)
+    run_clip(frames[:3], dets[:3], pose_net, flow_net, rank, world)                       # warm-up: plans + graphs
+    parallel.barrier()
+    t0 = time.perf_counter()
+    out, tm = run_clip(frames, dets, pose_net, flow_net, rank, world)
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        n_ids = len({i for f in out for i in f["ids"]})
+        print("clip: {} frames {}x{} on {} GPU(s): {:.2f} s = {:.1f} frames/s (flow {:.2f} s, detector-box pose {:.2f} s, "
+              "tracking pass {:.2f} s); {} track ids for {} people".format(
+                  args.frames, frames.shape[2], frames.shape[1], world, dt, args.frames / dt, tm["flow_s"], tm["pose_s"],
+                  tm["track_s"], n_ids, args.people))
+        if args.save:
+            np.savez_compressed(args.save, boxes=np.array([f["boxes"] for f in out], dtype=object),
+                                ids=np.array([f["ids"] for f in out], dtype=object), allow_pickle=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
