@@ -157,7 +157,7 @@ __device__ __forceinline__ void conv_row_table(const ConvParams& p, long long* s
 
 // PRE: the row table is already in LDS and `rpre` holds this thread's residual chunks (issued before the
 // K-loop so their HBM latency overlaps the operand loads); otherwise both are produced here.
-template <typename T, int BP, int BC, int WGP, int WGC, bool PRE = false>
+template <typename T, int BP, int BC, int WGP, int WGC, bool PRE = false, int NT = 256>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&acc)[BC / WGC / 32][BP / WGP / 32],
                                               char* smem, int opix_off, int m0, int co0, int py, int px,
                                               const uint4_t* rpre = nullptr) {
@@ -181,14 +181,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
       if (p.res) {
         if constexpr (PRE) {
 #pragma unroll
-          for (int k = 0; k < BP * NCH / 256; ++k) {
-            const int idx = tid + k * 256;
+          for (int k = 0; k < BP * NCH / NT; ++k) {
+            const int idx = tid + k * NT;
             const int pl = idx / NCH, ch = idx % NCH;
             *reinterpret_cast<uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4)) = rpre[k];
           }
         } else {
           const half_t* rbase = reinterpret_cast<const half_t*>(p.res) + p.res_coff + co0;
-          for (int idx = tid; idx < BP * NCH; idx += 256) {
+          for (int idx = tid; idx < BP * NCH; idx += NT) {
             const int pl = idx / NCH, ch = idx % NCH;
             const long long o = s_opix[pl];
             uint4_t v = {0u, 0u, 0u, 0u};
@@ -235,7 +235,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
       }
       __syncthreads();
       half_t* ybase = reinterpret_cast<half_t*>(p.y) + p.y_coff + co0;
-      for (int idx = tid; idx < BP * NCH; idx += 256) {
+      for (int idx = tid; idx < BP * NCH; idx += NT) {
         const int pl = idx / NCH, ch = idx % NCH;
         const long long o = s_opix[pl];
         if (o >= 0 && co0 + ch * 8 < p.Cout)
@@ -490,10 +490,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #ifndef FT_DMA_WAVES_BIG
 #define FT_DMA_WAVES_BIG 3   // 128x128 tile: 64 accumulator + <= 104 other registers
 #endif
-template <typename T, int BP, int BC, int WGP, int WGC, int BKB, int STAGES, bool HAS_RES>
-__global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4)) void conv_igemm_dma_kernel(const ConvParams p) {
+// KS > 1 = intra-workgroup split-K for layers with few tiles but a long K (layer3/4, deconv.0 at batch 64, every
+// layer at batch 1): KS groups of 4 waves each run the K-loop over 1/KS of the K-steps with their own LDS ring
+// (same tile, same barriers), then partial accumulators are summed through LDS and group 0 runs the epilogue.
+// The K-loop of ONE wave is a ~600-cycle serial chain per K-step with 128-256 cycles of MFMA in it; what fills
+// the matrix pipe is other waves, and a small layer has no other tiles to offer — so the extra waves come from K.
+template <typename T, int BP, int BC, int WGP, int WGC, int BKB, int STAGES, bool HAS_RES, int KS>
+__global__ __launch_bounds__(64 * WGP * WGC * KS, (KS > 1 || WGP * WGC > 4 ? 1 : (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4)))
+void conv_igemm_dma_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only types (__amdgpu_buffer_rsrc_t); the host pass only needs the stub
-  constexpr int NW = 4;
+  constexpr int NW = WGP * WGC;             // waves per K-group: 4 (128x128 and smaller tiles) or 8 (256x128)
+  constexpr int NT = 64 * NW;
   constexpr int CH = BKB / 16;              // 16-byte chunks per tile row
   constexpr int RPI = 64 / CH;              // tile rows filled by one 1-KiB wave load
   constexpr int NIA = BC / RPI / NW;        // weight-tile loads per wave per stage
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   constexpr int KK = BKB / 32;
   constexpr int SWZ_DIV = 256 / BKB;
   constexpr int A_BYTES = BC * BKB, B_BYTES = BP * BKB, STAGE = A_BYTES + B_BYTES;
-  static_assert(WGP * WGC == NW && NIA >= 1 && NIB >= 1, "tile shape");
+  static_assert((NW == 4 || NW == 8) && NIA >= 1 && NIB >= 1 && (KS == 1 || NW == 4), "tile shape");
   static_assert(BC % (RPI * NW) == 0 && BP % (RPI * NW) == 0, "tile rows must split evenly over the waves");
   static_assert(NL * (STAGES - 1) <= 63, "vmcnt is a 6-bit counter");
   static_assert(STAGES >= (FT_DMA_FRAGDB ? 3 : 2), "ring depth");
@@ -514,8 +521,11 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave_all / NW;            // K-split group (0 when KS == 1)
+  const int wave = wave_all % NW;           // wave inside the group
   const int wp = wave % WGP, wc = wave / WGP;
+  char* const gsm = smem + grp * (STAGES * STAGE);   // this group's ring
 
   int ctile, phase, ptile;
   {
@@ -534,6 +544,10 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   const int dbase_y = p.transposed ? py : -p.pad;
   const int dbase_x = p.transposed ? px : -p.pad_x;
   constexpr int esz = (int)sizeof(T);
+  // K-steps of this group: [ks_begin, ks_end); every group iterates nk_g times so the barriers line up
+  const int nk_g = (p.nk + KS - 1) / KS;
+  const int ks_begin = grp * nk_g;
+  const int ks_end = ks_begin + nk_g < p.nk ? ks_begin + nk_g : p.nk;
 
   // buffer descriptors: weights of this (phase, co tile); the whole activation buffer
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -577,25 +591,43 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   }
 
   // ---- K position of the NEXT stage to issue (wave-uniform, lives in SGPRs) -----------------------------
-  int i_ky = 0, i_kx = 0, i_cc = 0, i_ks = 0;
+  int i_ks = ks_begin, i_cc, i_ky, i_kx;
+  {
+    const int tap0 = ks_begin / p.kc;
+    i_cc = ks_begin - tap0 * p.kc;
+    i_ky = tap0 / p.kw;
+    i_kx = tap0 - i_ky * p.kw;
+  }
   const int cstride_b = p.x_cstride * esz;
+#ifdef FT_CONV_TIMING
+  unsigned long long tiss[3] = {0, 0, 0};
+#define FT_TI(i) do { const unsigned long long _t = __builtin_readcyclecounter(); tiss[i] += _t - tip; tip = _t; } while (0)
+#else
+#define FT_TI(i) do { } while (0)
+#endif
   auto issue = [&](int stage) {
-    char* sA = smem + stage * STAGE;
+#ifdef FT_CONV_TIMING
+    unsigned long long tip = __builtin_readcyclecounter();
+#endif
+    char* sA = gsm + stage * STAGE;
     char* sB = sA + A_BYTES;
-    const bool live = i_ks < p.nk;
+    const bool live = i_ks < ks_end;
     const int a_soff = i_ks * BKB;
+    const int tap = i_ky * p.kw + i_kx;
+    const int delta = ((p.dmul * i_ky) * p.Wi + p.dmul * i_kx) * cstride_b + i_cc * BKB;
+    const unsigned tapbit = live ? (1u << tap) : 0u;
+    FT_TI(0);
 #pragma unroll
     for (int t = 0; t < NIA; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(sA + (wave + NW * t) * 1024), 16,
                                                live ? a_voff[t] : kOOB, live ? a_soff : 0, 0, 0);
-    const int tap = i_ky * p.kw + i_kx;
-    const int delta = ((p.dmul * i_ky) * p.Wi + p.dmul * i_kx) * cstride_b + i_cc * BKB;
-    const unsigned tapbit = live ? (1u << tap) : 0u;
+    FT_TI(1);
 #pragma unroll
     for (int t = 0; t < NIB; ++t) {
       const unsigned voff = (b_mask[t] & tapbit) ? (unsigned)(b_base[t] + delta) : kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(sB + (wave + NW * t) * 1024), 16, voff, 0, 0, 0);
     }
+    FT_TI(2);
     ++i_ks;
     if (++i_cc == p.kc) {
       i_cc = 0;
@@ -629,9 +661,9 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   // pipeline instead of sitting between the last MFMA and the store (1x1 bottleneck-exit layers are
   // bandwidth-bound: what matters is bytes in flight per CU).
   constexpr bool PRE = HAS_RES && sizeof(T) == 2;
-  constexpr int NPRE = PRE ? BP * (BC / 8) / 256 : 1;
+  constexpr int NPRE = PRE ? BP * (BC / 8) / NT : 1;
   uint4_t rpre[NPRE];
-  long long* s_opix = reinterpret_cast<long long*>(smem + STAGES * STAGE);
+  long long* s_opix = reinterpret_cast<long long*>(smem + KS * STAGES * STAGE);
   if constexpr (PRE) {
     conv_row_table<BP>(p, s_opix, m0, py, px);
     __syncthreads();
@@ -639,7 +671,8 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
     const half_t* rbase = reinterpret_cast<const half_t*>(p.res) + p.res_coff + co0;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int idx = tid + k * 256;
+      if (KS > 1 && grp != 0) { rpre[k] = uint4_t{0u, 0u, 0u, 0u}; continue; }
+      const int idx = tid + k * NT;
       const int pl = idx / NCH, ch = idx % NCH;
       const long long o = s_opix[pl];
       uint4_t v = {0u, 0u, 0u, 0u};
@@ -672,7 +705,7 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   uint4_t fa[2][KK][MT_C], fb[2][KK][MT_P];
   auto load_frags = [&](auto set, int slot) {
     constexpr int P = decltype(set)::value;
-    const char* st = smem + slot * STAGE;
+    const char* st = gsm + slot * STAGE;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -700,19 +733,37 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
   __builtin_amdgcn_s_barrier();
   load_frags(std::integral_constant<int, 0>{}, 0);
   int ks = 0;
-  for (; ks + 1 < p.nk; ks += 2) {
+  for (; ks + 1 < nk_g; ks += 2) {
     step(std::integral_constant<int, 0>{});
     step(std::integral_constant<int, 1>{});
   }
-  if (ks < p.nk) step(std::integral_constant<int, 0>{});
+  if (ks < nk_g) step(std::integral_constant<int, 0>{});
 #else
-  for (int ks = 0; ks < p.nk; ++ks) {
+#ifdef FT_CONV_TIMING   // developer build: per-phase s_memtime accounting of the K-loop, dumped through p.y
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long t_start = __builtin_readcyclecounter();
+#define FT_T(i)                                           \
+  do {                                                    \
+    const unsigned long long _t = __builtin_readcyclecounter(); \
+    tacc[i] += _t - tprev;                                \
+    tprev = _t;                                           \
+  } while (0)
+#else
+#define FT_T(i) do { } while (0)
+#endif
+  for (int ks = 0; ks < nk_g; ++ks) {
+#ifdef FT_CONV_TIMING
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     // this wave's loads of K-step ks have landed (STAGES-2 younger stages may still be in flight) ...
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 2)) : "memory");
+    FT_T(0);
     // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
     __builtin_amdgcn_s_barrier();
+    FT_T(1);
     if (!(p.dbg & 2)) issue(nxt);
-    const char* st = smem + cur * STAGE;
+    FT_T(2);
+    const char* st = gsm + cur * STAGE;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       uint4_t a[MT_C], b[MT_P];
@@ -720,6 +771,10 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
       for (int i = 0; i < MT_C; ++i) a[i] = *reinterpret_cast<const uint4_t*>(st + (a_off[i] ^ (kk << 5)));
 #pragma unroll
       for (int j = 0; j < MT_P; ++j) b[j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
+#ifdef FT_CONV_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      FT_T(3);
+#endif
       if (p.dbg & 1) {
 #pragma unroll
         for (int i = 0; i < MT_C; ++i) asm volatile("" ::"v"(a[i]));
@@ -728,10 +783,26 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
       } else {
         mma_slice<MT_C, MT_P>(a, b, acc, (T*)nullptr);
       }
+      FT_T(4);
     }
     cur = cur + 1 == STAGES ? 0 : cur + 1;
     nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    FT_T(5);
   }
+#ifdef FT_CONV_TIMING
+  if (p.dbg & 32) {
+    const unsigned long long t_loop = __builtin_readcyclecounter() - t_start;
+    if (lane == 0 && wave_all == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + (blockIdx.x == 0 ? 0 : 8);
+      for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+      o[6] = t_loop;
+      o[7] = (unsigned long long)nk_g;
+      unsigned long long* o2 = reinterpret_cast<unsigned long long*>(p.y) + 16 + (blockIdx.x == 0 ? 0 : 4);
+      for (int i = 0; i < 3; ++i) o2[i] = tiss[i];
+    }
+    return;
+  }
+#endif
 #endif
   // drain the (all out-of-range) tail loads before LDS is reused by the epilogue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,7 +811,42 @@ __global__ __launch_bounds__(256, (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))
     if (acc[0][0][0] == 12345.678f) p.y[0] = 1;   // keep the accumulators live
     return;
   }
-  conv_epilogue<T, BP, BC, WGP, WGC, PRE>(p, acc, smem, STAGES * STAGE, m0, co0, py, px, rpre);
+  if constexpr (KS > 1) {
+    // sum the K-split partials through LDS (the rings are dead): group g > 0 parks its accumulators lane-
+    // contiguously (16-byte stores, conflict-free), group 0 adds them; then only group 0 lives on (s_barrier
+    // ignores terminated waves)
+    constexpr int NV4 = MT_C * MT_P * 4;                       // float4s per lane
+    float4_t* part = reinterpret_cast<float4_t*>(smem);
+    if (grp != 0) {
+      float4_t* dst = part + ((size_t)((grp - 1) * NW + wave) * NV4) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < MT_C; ++i)
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            dst[((i * MT_P + j) * 4 + q) * 64] = v;
+          }
+    }
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float4_t* src = part + ((size_t)((g - 1) * NW + wave) * NV4) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < MT_C; ++i)
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4_t v = src[((i * MT_P + j) * 4 + q) * 64];
+            acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1]; acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+          }
+    }
+    __syncthreads();   // group 0 only: the partial region is about to be reused by the epilogue
+  }
+  conv_epilogue<T, BP, BC, WGP, WGC, PRE, NT>(p, acc, smem, KS * STAGES * STAGE, m0, co0, py, px, rpre);
 #endif
 }
 
@@ -974,11 +1080,14 @@ static void launch_generic(const ConvParams& p, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((conv_igemm_kernel<T, kBP, BC, WGP, WGC, kBKB>), grid, dim3(256), lds, s, p);
 }
 
-template <typename T, int BP, int BC, int WGP, int WGC, bool HAS_RES>
+template <typename T, int BP, int BC, int WGP, int WGC, bool HAS_RES, int KS = 1>
 static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)kDmaStages * (BC + BP) * kDmaBKB + (size_t)BP * 8;
-  static_assert((size_t)BP * BC * 2 <= (size_t)kDmaStages * (BC + BP) * kDmaBKB, "fp16 output tile must fit in the ring");
-  auto k = conv_igemm_dma_kernel<T, BP, BC, WGP, WGC, kDmaBKB, kDmaStages, HAS_RES>;
+  constexpr size_t ring = (size_t)KS * kDmaStages * (BC + BP) * kDmaBKB;
+  constexpr size_t lds = ring + (size_t)BP * 8;
+  static_assert((size_t)BP * BC * 2 <= ring, "fp16 output tile must fit in the ring");
+  static_assert((size_t)(KS - 1) * BP * BC * 4 <= ring, "K-split partials must fit in the rings");
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = conv_igemm_dma_kernel<T, BP, BC, WGP, WGC, kDmaBKB, kDmaStages, HAS_RES, KS>;
   if (lds > 64 * 1024) {
     static thread_local bool raised = false;
     if (!raised) {
@@ -986,15 +1095,15 @@ static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
       raised = true;
     }
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, grid, dim3(64 * WGP * WGC * KS), lds, s, p);
   return FT_OK;
 }
 
-template <typename T, int BP, int BC, int WGP, int WGC>
+template <typename T, int BP, int BC, int WGP, int WGC, int KS = 1>
 static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
   // the residual-prefetch variant exists for the fp16 LDS-transposed epilogue only
-  if (sizeof(T) == 2 && p.res && p.epi_lds) return launch_dma_r<T, BP, BC, WGP, WGC, true>(p, grid, s);
-  return launch_dma_r<T, BP, BC, WGP, WGC, false>(p, grid, s);
+  if (sizeof(T) == 2 && p.res && p.epi_lds) return launch_dma_r<T, BP, BC, WGP, WGC, true, KS>(p, grid, s);
+  return launch_dma_r<T, BP, BC, WGP, WGC, false, KS>(p, grid, s);
 }
 
 static int env_int(const char* name) {  // developer tile overrides (FT_CONV_BP / FT_CONV_BC), 0 = heuristic
@@ -1121,24 +1230,54 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     int bc = d->Cout % 128 == 0 ? 128 : 64;
     int bp = 128;
     auto blocks = [&](int bp_, int bc_) { return (long long)ceil_div(p.M, bp_) * (g.cout_pad / bc_) * g.nphases; };
+    // The K-loop is bound by operand delivery L2 -> LDS (~10 TB/s chip-wide measured, same as the best GEMMs of
+    // the hardware guide): bytes per MAC = (1/BP + 1/BC) * esz, so the largest tile that still fills the chip wins.
+    if (d->dtype == FT_F16 && bc == 128 && g.ntaps * g.cin_pad > 512 && blocks(256, 128) >= 2 * 256) bp = 256;
     if (blocks(bp, bc) < 384) bp = 64;
     if (blocks(bp, bc) < 384 && bc == 128) bc = 64;
     // short-K layers (1x1 bottleneck exits) are HBM-bound: smaller pixel tiles = more workgroups per CU =
     // more bytes in flight (measured on MI355X, R50 shapes: 64x128 beats 128x128 by 10-18 % for K <= 512)
     if (g.ntaps * g.cin_pad <= 512 && bc == 128) bp = 64;
-    static const int force_bp = env_int("FT_CONV_BP"), force_bc = env_int("FT_CONV_BC");
-    if (force_bp == 64 || force_bp == 128) bp = force_bp;
-    if ((force_bc == 64 || force_bc == 128) && g.cout_pad % force_bc == 0) bc = force_bc;
+    static const int force_bp = env_int("FT_CONV_BP"), force_bc = env_int("FT_CONV_BC"), force_ks = env_int("FT_CONV_KS");
+    if (force_bp == 64 || force_bp == 128 || (force_bp == 256 && bc == 128 && d->dtype == FT_F16)) bp = force_bp;
+    if ((force_bc == 64 || force_bc == 128) && g.cout_pad % force_bc == 0 && bp != 256) bc = force_bc;
+    // intra-workgroup split-K (fp16): few tiles + long K => take the missing waves from K, as long as every
+    // workgroup still fits on the chip in ONE round (each K-group brings its own LDS ring)
+    int ks = 1;
+    if (d->dtype == FT_F16 && bp <= 128 && !(bp == 128 && bc == 64)) {
+      const long long nblk = blocks(bp, bc);
+      const long long per_cu = (nblk + 255) / 256;
+      const size_t ring = (size_t)kDmaStages * (bc + bp) * kDmaBKB;
+      for (int cand = 4; cand >= 2; cand >>= 1) {
+        if (cand == 4 && bp == 128) continue;
+        if (per_cu * (cand * ring + 2048) <= 160 * 1024 && per_cu * cand * 4 <= 32 && g.nk >= 8 * cand && nblk <= 768) {
+          ks = cand;
+          break;
+        }
+      }
+    }
+    if (force_ks == 1) ks = 1;
+    if ((force_ks == 2 || force_ks == 4) && d->dtype == FT_F16 && bp <= 128 && !(bp == 128 && bc == 64) &&
+        !(force_ks == 4 && bp == 128))
+      ks = force_ks;
     p.npt = ceil_div(p.M, bp);
     p.nct = g.cout_pad / bc;
     if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
     dim3 grid(p.npt * p.nct * p.nph);
     int rc;
     if (d->dtype == FT_F16) {
-      if (bp == 128 && bc == 128) rc = launch_dma<half_t, 128, 128, 2, 2>(p, grid, s);
+      if (bp == 256) rc = launch_dma<half_t, 256, 128, 4, 2>(p, grid, s);
+      else if (bp == 128 && bc == 128)
+        rc = ks == 2 ? launch_dma<half_t, 128, 128, 2, 2, 2>(p, grid, s) : launch_dma<half_t, 128, 128, 2, 2>(p, grid, s);
       else if (bp == 128) rc = launch_dma<half_t, 128, 64, 2, 2>(p, grid, s);
-      else if (bc == 128) rc = launch_dma<half_t, 64, 128, 2, 2>(p, grid, s);
-      else rc = launch_dma<half_t, 64, 64, 2, 2>(p, grid, s);
+      else if (bc == 128)
+        rc = ks == 4   ? launch_dma<half_t, 64, 128, 2, 2, 4>(p, grid, s)
+             : ks == 2 ? launch_dma<half_t, 64, 128, 2, 2, 2>(p, grid, s)
+                       : launch_dma<half_t, 64, 128, 2, 2>(p, grid, s);
+      else
+        rc = ks == 4   ? launch_dma<half_t, 64, 64, 2, 2, 4>(p, grid, s)
+             : ks == 2 ? launch_dma<half_t, 64, 64, 2, 2, 2>(p, grid, s)
+                       : launch_dma<half_t, 64, 64, 2, 2>(p, grid, s);
     } else {
       if (bp == 128 && bc == 128) rc = launch_dma<float, 128, 128, 2, 2>(p, grid, s);
       else if (bp == 128) rc = launch_dma<float, 128, 64, 2, 2>(p, grid, s);
