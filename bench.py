@@ -31,18 +31,18 @@ from flowtrack.pytorch_amd import parallel, synth  # noqa: E402
 MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_pose(device, dtype, seed=1234):
+def build_pose(device, dtype, seed=1234, backbone="resnet50"):
     from flowtrack.pytorch_amd.pose import models
-    m = models.deconv("resnet50", num_classes=17, pretrained=False)
+    m = models.deconv(backbone, num_classes=17, pretrained=False)
     m.load_state_dict(synth.fill_pose_state_dict(m.state_dict(), seed))
     m = m.to(device).eval()
     m.compute_dtype = dtype
     return m
 
 
-def build_flow(device, dtype, seed=1234):
+def build_flow(device, dtype, seed=1234, name="FlowNet2S"):
     from flowtrack.pytorch_amd.flownet import models
-    m = models.FlowNet2S(types.SimpleNamespace(rgb_max=255.0, fp16=dtype == torch.float16))
+    m = getattr(models, name)(types.SimpleNamespace(rgb_max=255.0, fp16=dtype == torch.float16))
     m.load_state_dict(synth.fill_flow_state_dict(m.state_dict(), seed))
     m = m.to(device).eval()
     m.compute_dtype = dtype
@@ -155,6 +155,11 @@ def main():
     ap.add_argument("--workload", choices=["pose", "flow"], default="pose")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 crops / 16 pairs)")
+    ap.add_argument("--backbone", choices=["resnet50", "resnet101", "resnet152"], default="resnet50",
+                    help="pose trunk; resnet101 + --res 384x288 + --batch 16 is BASELINE.json configs[2]")
+    ap.add_argument("--res", default="256x192", help="pose crop HxW (multiples of 32)")
+    ap.add_argument("--flow-model", default="FlowNet2S",
+                    choices=["FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2CSS", "FlowNet2SD", "FlowNet2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
@@ -173,9 +178,12 @@ def main():
 
     if args.workload == "pose":
         B = args.batch or 64
-        model = build_pose(device, dtype)
-        x = synth.pose_crops(100 + rank, B).to(device)          # resident in HBM before the timed region
-        unit, metric = "crops/s", "pose crops/sec (ResNet-50 + 3-deconv head, 256x192)"
+        H, W = (int(v) for v in args.res.lower().split("x"))
+        depth = args.backbone[len("resnet"):]
+        default_cfg = args.backbone == "resnet50" and (H, W) == (256, 192)
+        model = build_pose(device, dtype, backbone=args.backbone)
+        x = synth.pose_crops(100 + rank, B, H, W).to(device)    # resident in HBM before the timed region
+        unit, metric = "crops/s", f"pose crops/sec (ResNet-{depth} + 3-deconv head, {H}x{W})"
         kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
 
         def step():
@@ -185,17 +193,20 @@ def main():
             rows = parallel.all_gather_rows(rows, B * world) if world > 1 else rows
             kp_host.copy_(rows[rank * B:(rank + 1) * B] if world > 1 else rows, non_blocking=True)
             return rows
-        workload = f"ResNet-50 pose head {args.dtype}, batch {B} x 256x192 synthetic crops per GPU (BASELINE.json configs[1])"
+        cfg = "configs[1]" if default_cfg else ("configs[2]" if (args.backbone, H, W) == ("resnet101", 384, 288) else "variant")
+        workload = f"ResNet-{depth} pose head {args.dtype}, batch {B} x {H}x{W} synthetic crops per GPU (BASELINE.json {cfg})"
     else:
         B = args.batch or 16
-        model = build_flow(device, dtype)
+        default_cfg = args.flow_model == "FlowNet2S"
+        model = build_flow(device, dtype, name=args.flow_model)
         x = synth.frame_pairs(100 + rank, B).to(device)
-        unit, metric = "pairs/s", "flow frame-pairs/sec (FlowNet2S, 512x384)"
+        unit, metric = "pairs/s", f"flow frame-pairs/sec ({args.flow_model}, 512x384)"
 
         def step():
             flow = model(x, copy_output=False)
             return parallel.all_gather_rows(flow, B * world) if world > 1 else flow
-        workload = f"FlowNet2S {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU (BASELINE.json configs[3])"
+        workload = (f"{args.flow_model} {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU "
+                    f"(BASELINE.json configs[3]{'' if default_cfg else ' shape, other stack'})")
 
     for _ in range(max(args.warmup, 2)):   # >= 2: first run is eager + graph capture, second replays the graph
         step()
@@ -223,7 +234,7 @@ def main():
         out["achieved_tflops_end_to_end"] = round(value / world * plan.prog.flops / B / 1e12, 2)
         if not args.no_roofline:
             roof, per_layer = conv_roofline(plan.prog, args.dtype)
-            if args.dtype == "fp16" and not args.batch:   # the committed PMC run is this exact default workload
+            if args.dtype == "fp16" and not args.batch and default_cfg:   # the committed PMC run is this exact default workload
                 roof["traffic"] = pmc_traffic(args.workload)
                 roof["traffic_unit"] = "HBM bytes per conv launch (avg), rocprofv3 PMC, profiles/"
             out["roofline"] = roof
@@ -231,7 +242,7 @@ def main():
                 for label, fl, ms in per_layer:
                     print(f"  {label:28s} {fl / 1e9:9.2f} GFLOP {ms * 1e3:9.1f} us {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TF/s",
                           file=sys.stderr)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and default_cfg:
             out["cpu_baseline"] = cpu_baseline_pose() if args.workload == "pose" else cpu_baseline_flow()
         print(json.dumps(out), flush=True)
     parallel.barrier()

@@ -73,6 +73,7 @@ _PROTOTYPES = {
     "ft_unpack_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     "ft_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_bn_batch_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_heatmap_max_preds": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
     "ft_flow_rgb_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -83,6 +84,8 @@ _PROTOTYPES = {
     "ft_correlation_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_int, c_void_p]),
     "ft_resample2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ft_channelnorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ft_upsample_nearest4x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ft_flow_fusion_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ft_crop_affine_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p]),
     "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]),

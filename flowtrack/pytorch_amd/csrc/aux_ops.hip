@@ -243,6 +243,59 @@ __global__ __launch_bounds__(256) void upsample_bilinear4x_kernel(const float* _
   }
 }
 
+// ---- BatchNorm2d batch statistics (training-mode forward / running-stat recalibration), NHWC -------------
+// The inference path folds eval-mode BN into the conv epilogue and needs no reduction; this kernel covers the
+// `model.train()`-style forward of nn.BatchNorm2d (tools/pose/main.py:207,342: per-channel mean and biased
+// variance over N*H*W) for recalibrating running statistics.  Lanes own channels (16-byte vectors along C),
+// rows of pixels are strided over the workgroup's waves, per-wave partials meet in LDS, workgroups combine
+// with one fp32 atomicAdd pair per channel (sum, sum of squares; fp32, Welford is not needed at these counts:
+// tolerance stated in the test).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_batch_stats_kernel(const T* __restrict__ x, int C, int cstride, size_t npix,
+                                                             float* __restrict__ sums /* [2*C], pre-zeroed */) {
+  const int cvecs = C / 8;
+  const int lane_v = threadIdx.x % 32, rowl = threadIdx.x / 32;   // 32 vector lanes x 8 pixel rows per pass
+  __shared__ float s_part[8][32][16];
+  for (int v0 = 0; v0 < cvecs; v0 += 32) {
+    const int v = v0 + lane_v;
+    float a[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = q[e] = 0.f;
+    if (v < cvecs) {
+      for (size_t pix = (size_t)blockIdx.x * 8 + rowl; pix < npix; pix += (size_t)gridDim.x * 8) {
+        float f[8];
+        load8<T>(x + pix * cstride + v * 8, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] += f[e]; q[e] += f[e] * f[e]; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_part[rowl][lane_v][e] = a[e]; s_part[rowl][lane_v][8 + e] = q[e]; }
+    __syncthreads();
+    if (rowl == 0 && v < cvecs) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_part[r][lane_v][e];
+        atomicAdd(&sums[(e < 8 ? 0 : C) + v * 8 + (e & 7)], t);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_finish_stats_kernel(const float* __restrict__ sums, int C, float inv_n, float* __restrict__ mean,
+                                       float* __restrict__ var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float m = sums[c] * inv_n;
+    mean[c] = m;
+    const float v = sums[C + c] * inv_n - m * m;
+    var[c] = v > 0.f ? v : 0.f;
+  }
+}
+
 static inline int grid_for(size_t total) {
   size_t g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -344,5 +397,27 @@ extern "C" int ft_upsample_bilinear4x(const float* x, float* y, int N, int C, in
   hipLaunchKernelGGL(upsample_bilinear4x_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, h, w,
                      total, mul);
   FT_LAUNCH_CHECK("upsample_bilinear4x_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_bn_batch_stats(const void* x, int N, int H, int W, int C, int x_cstride, int dtype, float* workspace,
+                                 float* mean, float* var, ft_stream_t stream) {
+  if (!x || !workspace || !mean || !var || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || x_cstride % 8 || x_cstride < C)
+    return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const size_t npix = (size_t)N * H * W;
+  FT_HIP_CHECK(hipMemsetAsync(workspace, 0, sizeof(float) * 2 * (size_t)C, as_stream(stream)));
+  size_t g = (npix + 63) / 64;
+  g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(bn_batch_stats_kernel<half_t>, dim3((unsigned)g), dim3(256), 0, as_stream(stream),
+                       static_cast<const half_t*>(x), C, x_cstride, npix, workspace);
+  else
+    hipLaunchKernelGGL(bn_batch_stats_kernel<float>, dim3((unsigned)g), dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(x), C, x_cstride, npix, workspace);
+  FT_LAUNCH_CHECK("bn_batch_stats_kernel");
+  hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, C,
+                     1.0f / (float)npix, mean, var);
+  FT_LAUNCH_CHECK("bn_finish_stats_kernel");
   return FT_OK;
 }

@@ -380,6 +380,73 @@ __global__ __launch_bounds__(256) void flow_warp_concat_kernel(const T* __restri
   }
 }
 
+// ---- FlowNet2 fusion input (models.py:140-168): 11 channels per pixel from img0/img1 and two flow fields -----
+// (img0, sd_flow, s2_flow, |sd_flow|, |s2_flow|, |img0 - warp(img1, sd_flow)|, |img0 - warp(img1, s2_flow)|):
+// two Resample2d, four ChannelNorm and the concat of the reference in one pass; NHWC [B,H,W,16] out.
+template <typename T>
+__device__ __forceinline__ float warp_err(const T* __restrict__ img, int H, int W, int xl, int xp, int yy, int xx,
+                                          float dx, float dy, const float (&c)[8]) {
+  const float xf = (float)xx + dx, yf = (float)yy + dy;
+  const float fx = floorf(xf), fy = floorf(yf);
+  const float alpha = xf - fx, beta = yf - fy;
+  const int xL = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
+  const int xR = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
+  const int yT = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
+  const int yB = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
+  const float w00 = (1.f - alpha) * (1.f - beta), w01 = alpha * (1.f - beta), w10 = (1.f - alpha) * beta, w11 = alpha * beta;
+  float tl[8], tr[8], bl[8], br[8];
+  ld8<T>(img + ((size_t)yT * xp + xl + xL) * 8, tl);
+  ld8<T>(img + ((size_t)yT * xp + xl + xR) * 8, tr);
+  ld8<T>(img + ((size_t)yB * xp + xl + xL) * 8, bl);
+  ld8<T>(img + ((size_t)yB * xp + xl + xR) * 8, br);
+  float nrm = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = w00 * tl[3 + k];
+    v += w01 * tr[3 + k];
+    v += w10 * bl[3 + k];
+    v += w11 * br[3 + k];
+    const float d = c[k] - v;
+    nrm += d * d;
+  }
+  return sqrtf(nrm);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void flow_fusion_concat_kernel(const T* __restrict__ x6, const float* __restrict__ fsd,
+                                                                 const float* __restrict__ fs2, T* __restrict__ y, int H, int W,
+                                                                 int xl, int xp, int yl, int yp, size_t total) {
+  const size_t HW = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
+    const T* img = x6 + b * (size_t)H * xp * 8;
+    T* dst = y + (((size_t)b * H + yy) * yp + yl + xx) * 16;
+    float c[8];
+    ld8<T>(img + ((size_t)yy * xp + xl + xx) * 8, c);
+    const float sdx = fsd[(b * 2 + 0) * HW + pix], sdy = fsd[(b * 2 + 1) * HW + pix];
+    const float s2x = fs2[(b * 2 + 0) * HW + pix], s2y = fs2[(b * 2 + 1) * HW + pix];
+    const float lo[8] = {c[0], c[1], c[2], sdx, sdy, s2x, s2y, sqrtf(sdx * sdx + sdy * sdy)};
+    const float hi[8] = {sqrtf(s2x * s2x + s2y * s2y), warp_err<T>(img, H, W, xl, xp, yy, xx, sdx, sdy, c),
+                         warp_err<T>(img, H, W, xl, xp, yy, xx, s2x, s2y, c), 0.f, 0.f, 0.f, 0.f, 0.f};
+    st8<T>(dst, lo);
+    st8<T>(dst + 8, hi);
+  }
+}
+
+// nn.Upsample(scale_factor=4, mode='nearest') of (x * mul)  (models.py:59-60,448)
+__global__ __launch_bounds__(256) void upsample_nearest4x_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w,
+                                                                 size_t total, float mul) {
+  const int H = 4 * h, W = 4 * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % W);
+    const size_t t = i / W;
+    const int oy = (int)(t % H);
+    const size_t nc = t / H;
+    y[i] = x[nc * (size_t)h * w + (size_t)(oy >> 2) * w + (ox >> 2)] * mul;
+  }
+}
+
 static inline int grid_for(size_t total) {
   size_t g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -509,5 +576,31 @@ extern "C" int ft_flow_warp_concat(const void* x6, const float* flow, float div_
                        static_cast<const float*>(x6), flow, div_flow, static_cast<float*>(y), H, W, x_lpad, x_wpitch,
                        y_lpad, y_wpitch, total);
   FT_LAUNCH_CHECK("flow_warp_concat_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_flow_fusion_concat(const void* x6, const float* flow_sd, const float* flow_s2, void* y, int B, int H, int W,
+                                     int x_lpad, int x_wpitch, int y_lpad, int y_wpitch, int dtype, ft_stream_t stream) {
+  if (!x6 || !flow_sd || !flow_s2 || !y || B <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
+  if (x_lpad < 0 || x_wpitch < x_lpad + W || y_lpad < 0 || y_wpitch < y_lpad + W) return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  const size_t total = (size_t)B * H * W;
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(flow_fusion_concat_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const half_t*>(x6), flow_sd, flow_s2, static_cast<half_t*>(y), H, W, x_lpad, x_wpitch,
+                       y_lpad, y_wpitch, total);
+  else
+    hipLaunchKernelGGL(flow_fusion_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(x6), flow_sd, flow_s2, static_cast<float*>(y), H, W, x_lpad, x_wpitch,
+                       y_lpad, y_wpitch, total);
+  FT_LAUNCH_CHECK("flow_fusion_concat_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_upsample_nearest4x(const float* x, float* y, int N, int C, int h, int w, float mul, ft_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0) return FT_ERR_INVALID_ARG;
+  const size_t total = (size_t)N * C * 16 * h * w;
+  hipLaunchKernelGGL(upsample_nearest4x_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, h, w, total, mul);
+  FT_LAUNCH_CHECK("upsample_nearest4x_kernel");
   return FT_OK;
 }

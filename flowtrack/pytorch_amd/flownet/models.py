@@ -125,6 +125,77 @@ class FlowNetC(_Decoder):
         self.upsample1 = ActMarker("upsample_bilinear_x4")
 
 
+def i_conv(batchNorm: bool, in_planes: int, out_planes: int, kernel_size: int = 3, stride: int = 1, bias: bool = True):
+    """submodules.py:20-29: Conv2d (+BN), NO activation."""
+    pad = (kernel_size - 1) // 2
+    if batchNorm:
+        return nn.Sequential(ConvParams(in_planes, out_planes, kernel_size, stride, pad, bias=bias), BatchNormParams(out_planes))
+    return nn.Sequential(ConvParams(in_planes, out_planes, kernel_size, stride, pad, bias=bias))
+
+
+class FlowNetSD(nn.Module):
+    """Parameter layout of FlowNetSD.py:11-66 (holders only)."""
+
+    def __init__(self, args=None, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.conv0 = conv(batchNorm, 6, 64)
+        self.conv1 = conv(batchNorm, 64, 64, stride=2)
+        self.conv1_1 = conv(batchNorm, 64, 128)
+        self.conv2 = conv(batchNorm, 128, 128, stride=2)
+        self.conv2_1 = conv(batchNorm, 128, 128)
+        self.conv3 = conv(batchNorm, 128, 256, stride=2)
+        self.conv3_1 = conv(batchNorm, 256, 256)
+        self.conv4 = conv(batchNorm, 256, 512, stride=2)
+        self.conv4_1 = conv(batchNorm, 512, 512)
+        self.conv5 = conv(batchNorm, 512, 512, stride=2)
+        self.conv5_1 = conv(batchNorm, 512, 512)
+        self.conv6 = conv(batchNorm, 512, 1024, stride=2)
+        self.conv6_1 = conv(batchNorm, 1024, 1024)
+        self.deconv5 = deconv(1024, 512)
+        self.deconv4 = deconv(1026, 256)
+        self.deconv3 = deconv(770, 128)
+        self.deconv2 = deconv(386, 64)
+        self.inter_conv5 = i_conv(batchNorm, 1026, 512)
+        self.inter_conv4 = i_conv(batchNorm, 770, 256)
+        self.inter_conv3 = i_conv(batchNorm, 386, 128)
+        self.inter_conv2 = i_conv(batchNorm, 194, 64)
+        self.predict_flow6 = predict_flow(1024)
+        self.predict_flow5 = predict_flow(512)
+        self.predict_flow4 = predict_flow(256)
+        self.predict_flow3 = predict_flow(128)
+        self.predict_flow2 = predict_flow(64)
+        self.upsampled_flow6_to_5 = ConvTransposeParams(2, 2, bias=True)
+        self.upsampled_flow5_to_4 = ConvTransposeParams(2, 2, bias=True)
+        self.upsampled_flow4_to_3 = ConvTransposeParams(2, 2, bias=True)
+        self.upsampled_flow3_to_2 = ConvTransposeParams(2, 2, bias=True)
+        _reference_init(self)
+        self.upsample1 = ActMarker("upsample_bilinear_x4")
+
+
+class FlowNetFusion(nn.Module):
+    """Parameter layout of FlowNetFusion.py:11-46 (holders only)."""
+
+    def __init__(self, args=None, batchNorm: bool = True):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.conv0 = conv(batchNorm, 11, 64)
+        self.conv1 = conv(batchNorm, 64, 64, stride=2)
+        self.conv1_1 = conv(batchNorm, 64, 128)
+        self.conv2 = conv(batchNorm, 128, 128, stride=2)
+        self.conv2_1 = conv(batchNorm, 128, 128)
+        self.deconv1 = deconv(128, 32)
+        self.deconv0 = deconv(162, 16)
+        self.inter_conv1 = i_conv(batchNorm, 162, 32)
+        self.inter_conv0 = i_conv(batchNorm, 82, 16)
+        self.predict_flow2 = predict_flow(128)
+        self.predict_flow1 = predict_flow(32)
+        self.predict_flow0 = predict_flow(16)
+        self.upsampled_flow2_to_1 = ConvTransposeParams(2, 2, bias=True)
+        self.upsampled_flow1_to_0 = ConvTransposeParams(2, 2, bias=True)
+        _reference_init(self)
+
+
 CORR_MAX_DISP, CORR_STRIDE2 = 20, 2
 CORR_CH = (2 * (CORR_MAX_DISP // CORR_STRIDE2) + 1) ** 2  # 441
 
@@ -146,6 +217,13 @@ def _fd(seq: nn.Sequential, label: str, mk: dict) -> FusedConv:
     c = seq[0]
     return mk["owner"].fused(label, c.weight, transposed=True, stride=2, pad=1, bias=c.bias, act="leaky", slope=LEAK,
                              **_mk(mk))
+
+
+def _fi(seq: nn.Sequential, label: str, mk: dict) -> FusedConv:
+    """i_conv: conv (+BN) without activation."""
+    c = seq[0]
+    bn = seq[1].as_dict() if len(seq) > 1 and isinstance(seq[1], BatchNormParams) else None
+    return mk["owner"].fused(label, c.weight, stride=c.stride, pad=c.padding, bias=c.bias, bn=bn, act=None, **_mk(mk))
 
 
 def _fp(c: ConvParams, label: str, mk: dict) -> FusedConv:
@@ -252,6 +330,90 @@ def record_flownetc(prog: Program, p: FlowNetC, x2b: ActView, prefix: str, mk: d
     return _record_decoder(prog, p, c61, cc5, cc4, cc3, cc2[:B], prefix, mk)
 
 
+def record_flownetsd(prog: Program, p: FlowNetSD, x: ActView, prefix: str, mk: dict) -> torch.Tensor:
+    """FlowNetSD.forward (FlowNetSD.py:68-106): stride-1 stem, inter_conv before every flow prediction."""
+    B, H, W, dtype, device = x.N, x.H, x.W, mk["dtype"], mk["device"]
+    cc5, cc4, cc3, cc2 = _concat_buffers(B, H, W, dtype, device)
+    act = lambda h, w, c: new_act(B, h, w, c, dtype, device)
+    c0 = act(H, W, 64)
+    _fc(p.conv0, prefix + "conv0", mk).record(prog, x, c0)
+    c1 = act(H // 2, W // 2, 64)
+    _fc(p.conv1, prefix + "conv1", mk).record(prog, c0, c1)
+    c11 = act(H // 2, W // 2, 128)
+    _fc(p.conv1_1, prefix + "conv1_1", mk).record(prog, c1, c11)
+    c2 = act(H // 4, W // 4, 128)
+    _fc(p.conv2, prefix + "conv2", mk).record(prog, c11, c2)
+    _fc(p.conv2_1, prefix + "conv2_1", mk).record(prog, c2, ActView(cc2, 128, 0))
+    c3 = act(H // 8, W // 8, 256)
+    _fc(p.conv3, prefix + "conv3", mk).record(prog, ActView(cc2, 128, 0), c3)
+    _fc(p.conv3_1, prefix + "conv3_1", mk).record(prog, c3, ActView(cc3, 256, 0))
+    c4 = act(H // 16, W // 16, 512)
+    _fc(p.conv4, prefix + "conv4", mk).record(prog, ActView(cc3, 256, 0), c4)
+    _fc(p.conv4_1, prefix + "conv4_1", mk).record(prog, c4, ActView(cc4, 512, 0))
+    c5 = act(H // 32, W // 32, 512)
+    _fc(p.conv5, prefix + "conv5", mk).record(prog, ActView(cc4, 512, 0), c5)
+    _fc(p.conv5_1, prefix + "conv5_1", mk).record(prog, c5, ActView(cc5, 512, 0))
+    c6 = act(H // 64, W // 64, 1024)
+    _fc(p.conv6, prefix + "conv6", mk).record(prog, ActView(cc5, 512, 0), c6)
+    c61 = act(H // 64, W // 64, 1024)
+    _fc(p.conv6_1, prefix + "conv6_1", mk).record(prog, c6, c61)
+
+    flow = act(c61.H, c61.W, 2)
+    _fp(p.predict_flow6, prefix + "predict_flow6", mk).record(prog, c61, flow)
+    prev = c61
+    stages = ((cc5, 1026, 512, 1024, p.upsampled_flow6_to_5, p.deconv5, p.inter_conv5, p.predict_flow5, "5"),
+              (cc4, 770, 512, 768, p.upsampled_flow5_to_4, p.deconv4, p.inter_conv4, p.predict_flow4, "4"),
+              (cc3, 386, 256, 384, p.upsampled_flow4_to_3, p.deconv3, p.inter_conv3, p.predict_flow3, "3"),
+              (cc2, 194, 128, 192, p.upsampled_flow3_to_2, p.deconv2, p.inter_conv2, p.predict_flow2, "2"))
+    for cc, ctot, doff, foff, upf, dec, inter, pred, tag in stages:
+        up_name = {"5": "upsampled_flow6_to_5", "4": "upsampled_flow5_to_4", "3": "upsampled_flow4_to_3", "2": "upsampled_flow3_to_2"}[tag]
+        _fu(upf, prefix + up_name, mk).record(prog, flow, ActView(cc, 2, foff))
+        _fd(dec, prefix + "deconv" + tag, mk).record(prog, prev, ActView(cc, dec[0].cout, doff))
+        concat = ActView(cc, ctot, 0)
+        inter_out = act(concat.H, concat.W, inter[0].cout)
+        _fi(inter, prefix + "inter_conv" + tag, mk).record(prog, concat, inter_out)
+        if tag == "2":
+            flow2 = torch.empty((B, 2, concat.H, concat.W), dtype=torch.float32, device=device)
+            _fp(pred, prefix + "predict_flow2", mk).record(prog, inter_out, flow2)
+            return flow2
+        flow = act(concat.H, concat.W, 2)
+        _fp(pred, prefix + "predict_flow" + tag, mk).record(prog, inter_out, flow)
+        prev = concat
+
+
+def record_flownetfusion(prog: Program, p: FlowNetFusion, x: ActView, prefix: str, mk: dict) -> torch.Tensor:
+    """FlowNetFusion.forward (FlowNetFusion.py:48-66) on the 11-channel full-resolution input; returns flow0
+    NCHW fp32 [B,2,H,W]."""
+    B, H, W, dtype, device = x.N, x.H, x.W, mk["dtype"], mk["device"]
+    z = lambda h, w, c: torch.zeros((B, h, w, act_stride(c)), dtype=dtype, device=device)
+    cat1 = z(H // 2, W // 2, 162)      # (conv1_1 128 | deconv1 32 | flow2_up 2)
+    cat0 = z(H, W, 82)                 # (conv0 64 | deconv0 16 | flow1_up 2)
+    _fc(p.conv0, prefix + "conv0", mk).record(prog, x, ActView(cat0, 64, 0))
+    c1 = new_act(B, H // 2, W // 2, 64, dtype, device)
+    _fc(p.conv1, prefix + "conv1", mk).record(prog, ActView(cat0, 64, 0), c1)
+    _fc(p.conv1_1, prefix + "conv1_1", mk).record(prog, c1, ActView(cat1, 128, 0))
+    c2 = new_act(B, H // 4, W // 4, 128, dtype, device)
+    _fc(p.conv2, prefix + "conv2", mk).record(prog, ActView(cat1, 128, 0), c2)
+    c21 = new_act(B, H // 4, W // 4, 128, dtype, device)
+    _fc(p.conv2_1, prefix + "conv2_1", mk).record(prog, c2, c21)
+    flow2 = new_act(B, H // 4, W // 4, 2, dtype, device)
+    _fp(p.predict_flow2, prefix + "predict_flow2", mk).record(prog, c21, flow2)
+    _fu(p.upsampled_flow2_to_1, prefix + "upsampled_flow2_to_1", mk).record(prog, flow2, ActView(cat1, 2, 160))
+    _fd(p.deconv1, prefix + "deconv1", mk).record(prog, c21, ActView(cat1, 32, 128))
+    concat1 = ActView(cat1, 162, 0)
+    i1 = new_act(B, H // 2, W // 2, 32, dtype, device)
+    _fi(p.inter_conv1, prefix + "inter_conv1", mk).record(prog, concat1, i1)
+    flow1 = new_act(B, H // 2, W // 2, 2, dtype, device)
+    _fp(p.predict_flow1, prefix + "predict_flow1", mk).record(prog, i1, flow1)
+    _fu(p.upsampled_flow1_to_0, prefix + "upsampled_flow1_to_0", mk).record(prog, flow1, ActView(cat0, 2, 80))
+    _fd(p.deconv0, prefix + "deconv0", mk).record(prog, concat1, ActView(cat0, 16, 64))
+    i0 = new_act(B, H, W, 16, dtype, device)
+    _fi(p.inter_conv0, prefix + "inter_conv0", mk).record(prog, ActView(cat0, 82, 0), i0)
+    flow0 = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+    _fp(p.predict_flow0, prefix + "predict_flow0", mk).record(prog, i0, flow0)
+    return flow0
+
+
 class _FlowPlan:
     def __init__(self, prog, x_static, out):
         self.prog, self.x_static, self.out = prog, x_static, out
@@ -263,9 +425,11 @@ class _FlowBase(HipModule):
     rgb_max: float = 255.0
     div_flow: float = 20.0
 
-    def _record_normalise(self, prog: Program, x_static: torch.Tensor, modes, dtype, device):
+    def _record_normalise(self, prog: Program, x_static: torch.Tensor, modes, dtype, device, pad: int = 3):
         """rgb_mean + (x-mean)/rgb_max (models.py:255-257); returns one row-packed NHWC view per mode
-        (mode 0: [B,H,W+6,8] with 6 channels; mode 1: [2B,H,W+6,4] with 3 channels; conv1 is 7x7/s2/p3)."""
+        (mode 0: [B,H,W+2*pad,8] with 6 channels; mode 1: [2B,H,W+2*pad,4] with 3 channels; `pad` = padding of
+        the conv that reads it: 3 for the 7x7/s2 stems, 1 for FlowNetSD's 3x3/s1 conv0).  A mode may also be a
+        (mode, pad) pair."""
         B, _, _, H, W = x_static.shape
         partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
         mean = torch.empty((B * 3,), dtype=torch.float32, device=device)
@@ -273,7 +437,8 @@ class _FlowBase(HipModule):
                  keep=(x_static, partial, mean))
         outs = []
         for mode in modes:
-            view = new_rowpacked_act(B if mode == 0 else 2 * B, H, W, 6 if mode == 0 else 3, 3, dtype, device)
+            mode, pad = mode if isinstance(mode, tuple) else (mode, pad)
+            view = new_rowpacked_act(B if mode == 0 else 2 * B, H, W, 6 if mode == 0 else 3, pad, dtype, device)
             prog.add("ft_flow_pack_pair", x_static.data_ptr(), mean.data_ptr(), ctypes.c_float(self.rgb_max),
                      view.t.data_ptr(), B, H, W, mode, view.lpad, view.wpitch, _lib.dtype_code(dtype), keep=(view.t,))
             outs.append(view)
@@ -375,4 +540,113 @@ class FlowNet2CS(_FlowBase):
         flow2s = record_flownets(prog, self.flownets_1, concat1, "flownets_1.", mk)
         out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
         record_upsample4x(prog, flow2s, out, self.div_flow)             # models.py:406-407
+        return _FlowPlan(prog, x_static, out)
+
+
+def record_upsample_nearest4x(prog: Program, x: torch.Tensor, y: torch.Tensor, mul: float) -> None:
+    N, C, h, w = x.shape
+    prog.add("ft_upsample_nearest4x", x.data_ptr(), y.data_ptr(), N, C, h, w, ctypes.c_float(mul), keep=(x, y))
+
+
+def _record_warp_stage(prog: Program, x6: ActView, flow: torch.Tensor, div_flow: float, dtype, device) -> ActView:
+    """(img0, img1, warp(img1, flow), flow/div_flow, |img0 - warp|) -> row-packed 12-channel input of the next FlowNetS."""
+    B, H, W = x6.N, x6.H, x6.W
+    concat = new_rowpacked_act(B, H, W, 12, 3, dtype, device)
+    prog.add("ft_flow_warp_concat", x6.t.data_ptr(), flow.data_ptr(), ctypes.c_float(div_flow), concat.t.data_ptr(),
+             B, H, W, x6.lpad, x6.wpitch, concat.lpad, concat.wpitch, _lib.dtype_code(dtype), keep=(x6.t, flow, concat.t))
+    return concat
+
+
+class FlowNet2SD(FlowNetSD, _FlowBase):
+    """models.py:294-344."""
+
+    def __init__(self, args, batchNorm: bool = False, div_flow: float = 20):
+        _FlowBase.__init__(self)
+        FlowNetSD.__init__(self, args, batchNorm=batchNorm)
+        self.rgb_max = float(args.rgb_max)
+        self.div_flow = float(div_flow)
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device, owner=self)
+        x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
+        (x6,) = self._record_normalise(prog, x_static, (0,), dtype, device, pad=1)     # conv0 is 3x3 / s1 / p1
+        flow2 = record_flownetsd(prog, self, x6, "", mk)
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2, out, self.div_flow)
+        return _FlowPlan(prog, x_static, out)
+
+
+class FlowNet2CSS(_FlowBase):
+    """models.py:411-498: FlowNetC -> warp -> FlowNetS -> warp -> FlowNetS, last upsample NEAREST."""
+
+    def __init__(self, args, batchNorm: bool = False, div_flow: float = 20.):
+        super().__init__()
+        self.batchNorm = batchNorm
+        self.div_flow = float(div_flow)
+        self.rgb_max = float(args.rgb_max)
+        self.args = args
+        self.channelnorm = ActMarker("channelnorm")
+        self.flownetc = FlowNetC(args, batchNorm=batchNorm)
+        self.upsample1 = ActMarker("upsample_bilinear_x4")
+        self.resample1 = ActMarker("resample2d")
+        self.flownets_1 = FlowNetS(args, batchNorm=batchNorm)
+        self.upsample2 = ActMarker("upsample_bilinear_x4")
+        self.resample2 = ActMarker("resample2d")
+        self.flownets_2 = FlowNetS(args, batchNorm=batchNorm)
+        self.upsample3 = ActMarker("upsample_nearest_x4")
+
+    def _record_css(self, prog, x_static, B, H, W, dtype, device, mk, extra_modes=()):
+        """Shared with FlowNet2: returns (x6, flownets2_flow2 NCHW fp32 at 1/4 resolution, extra normalised views)."""
+        x6, x2b, *extra = self._record_normalise(prog, x_static, (0, 1) + tuple(extra_modes), dtype, device)
+        flow2c = record_flownetc(prog, self.flownetc, x2b, "flownetc.", mk)
+        flowc = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2c, flowc, self.div_flow)
+        concat1 = _record_warp_stage(prog, x6, flowc, self.div_flow, dtype, device)
+        flow2s1 = record_flownets(prog, self.flownets_1, concat1, "flownets_1.", mk)
+        flows1 = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample4x(prog, flow2s1, flows1, self.div_flow)
+        concat2 = _record_warp_stage(prog, x6, flows1, self.div_flow, dtype, device)
+        flow2s2 = record_flownets(prog, self.flownets_2, concat2, "flownets_2.", mk)
+        return x6, flow2s2, extra
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device, owner=self)
+        x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
+        _, flow2s2, _ = self._record_css(prog, x_static, B, H, W, dtype, device, mk)
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample_nearest4x(prog, flow2s2, out, self.div_flow)                   # models.py:495-496
+        return _FlowPlan(prog, x_static, out)
+
+
+class FlowNet2(FlowNet2CSS):
+    """models.py:19-178: the CSS stack + FlowNetSD on the raw pair + FlowNetFusion.  Inference only: the
+    reference's gradient hooks (`register_hook(save_grad(...))`, :151-176) have no counterpart."""
+
+    def __init__(self, args, batchNorm: bool = False, div_flow: float = 20.):
+        super().__init__(args, batchNorm=batchNorm, div_flow=div_flow)
+        del self.upsample3
+        self.flownets_d = FlowNetSD(args, batchNorm=batchNorm)
+        self.upsample3 = ActMarker("upsample_nearest_x4")
+        self.upsample4 = ActMarker("upsample_nearest_x4")
+        self.resample3 = ActMarker("resample2d")
+        self.resample4 = ActMarker("resample2d")
+        self.flownetfusion = FlowNetFusion(args, batchNorm=batchNorm)
+
+    def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:
+        prog = Program(self._side_stream(device))
+        mk = dict(dtype=dtype, device=device, owner=self)
+        x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
+        # FlowNetSD reads the same normalised pair through a 3x3/s1/p1 stem: its own row-packed copy (pad 1)
+        x6, flow2s2, (x6sd,) = self._record_css(prog, x_static, B, H, W, dtype, device, mk, extra_modes=((0, 1),))
+        flows2 = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample_nearest4x(prog, flow2s2, flows2, self.div_flow)                # upsample4(flow2 * div_flow), :131
+        flow2sd = record_flownetsd(prog, self.flownets_d, x6sd, "flownets_d.", mk)
+        flowsd = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        record_upsample_nearest4x(prog, flow2sd, flowsd, 1.0 / self.div_flow)         # upsample3(flow2 / div_flow), :145
+        cat3 = new_rowpacked_act(B, H, W, 11, 1, dtype, device)                        # fusion conv0 is 3x3/s1/p1
+        prog.add("ft_flow_fusion_concat", x6.t.data_ptr(), flowsd.data_ptr(), flows2.data_ptr(), cat3.t.data_ptr(), B, H, W,
+                 x6.lpad, x6.wpitch, cat3.lpad, cat3.wpitch, _lib.dtype_code(dtype), keep=(x6.t, flowsd, flows2, cat3.t))   # :134-168
+        out = record_flownetfusion(prog, self.flownetfusion, cat3, "flownetfusion.", mk)
         return _FlowPlan(prog, x_static, out)

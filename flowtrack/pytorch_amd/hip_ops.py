@@ -353,3 +353,18 @@ def heatmap_max_preds(heatmaps: torch.Tensor, adjust_coords: bool):
                                    score.data_ptr(), coords.data_ptr(), current_stream_handle()),
           "ft_heatmap_max_preds")
     return idx, score, coords
+
+
+def bn_batch_stats(x: ActView):
+    """Per-channel (mean, biased var) over N*H*W of an NHWC view — nn.BatchNorm2d's training-mode reduction."""
+    require_gpu(x.t.device)
+    if x.coff or x.rowpacked:
+        raise FlowtrackHipError("bn_batch_stats works on plain NHWC buffers (coff == 0)")
+    lib = _lib.load()
+    C = x.C
+    ws = torch.empty(2 * C, dtype=torch.float32, device=x.t.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.t.device)
+    var = torch.empty(C, dtype=torch.float32, device=x.t.device)
+    check(lib.ft_bn_batch_stats(x.t.data_ptr(), x.N, x.H, x.W, C, x.cstride, _lib.dtype_code(x.t.dtype), ws.data_ptr(),
+                                mean.data_ptr(), var.data_ptr(), current_stream_handle()), "ft_bn_batch_stats")
+    return mean, var

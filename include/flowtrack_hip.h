@@ -159,6 +159,14 @@ int ft_unpack_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W,
 int ft_maxpool3x3s2_fwd(const void* x, void* y, int N, int Hi, int Wi, int C,
                         int dtype, ft_stream_t stream);
 
+/* ---- P4: BatchNorm2d batch statistics -----------------------------------------
+ * Per-channel mean and BIASED variance over N*H*W of an NHWC view (C and x_cstride multiples of 8) — the
+ * reduction nn.BatchNorm2d performs in training mode (tools/pose/main.py:207,342; running-stat
+ * recalibration).  The inference path does not need it (eval-mode BN is folded into ft_conv2d_fwd).
+ * workspace: float[2*C] scratch (zeroed by the call); mean, var: float[C]. */
+int ft_bn_batch_stats(const void* x, int N, int H, int W, int C, int x_cstride, int dtype,
+                      float* workspace, float* mean, float* var, ft_stream_t stream);
+
 /* ---- P8/P9: heatmap -> keypoints ------------------------------------------
  * max_preds + the adjust_coords nudge of final_preds
  * (lib/pose/utils/evaluation.py:11-35): per (n,k) map the arg-max over H*W
@@ -233,6 +241,17 @@ int ft_channelnorm_fwd(const float* in1, float* out, int B, int C, int H, int W,
 int ft_flow_warp_concat(const void* x6, const float* flow, float div_flow,
                         void* y, int B, int H, int W, int x_lpad, int x_wpitch,
                         int y_lpad, int y_wpitch, int dtype, ft_stream_t stream);
+
+/* ---- N4: full FlowNet2 stack helpers -------------------------------------------
+ * nn.Upsample(scale_factor=4, mode='nearest') of (x * mul) (lib/flownet/model/models.py:59-60,448). */
+int ft_upsample_nearest4x(const float* x, float* y, int N, int C, int h, int w, float mul,
+                          ft_stream_t stream);
+/* Input of FlowNetFusion (models.py:140-168) in one pass: from x6 (as ft_flow_warp_concat) and two flow fields
+ * NCHW fp32 [B,2,H,W] builds NHWC `dtype` [B,H,y_wpitch,16] (pixel x at column y_lpad + x; padding columns untouched) = (img0(3), flow_sd(2), flow_s2(2), |flow_sd|, |flow_s2|,
+ * |img0 - warp(img1, flow_sd)|, |img0 - warp(img1, flow_s2)|, 0...) — two Resample2d + four ChannelNorm + cat. */
+int ft_flow_fusion_concat(const void* x6, const float* flow_sd, const float* flow_s2, void* y, int B, int H,
+                          int W, int x_lpad, int x_wpitch, int y_lpad, int y_wpitch, int dtype,
+                          ft_stream_t stream);
 
 /* ---- N2: person crops for the pose net --------------------------------------
  * Replaces the per-box host loop `transform_image` = cv2.warpAffine(img, t[:2], (res_w, res_h))

@@ -5,10 +5,14 @@ Functional torch-CPU fp32 restatement of the FlowNet2 family, driven by referenc
   flownet2c_forward   <- FlowNet2C.forward   models.py:185-246  (trunk FlowNetC.py:71-128)
   flownet2cs_forward  <- FlowNet2CS.forward  models.py:383-409
   flownets_trunk      <- FlowNetS.forward    lib/flownet/networks/FlowNetS.py:60-94
+  flownet2sd_forward  <- FlowNet2SD.forward  models.py:330-344  (trunk FlowNetSD.py:68-106)
+  flownet2css_forward <- FlowNet2CSS.forward models.py:455-498
+  flownet2_forward    <- FlowNet2.forward    models.py:108-178  (fusion FlowNetFusion.py:48-66)
 Stock layers are torch.nn.functional on CPU (what the reference itself executes); the three
 CUDA-only operators come from oracle/ops_ref.py (C restatement of the .cu kernels).
-FlowNet2S is pinned against the imported reference by tests/golden/make_golden.py; FlowNet2C/CS
-cannot run in the reference without CUDA => pinned only through their building blocks.
+FlowNet2S and FlowNet2SD are pinned against the imported reference by tests/golden/make_golden.py;
+FlowNet2C/CS/CSS/FlowNet2 cannot run in the reference without CUDA => pinned only through their
+building blocks (every stock layer they use is exercised by the two pinned networks).
 """
 from __future__ import annotations
 
@@ -128,6 +132,97 @@ def flownet2cs_forward(sd, inputs, rgb_max=255.0, div_flow=20.0, return_parts=Fa
     out = _up4(flownets_trunk(sd, concat1, pre="flownets_1."), div_flow)
     if return_parts:
         return out, {"flowc": flowc, "concat1": concat1}
+    return out
+
+
+def _iconv(sd, p, x):
+    """submodules.i_conv (submodules.py:20-29): Conv2d(+BN), no activation."""
+    y = F.conv2d(x, sd[p + ".0.weight"], sd.get(p + ".0.bias"), stride=1, padding=1)
+    if p + ".1.running_mean" in sd:
+        y = F.batch_norm(y, sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd[p + ".1.weight"], sd[p + ".1.bias"],
+                         training=False, eps=1e-5)
+    return y
+
+
+def flownetsd_trunk(sd, x, pre=""):
+    """FlowNetSD.forward (FlowNetSD.py:68-106) -> flow2."""
+    c0 = _conv(sd, pre + "conv0", x, 3, 1)
+    c1 = _conv(sd, pre + "conv1_1", _conv(sd, pre + "conv1", c0, 3, 2), 3, 1)
+    c2 = _conv(sd, pre + "conv2_1", _conv(sd, pre + "conv2", c1, 3, 2), 3, 1)
+    c3 = _conv(sd, pre + "conv3_1", _conv(sd, pre + "conv3", c2, 3, 2), 3, 1)
+    c4 = _conv(sd, pre + "conv4_1", _conv(sd, pre + "conv4", c3, 3, 2), 3, 1)
+    c5 = _conv(sd, pre + "conv5_1", _conv(sd, pre + "conv5", c4, 3, 2), 3, 1)
+    c6 = _conv(sd, pre + "conv6_1", _conv(sd, pre + "conv6", c5, 3, 2), 3, 1)
+    flow6 = _predict(sd, pre + "predict_flow6", c6)
+    concat5 = torch.cat((c5, _deconv(sd, pre + "deconv5", c6), _upflow(sd, pre + "upsampled_flow6_to_5", flow6)), 1)
+    flow5 = _predict(sd, pre + "predict_flow5", _iconv(sd, pre + "inter_conv5", concat5))
+    concat4 = torch.cat((c4, _deconv(sd, pre + "deconv4", concat5), _upflow(sd, pre + "upsampled_flow5_to_4", flow5)), 1)
+    flow4 = _predict(sd, pre + "predict_flow4", _iconv(sd, pre + "inter_conv4", concat4))
+    concat3 = torch.cat((c3, _deconv(sd, pre + "deconv3", concat4), _upflow(sd, pre + "upsampled_flow4_to_3", flow4)), 1)
+    flow3 = _predict(sd, pre + "predict_flow3", _iconv(sd, pre + "inter_conv3", concat3))
+    concat2 = torch.cat((c2, _deconv(sd, pre + "deconv2", concat3), _upflow(sd, pre + "upsampled_flow3_to_2", flow3)), 1)
+    return _predict(sd, pre + "predict_flow2", _iconv(sd, pre + "inter_conv2", concat2))
+
+
+def flownetfusion_trunk(sd, x, pre=""):
+    """FlowNetFusion.forward (FlowNetFusion.py:48-66) -> flow0 at input resolution."""
+    c0 = _conv(sd, pre + "conv0", x, 3, 1)
+    c1 = _conv(sd, pre + "conv1_1", _conv(sd, pre + "conv1", c0, 3, 2), 3, 1)
+    c2 = _conv(sd, pre + "conv2_1", _conv(sd, pre + "conv2", c1, 3, 2), 3, 1)
+    flow2 = _predict(sd, pre + "predict_flow2", c2)
+    concat1 = torch.cat((c1, _deconv(sd, pre + "deconv1", c2), _upflow(sd, pre + "upsampled_flow2_to_1", flow2)), 1)
+    flow1 = _predict(sd, pre + "predict_flow1", _iconv(sd, pre + "inter_conv1", concat1))
+    concat0 = torch.cat((c0, _deconv(sd, pre + "deconv0", concat1), _upflow(sd, pre + "upsampled_flow1_to_0", flow1)), 1)
+    return _predict(sd, pre + "predict_flow0", _iconv(sd, pre + "inter_conv0", concat0))
+
+
+def _up4_nearest(x):
+    return F.interpolate(x, scale_factor=4, mode="nearest")
+
+
+def _warp_stage(x, flow, div_flow):
+    """(x, warp(img1, flow), flow/div_flow, |img0 - warp|): models.py:124-131."""
+    warped = torch.from_numpy(ops_ref.resample2d_c(x[:, 3:].contiguous().numpy(), flow.contiguous().numpy()))
+    norm = torch.from_numpy(ops_ref.channelnorm_c((x[:, :3] - warped).contiguous().numpy()))
+    return torch.cat((x, warped, flow / div_flow, norm), dim=1)
+
+
+def _css_flow2(sd, x, div_flow):
+    flowc = _up4(flownetc_trunk(sd, x[:, 0:3], x[:, 3:], pre="flownetc."), div_flow)
+    flows1 = _up4(flownets_trunk(sd, _warp_stage(x, flowc, div_flow), pre="flownets_1."), div_flow)
+    return flownets_trunk(sd, _warp_stage(x, flows1, div_flow), pre="flownets_2.")
+
+
+@torch.no_grad()
+def flownet2sd_forward(sd, inputs, rgb_max=255.0, div_flow=20.0):
+    sd = _f32(sd)
+    x = _normalise(inputs.float(), rgb_max)
+    x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
+    return _up4(flownetsd_trunk(sd, x), div_flow)
+
+
+@torch.no_grad()
+def flownet2css_forward(sd, inputs, rgb_max=255.0, div_flow=20.0):
+    sd = _f32(sd)
+    x = _normalise(inputs.float(), rgb_max)
+    x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
+    return _up4_nearest(_css_flow2(sd, x, div_flow) * div_flow)
+
+
+@torch.no_grad()
+def flownet2_forward(sd, inputs, rgb_max=255.0, div_flow=20.0, return_parts=False):
+    sd = _f32(sd)
+    x = _normalise(inputs.float(), rgb_max)
+    x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
+    img0, img1 = x[:, :3], x[:, 3:].contiguous()
+    flows2 = _up4_nearest(_css_flow2(sd, x, div_flow) * div_flow)                      # models.py:144
+    flowsd = _up4_nearest(flownetsd_trunk(sd, x, pre="flownets_d.") / div_flow)        # models.py:158 (divides)
+    chn = lambda t: torch.from_numpy(ops_ref.channelnorm_c(t.contiguous().numpy()))
+    warp = lambda f: torch.from_numpy(ops_ref.resample2d_c(img1.numpy(), f.contiguous().numpy()))
+    concat3 = torch.cat((img0, flowsd, flows2, chn(flowsd), chn(flows2), chn(img0 - warp(flowsd)), chn(img0 - warp(flows2))), 1)
+    out = flownetfusion_trunk(sd, concat3, pre="flownetfusion.")
+    if return_parts:
+        return out, {"concat3": concat3, "flows2": flows2, "flowsd": flowsd}
     return out
 
 

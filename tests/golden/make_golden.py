@@ -180,9 +180,21 @@ def main():
     print(f"FlowNet2S batchNorm: flow range [{f_ref.min():.3f}, {f_ref.max():.3f}]; oracle-vs-reference {err:.3e}")
     assert err <= 1e-4
     fout["synth_flow_bn"] = f_ref.numpy()
+    # (d) FlowNet2SD (models.py:294-344; trunk FlowNetSD.py) — plain and batchNorm, synthetic pair
+    for bn in (False, True):
+        netsd = ref_flow.FlowNet2SD(args, batchNorm=bn).eval()
+        sdsd = synth.fill_flow_state_dict(netsd.state_dict(), SEED + 2 + int(bn))
+        netsd.load_state_dict(sdsd)
+        with torch.no_grad():
+            f_ref = netsd(pair)
+        f_orc = flow_ref.flownet2sd_forward(sdsd, pair)
+        err = (f_ref - f_orc).abs().max().item()
+        print(f"FlowNet2SD bn={bn}: flow range [{f_ref.min():.3f}, {f_ref.max():.3f}]; oracle-vs-reference {err:.3e}")
+        assert err <= 1e-4
+        fout["synth_flow_sd_bn" if bn else "synth_flow_sd"] = f_ref.numpy()
     fout["seed"] = np.array(SEED)
     # state_dict contracts (names + shapes) of the models the reference can build here
-    for cls in ("FlowNet2S", "FlowNet2C", "FlowNet2CS"):
+    for cls in ("FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2SD", "FlowNet2CSS", "FlowNet2"):
         try:
             m = getattr(ref_flow, cls)(args)
             fout[f"keys_{cls}"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()])

@@ -172,26 +172,68 @@ def test_flownet2s_batchnorm_variant(hip_lib):
     assert np.abs(flow - G["synth_flow_bn"]).max() <= 2e-3
 
 
-@pytest.mark.parametrize("name", ["FlowNet2C", "FlowNet2CS"])
+@pytest.mark.parametrize("bn", [False, True], ids=["plain", "batchnorm"])
+def test_flownet2sd_fp32_matches_reference_golden(hip_lib, bn):
+    """FlowNet2SD (models.py:294-344): stride-1 stem + inter_conv decoder, vs the imported reference's output."""
+    m, sd = _build(models.FlowNet2SD, SEED + 2 + int(bn), torch.float32, batchNorm=bn)
+    B, H, W = (int(v) for v in G["synth_shape"])
+    flow = m(synth.frame_pairs(SEED, B, H, W).cuda()).cpu().numpy()
+    err = np.abs(flow - G["synth_flow_sd_bn" if bn else "synth_flow_sd"]).max()
+    assert err <= (2e-3 if bn else 1e-3), f"FlowNet2SD bn={bn}: max abs err {err:.3e} px"
+
+
+_ORACLE_FWD = {"FlowNet2S": flow_ref.flownet2s_forward, "FlowNet2C": flow_ref.flownet2c_forward,
+               "FlowNet2CS": flow_ref.flownet2cs_forward, "FlowNet2SD": flow_ref.flownet2sd_forward,
+               "FlowNet2CSS": flow_ref.flownet2css_forward, "FlowNet2": flow_ref.flownet2_forward}
+
+
+def test_fusion_concat_and_nearest_upsample(hip_lib, oracle_lib):
+    """ft_upsample_nearest4x and ft_flow_fusion_concat (FlowNetFusion's 11-channel input, models.py:140-168)
+    against Resample2d / ChannelNorm / cat of the oracle."""
+    import ctypes
+    from flowtrack.pytorch_amd.hip_ops import new_rowpacked_act
+    B, H, W = 2, 24, 40
+    x = synth.normal(5, "x6", (B, 6, H, W)) * 0.5
+    fsd = synth.normal(5, "fsd", (B, 2, H, W)) * 3.0
+    fs2 = synth.normal(5, "fs2", (B, 2, H, W)) * 3.0
+    small = synth.normal(5, "small", (B, 2, 3, 5))
+    gs, gy = _cuda(small), torch.empty((B, 2, 12, 20), dtype=torch.float32, device="cuda")
+    check(hip_lib.ft_upsample_nearest4x(gs.data_ptr(), gy.data_ptr(), B, 2, 3, 5, ctypes.c_float(0.05), _stream()))
+    assert torch.equal(gy.cpu(), torch.nn.functional.interpolate(small * np.float32(0.05), scale_factor=4, mode="nearest"))
+    chn = lambda t: torch.from_numpy(ops_ref.channelnorm_c(t.contiguous().numpy()))
+    warp = lambda f: torch.from_numpy(ops_ref.resample2d_c(x[:, 3:].contiguous().numpy(), f.contiguous().numpy()))
+    want = torch.cat((x[:, :3], fsd, fs2, chn(fsd), chn(fs2), chn(x[:, :3] - warp(fsd)), chn(x[:, :3] - warp(fs2))), 1)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.float16, 2e-2)):
+        x6 = new_rowpacked_act(B, H, W, 6, 3, dtype, "cuda")
+        x6.t[:, :, x6.lpad:x6.lpad + W, :6] = x.permute(0, 2, 3, 1).to(dtype).cuda()
+        y = new_rowpacked_act(B, H, W, 11, 1, dtype, "cuda")
+        gsd, gs2 = _cuda(fsd), _cuda(fs2)
+        check(hip_lib.ft_flow_fusion_concat(x6.t.data_ptr(), gsd.data_ptr(), gs2.data_ptr(), y.t.data_ptr(), B, H, W, x6.lpad,
+                                            x6.wpitch, y.lpad, y.wpitch, _lib.dtype_code(dtype), _stream()))
+        got = y.t.float().cpu()
+        live = got[:, :, y.lpad:y.lpad + W]
+        assert (live[..., :11].permute(0, 3, 1, 2) - want).abs().max() <= tol
+        assert torch.all(live[..., 11:] == 0) and torch.all(got[:, :, :y.lpad] == 0) and torch.all(got[:, :, y.lpad + W:] == 0)
+
+
+@pytest.mark.parametrize("name", ["FlowNet2C", "FlowNet2CS", "FlowNet2CSS", "FlowNet2"])
 def test_flownet2c_cs_fp32_vs_oracle(hip_lib, oracle_lib, name):
     m, sd = _build(getattr(models, name), SEED + 2, torch.float32)
     pair = synth.frame_pairs(SEED + 2, 2, 128, 192)
     flow = m(pair.cuda()).cpu()
-    fwd = flow_ref.flownet2c_forward if name == "FlowNet2C" else flow_ref.flownet2cs_forward
-    want = fwd(sd, pair)
+    want = _ORACLE_FWD[name](sd, pair)
     err = (flow - want).abs().max().item()
     print(name, "flow range", want.min().item(), want.max().item(), "err", err)
     assert err <= 1e-3, f"{name}: max abs err {err:.3e} px"
 
 
-@pytest.mark.parametrize("name", ["FlowNet2S", "FlowNet2C", "FlowNet2CS"])
+@pytest.mark.parametrize("name", ["FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2SD", "FlowNet2CSS", "FlowNet2"])
 def test_flownet_fp16_vs_fp32_oracle(hip_lib, oracle_lib, name):
     """pseudo-fp16 mode (fp16 storage, fp32 accumulate; tools/flownet/demo.py --fp16): EPE vs the fp32 oracle."""
     m, sd = _build(getattr(models, name), SEED + 3, torch.float16)
     pair = synth.frame_pairs(SEED + 3, 1, 128, 192)
     flow = m(pair.cuda()).cpu()
-    want = {"FlowNet2S": flow_ref.flownet2s_forward, "FlowNet2C": flow_ref.flownet2c_forward,
-            "FlowNet2CS": flow_ref.flownet2cs_forward}[name](sd, pair)
+    want = _ORACLE_FWD[name](sd, pair)
     e = flow_ref.epe(flow, want)
     mag = torch.norm(want, dim=1).mean().item()
     print(name, "fp16 EPE", e, "mean |flow|", mag)

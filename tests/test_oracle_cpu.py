@@ -56,12 +56,21 @@ def test_flownet2s_oracle_reproduces_reference_golden():
     assert np.abs(flow_ref.flownet2s_forward(sd, ims).numpy() - FG["sample_flow"]).max() <= 1e-4
 
 
+def test_flownet2sd_oracle_reproduces_reference_golden():
+    B, H, W = (int(v) for v in FG["synth_shape"])
+    pair = synth.frame_pairs(SEED, B, H, W)
+    for bn, key in ((False, "synth_flow_sd"), (True, "synth_flow_sd_bn")):
+        m = flow_models.FlowNet2SD(ARGS, batchNorm=bn)
+        sd = synth.fill_flow_state_dict(m.state_dict(), SEED + 2 + int(bn))
+        assert np.abs(flow_ref.flownet2sd_forward(sd, pair).numpy() - FG[key]).max() <= 1e-4
+
+
 def test_state_dict_contract_matches_reference():
     """key names, order and shapes of every model the reference can construct here."""
     K = np.load(os.path.join(GOLDEN, "state_dict_keys.npz"))
     fmt = lambda m: [f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()]
     assert fmt(pose_models.deconv("resnet50", 17, False)) == list(K["pose_r50"])
-    for cls in ("FlowNet2S", "FlowNet2C", "FlowNet2CS"):
+    for cls in ("FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2SD", "FlowNet2CSS", "FlowNet2"):
         assert fmt(getattr(flow_models, cls)(ARGS)) == list(K[f"keys_{cls}"]), cls
     m101 = pose_models.deconv("resnet101", 17, False)
     assert len(m101.layer3) == 23 and m101.state_dict()["deconv.0.weight"].shape == (2048, 256, 4, 4)
@@ -144,4 +153,26 @@ def test_flownet2c_cs_oracle_runs_and_is_consistent(oracle_lib):
     c1 = parts["concat1"]
     assert c1.shape == (1, 12, 64, 64) and torch.allclose(c1[:, 9:11], parts["flowc"] / 20.0)
     assert torch.allclose(c1[:, 11:12], torch.sqrt(((c1[:, :3] - c1[:, 6:9]) ** 2).sum(1, keepdim=True)), atol=1e-6)
+    assert out.shape == (1, 2, 64, 64) and torch.isfinite(out).all()
+
+
+def test_flownet2_css_oracle_wiring(oracle_lib):
+    """FlowNet2CSS / FlowNet2 cannot run in the reference without CUDA: check the oracle graph by properties.  CSS is
+    the nearest x4 upsample of flownets_2's flow2 * div_flow; FlowNet2's concat3 carries (img0, flow_sd, flow_s2,
+    |flow_sd|, |flow_s2|, 2 brightness errors) with flow_s2 == CSS's output and flow_sd == nearest(SD flow2 / 20)."""
+    m = flow_models.FlowNet2(ARGS)
+    sd = synth.fill_flow_state_dict(m.state_dict(), 22)
+    pair = synth.frame_pairs(22, 1, 64, 64)
+    out, parts = flow_ref.flownet2_forward(sd, pair, return_parts=True)
+    css_sd = {k: v for k, v in sd.items() if k.split(".")[0] in ("flownetc", "flownets_1", "flownets_2")}
+    assert torch.allclose(parts["flows2"], flow_ref.flownet2css_forward(css_sd, pair), atol=1e-5)
+    sdsd = {k[len("flownets_d."):]: v for k, v in sd.items() if k.startswith("flownets_d.")}
+    x = flow_ref._normalise(pair.float(), 255.0)
+    x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
+    flow2sd = flow_ref.flownetsd_trunk(flow_ref._f32(sdsd), x)
+    assert torch.allclose(parts["flowsd"][:, :, ::4, ::4], flow2sd / 20.0, atol=1e-6)
+    c3 = parts["concat3"]
+    assert c3.shape == (1, 11, 64, 64)
+    assert torch.allclose(c3[:, 7:8], torch.norm(c3[:, 3:5], dim=1, keepdim=True), atol=1e-6)
+    assert torch.allclose(c3[:, 8:9], torch.norm(c3[:, 5:7], dim=1, keepdim=True), atol=1e-6)
     assert out.shape == (1, 2, 64, 64) and torch.isfinite(out).all()

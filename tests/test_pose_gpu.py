@@ -104,3 +104,18 @@ def test_pose_fp16_vs_fp32_oracle(hip_lib):
     ap = evaluation.eval_mAP([pred], [anno], [scale * scale], evaluation.COCO_DELTA)
     print("fp16 max abs err", err, "argmax match", same.mean(), "AP@OKS", ap)
     assert ap[0] >= 0.99
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_bn_batch_statistics(hip_lib, dtype):
+    """nn.BatchNorm2d training-mode reduction (per-channel mean / biased variance over N*H*W) on NHWC."""
+    from flowtrack.pytorch_amd.hip_ops import ActView, bn_batch_stats
+    x = synth.normal(9, "bnx", (3, 72, 17, 13), std=2.0, mean=0.7)
+    if dtype == torch.float16:
+        x = x.half().float()
+    buf = torch.zeros((3, 17, 13, 96), dtype=dtype, device="cuda")
+    buf[..., :72] = x.permute(0, 2, 3, 1).to("cuda", dtype)
+    mean, var = bn_batch_stats(ActView(buf, 72, 0))
+    want_m = x.mean(dim=(0, 2, 3))
+    want_v = x.var(dim=(0, 2, 3), unbiased=False)
+    assert (mean.cpu() - want_m).abs().max() <= 1e-4 and (var.cpu() - want_v).abs().max() <= 1e-3

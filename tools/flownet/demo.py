@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 
 from flowtrack.pytorch_amd.flownet import models, tools   # noqa: E402
 
-MODEL_CHOICES = ['FlowNet2S', 'FlowNet2C', 'FlowNet2CS']
+MODEL_CHOICES = ['FlowNet2', 'FlowNet2S', 'FlowNet2C', 'FlowNet2CS', 'FlowNet2CSS', 'FlowNet2SD']
 
 
 def build_parser():
