@@ -87,6 +87,21 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   return v;
 }
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for_from(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_from<B + 1, E>(f);
+  }
+}
+
 // One 32-byte-per-row K slice for every (i, j) MFMA tile of the wave.
 template <int MT_C, int MT_P>
 __device__ __forceinline__ void mma_slice(const uint4_t (&a)[MT_C], const uint4_t (&b)[MT_P],
@@ -487,6 +502,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // pixel stride (x_cstride >= x_coff + cin_pad, padding channels zero), buffers < 2 GiB.
 // Occupancy target (waves per SIMD) the register allocator must respect: the K-loop is latency-bound per
 // workgroup (one barrier per K-step), so co-resident workgroups are what keeps the MFMA pipe fed.
+#ifndef FT_DMA_INTERLEAVE
+#define FT_DMA_INTERLEAVE 1
+#endif
+#ifndef FT_DMA_LEAN
+#define FT_DMA_LEAN 1
+#endif
 #ifndef FT_DMA_WAVES_BIG
 #define FT_DMA_WAVES_BIG 3   // 128x128 tile: 64 accumulator + <= 104 other registers
 #endif
@@ -635,6 +656,37 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     }
   };
 
+  // issue state of the stage being filled (wave-uniform scalars), split from the loads themselves so the
+  // K-loop can interleave ONE load after each MFMA: a blocked vector-memory issue then hides under the
+  // matrix instruction that is still executing instead of leaving the pipe empty (FT_DMA_INTERLEAVE)
+  char* is_sA = gsm;
+  bool is_live = false;
+  int is_asoff = 0, is_delta = 0;
+  unsigned is_tapbit = 0;
+  auto issue_prep = [&](int stage) {
+    is_sA = gsm + stage * STAGE;
+    is_live = i_ks < ks_end;
+    is_asoff = i_ks * BKB;
+    const int tap = i_ky * p.kw + i_kx;
+    is_delta = ((p.dmul * i_ky) * p.Wi + p.dmul * i_kx) * cstride_b + i_cc * BKB;
+    is_tapbit = is_live ? (1u << tap) : 0u;
+    ++i_ks;
+    if (++i_cc == p.kc) {
+      i_cc = 0;
+      if (++i_kx == p.kw) { i_kx = 0; ++i_ky; }
+    }
+  };
+  auto issue_one = [&](auto idx) {
+    constexpr int t = decltype(idx)::value;
+    if constexpr (t < NIA) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(is_sA + (wave + NW * t) * 1024), 16,
+                                               is_live ? a_voff[t] : kOOB, is_live ? is_asoff : 0, 0, 0);
+    } else {
+      constexpr int u = t - NIA;
+      const unsigned voff = (b_mask[u] & is_tapbit) ? (unsigned)(b_base[u] + is_delta) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(is_sA + A_BYTES + (wave + NW * u) * 1024), 16, voff, 0, 0, 0);
+    }
+  };
   // ---- per-lane fragment read offsets (stage-relative); kk selects chunk pair via XOR (kk << 5) ----------
   const int l31 = lane & 31, lhi = lane >> 5;
   int a_off[MT_C], b_off[MT_P];
@@ -751,6 +803,117 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 #else
 #define FT_T(i) do { } while (0)
 #endif
+#if FT_DMA_LEAN && !defined(FT_CONV_TIMING)
+  constexpr bool kLean = (KS == 1);
+#else
+  constexpr bool kLean = false;
+#endif
+  if constexpr (kLean) {
+    // ---- lean K-loop: unrolled by STAGES so every ring slot / LDS offset is an immediate, the pixel-tile
+    // offsets are recomputed only when the TAP changes (the channel walk inside a tap is the scalar soffset of
+    // the load), loads are interleaved one per MFMA pair, and the tail (no loads left to issue) is peeled so the
+    // main loop carries no "live" predicate.  ~35 instructions per K-step instead of ~100: the K-loop is issue-
+    // bound on its scalar / address arithmetic long before the matrix pipe is full (profiles/README.md).
+    unsigned cur_voff[NIB];
+    auto refresh = [&]() {
+      const int tap = i_ky * p.kw + i_kx;
+      const int delta = ((p.dmul * i_ky) * p.Wi + p.dmul * i_kx) * cstride_b;
+      const unsigned tapbit = 1u << tap;
+#pragma unroll
+      for (int t = 0; t < NIB; ++t) cur_voff[t] = (b_mask[t] & tapbit) ? (unsigned)(b_base[t] + delta) : kOOB;
+    };
+    if (i_ky < p.kh) refresh();
+    else {
+#pragma unroll
+      for (int t = 0; t < NIB; ++t) cur_voff[t] = kOOB;
+    }
+    int soff_a = i_ks * BKB, soff_b = i_cc * BKB;
+    auto lean_issue_one = [&](auto idx, auto slot_c) {
+      constexpr int t = decltype(idx)::value;
+      constexpr int slot = decltype(slot_c)::value;
+      if constexpr (t < NIA) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(smem + slot * STAGE + (wave + NW * t) * 1024), 16, a_voff[t],
+                                                 soff_a, 0, 0);
+      } else {
+        constexpr int u = t - NIA;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(smem + slot * STAGE + A_BYTES + (wave + NW * u) * 1024), 16,
+                                                 cur_voff[u], soff_b, 0, 0);
+      }
+    };
+    auto advance = [&]() {
+      soff_a += BKB;
+      soff_b += BKB;
+      if (++i_cc == p.kc) {
+        i_cc = 0;
+        soff_b = 0;
+        if (++i_kx == p.kw) { i_kx = 0; ++i_ky; }
+        if (i_ky < p.kh) refresh();
+      }
+    };
+    constexpr int NM = (sizeof(T) == 2 ? 1 : 4) * KK * MT_C * MT_P;   // MFMAs per K-step
+    constexpr int GAP = NM >= NL ? NM / NL : 1;                        // one load after every GAP-th MFMA
+    auto lstep = [&](auto slot_c, auto issue_c, auto wait_c) {
+      constexpr int slot = decltype(slot_c)::value;
+      constexpr bool do_issue = decltype(issue_c)::value;
+      constexpr int nslot = (slot + STAGES - 1) % STAGES;
+      // this wave's loads of this K-step have landed (wait_c younger loads may stay in flight) ...
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(wait_c)::value) : "memory");
+      // ... after the barrier everyone's have, and everyone is done reading the slot refilled below
+      __builtin_amdgcn_s_barrier();
+      const char* st = smem + slot * STAGE;
+      uint4_t fa[KK][MT_C], fb[KK][MT_P];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MT_C; ++i) fa[kk][i] = *reinterpret_cast<const uint4_t*>(st + (a_off[i] ^ (kk << 5)));
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j) fb[kk][j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
+      }
+      static_for<NM>([&](auto mi) {
+        constexpr int m = decltype(mi)::value;
+        constexpr int i = (m / MT_P) % MT_C, j = m % MT_P;
+        if constexpr (sizeof(T) == 2) {
+          constexpr int kk = m / (MT_C * MT_P);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk][i]),
+                                                             __builtin_bit_cast(half8_t, fb[kk][j]), acc[i][j], 0, 0, 0);
+        } else {
+          constexpr int kk = m / (4 * MT_C * MT_P), e = (m / (MT_C * MT_P)) % 4;
+          const float4_t af = __builtin_bit_cast(float4_t, fa[kk][i]), bf = __builtin_bit_cast(float4_t, fb[kk][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (do_issue && (m % GAP) == GAP - 1 && m / GAP < NL) {
+          lean_issue_one(std::integral_constant<int, m / GAP>{}, std::integral_constant<int, nslot>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      if constexpr (do_issue) {
+        if constexpr (NM < NL)
+          static_for_from<NM, NL>([&](auto t) { lean_issue_one(t, std::integral_constant<int, nslot>{}); });
+        advance();
+      }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    using wmain = std::integral_constant<int, NL * (STAGES - 2)>;
+    const int n_main = nk_g > STAGES - 1 ? nk_g - (STAGES - 1) : 0;   // K-steps that still have a stage to issue
+    const int tn = nk_g < STAGES - 1 ? nk_g : STAGES - 1;             // peeled tail steps
+    int ks = 0;
+    for (; ks + STAGES <= n_main; ks += STAGES)
+      static_for<STAGES>([&](auto sc) { lstep(sc, yes{}, wmain{}); });
+    const int rem = n_main - ks;
+    static_for<STAGES>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if (rem == r) {
+        static_for<r>([&](auto sc) { lstep(sc, yes{}, wmain{}); });
+        static_for<STAGES - 1>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if (t < tn)
+            lstep(std::integral_constant<int, (r + t) % STAGES>{}, no{}, std::integral_constant<int, NL * (STAGES - 2 - t)>{});
+        });
+      }
+    });
+  }
+  if constexpr (!kLean)
   for (int ks = 0; ks < nk_g; ++ks) {
 #ifdef FT_CONV_TIMING
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -761,6 +924,37 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
     __builtin_amdgcn_s_barrier();
     FT_T(1);
+#if FT_DMA_INTERLEAVE && !defined(FT_CONV_TIMING)
+    if constexpr (sizeof(T) == 2) {
+      issue_prep(nxt);
+      const char* st = gsm + cur * STAGE;
+      uint4_t fa[KK][MT_C], fb[KK][MT_P];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MT_C; ++i) fa[kk][i] = *reinterpret_cast<const uint4_t*>(st + (a_off[i] ^ (kk << 5)));
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j) fb[kk][j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
+      }
+      constexpr int NM = KK * MT_C * MT_P;                      // MFMAs per K-step
+      constexpr int GAP = NM >= NL ? NM / NL : 1;               // one load after every GAP-th MFMA
+      auto mm = [&](auto mi) {
+        constexpr int m = decltype(mi)::value;
+        constexpr int kk = m / (MT_C * MT_P), i = (m / MT_P) % MT_C, j = m % MT_P;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk][i]),
+                                                           __builtin_bit_cast(half8_t, fb[kk][j]), acc[i][j], 0, 0, 0);
+        if constexpr ((m % GAP) == GAP - 1 && m / GAP < NL) {
+          issue_one(std::integral_constant<int, m / GAP>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      static_for<NM>(mm);
+      if constexpr (NM < NL) static_for_from<NM, NL>([&](auto t) { issue_one(t); });
+      cur = cur + 1 == STAGES ? 0 : cur + 1;
+      nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+      continue;
+    }
+#endif
     if (!(p.dbg & 2)) issue(nxt);
     FT_T(2);
     const char* st = gsm + cur * STAGE;
