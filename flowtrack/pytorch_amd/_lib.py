@@ -34,7 +34,7 @@ class ConvDesc(ctypes.Structure):
         ("stride", c_int), ("pad", c_int), ("transposed", c_int), ("Ho", c_int), ("Wo", c_int),
         ("y_cstride", c_int), ("y_coff", c_int), ("out_layout", c_int), ("has_residual", c_int),
         ("res_cstride", c_int), ("res_coff", c_int), ("act", c_int), ("slope", c_float),
-        ("x_lpad", c_int), ("x_wpitch", c_int),
+        ("x_lpad", c_int), ("x_wpitch", c_int), ("tile_hint", c_int),
     ]
 
 
@@ -65,6 +65,7 @@ _PROTOTYPES = {
     "ft_event_destroy": (c_int, [c_void_p]),
     "ft_stream_synchronize": (c_int, [c_void_p]),
     "ft_conv_pack_geometry": (c_int, [POINTER(ConvDesc), POINTER(ConvGeometry)]),
+    "ft_conv_tile_candidates": (c_int, [POINTER(ConvDesc), POINTER(c_int), c_int]),
     "ft_conv_tap_source": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "ft_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),

@@ -1300,6 +1300,20 @@ static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
   return launch_dma_r<T, BP, BC, WGP, WGC, false, KS>(p, grid, s);
 }
 
+// Tile variants the dma kernel is instantiated for (ft_conv_tile_candidates / ft_conv_desc.tile_hint).
+static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks) {
+  if (!g.dma) return false;
+  if (!((bp == 64 || bp == 128 || bp == 256) && (bc == 64 || bc == 128) && (ks == 1 || ks == 2 || ks == 4))) return false;
+  if (g.cout_pad % bc != 0) return false;
+  if (bp == 256 && !(bc == 128 && d->dtype == FT_F16 && ks == 1)) return false;
+  if (ks > 1) {
+    if (d->dtype != FT_F16 || (bp == 128 && bc == 64) || (ks == 4 && bp == 128)) return false;
+    if (g.nk < 2 * ks) return false;
+    if ((size_t)ks * kDmaStages * (bc + bp) * kDmaBKB + 2048 + (size_t)bp * 8 > 160 * 1024) return false;
+  }
+  return true;
+}
+
 static int env_int(const char* name) {  // developer tile overrides (FT_CONV_BP / FT_CONV_BC), 0 = heuristic
   const char* v = getenv(name);
   return v ? atoi(v) : 0;
@@ -1308,6 +1322,19 @@ static int env_int(const char* name) {  // developer tile overrides (FT_CONV_BP 
 }  // namespace ft
 
 using namespace ft;
+
+extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int max) {
+  Geometry g;
+  int st = geometry(d, &g);
+  if (st != FT_OK) return -st;
+  if (!hints || max <= 0) return -FT_ERR_INVALID_ARG;
+  static const int kTiles[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  int n = 0;
+  for (const auto& t : kTiles)
+    for (int ks = 1; ks <= 4; ks <<= 1)
+      if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
+  return n;
+}
 
 extern "C" int ft_conv_pack_geometry(const ft_conv_desc* d, ft_conv_geometry* out) {
   Geometry g;
@@ -1432,9 +1459,6 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     // short-K layers (1x1 bottleneck exits) are HBM-bound: smaller pixel tiles = more workgroups per CU =
     // more bytes in flight (measured on MI355X, R50 shapes: 64x128 beats 128x128 by 10-18 % for K <= 512)
     if (g.ntaps * g.cin_pad <= 512 && bc == 128) bp = 64;
-    static const int force_bp = env_int("FT_CONV_BP"), force_bc = env_int("FT_CONV_BC"), force_ks = env_int("FT_CONV_KS");
-    if (force_bp == 64 || force_bp == 128 || (force_bp == 256 && bc == 128 && d->dtype == FT_F16)) bp = force_bp;
-    if ((force_bc == 64 || force_bc == 128) && g.cout_pad % force_bc == 0 && bp != 256) bc = force_bc;
     // intra-workgroup split-K (fp16): few tiles + long K => take the missing waves from K, as long as every
     // workgroup still fits on the chip in ONE round (each K-group brings its own LDS ring)
     int ks = 1;
@@ -1450,10 +1474,14 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
         }
       }
     }
-    if (force_ks == 1) ks = 1;
-    if ((force_ks == 2 || force_ks == 4) && d->dtype == FT_F16 && bp <= 128 && !(bp == 128 && bc == 64) &&
-        !(force_ks == 4 && bp == 128))
-      ks = force_ks;
+    // explicit choice: the caller's benchmarked hint, or the developer override from the environment
+    static const int force = (env_int("FT_CONV_BP") & 0xfff) | ((env_int("FT_CONV_BC") & 0xfff) << 12) | (env_int("FT_CONV_KS") << 24);
+    const int hint = force ? force : d->tile_hint;
+    if (hint) {
+      const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0xfff, hks = hint >> 24;
+      const int nbp = hbp ? hbp : bp, nbc = hbc ? hbc : bc, nks = hks ? hks : (hbp || hbc ? 1 : ks);
+      if (tile_valid(d, g, nbp, nbc, nks)) { bp = nbp; bc = nbc; ks = nks; }
+    }
     p.npt = ceil_div(p.M, bp);
     p.nct = g.cout_pad / bc;
     if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;

@@ -6,12 +6,13 @@ parameters stay in the reference's layout; plans hold the packed copies.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, hip_ops
 from .hip_ops import FlowtrackHipError, Program, require_gpu
 
 
@@ -83,6 +84,10 @@ class HipModule(nn.Module):
         prog.stream.wait_stream(cur)
         if first:
             prog.run_eager()          # surfaces argument errors before any capture
+            if hip_ops.benchmark:     # cudnn.benchmark counterpart: pick each conv's tile variant in situ
+                prog.stream.synchronize()
+                prog.tune_tiles(verbose=bool(os.environ.get("FT_CONV_BENCHMARK_VERBOSE")))
+                prog.run_eager()      # the outputs of this call come from the chosen variants
             if self.use_graph:
                 prog.stream.synchronize()
                 prog.capture()

@@ -11,6 +11,8 @@ reference graphs (lib/flownet/networks/FlowNetS.py:73-88) becomes "write into a 
 from __future__ import annotations
 
 import ctypes
+import os
+import sys
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -98,7 +100,7 @@ class Program:
         self.keepalive: list = []
         self.graph_exec = None
         self.flops = 0.0
-        self.conv_records: list = []  # (label, desc, flops) for per-layer timing / roofline
+        self.conv_records: list = []  # (label, call index, flops, ConvDesc) for per-layer timing / roofline / tuning
 
     @property
     def stream_handle(self) -> ctypes.c_void_p:
@@ -144,6 +146,8 @@ class Program:
             evs.append(e)
         acc = [0.0] * len(self.calls)
         for _ in range(iters):
+            with torch.cuda.stream(self.stream):
+                torch.cuda._sleep(4_000_000)   # device-side head start: the intervals below hold no host launch latency
             check(lib.ft_event_record(evs[0], sh))
             for i, (name, args) in enumerate(self.calls):
                 check(getattr(lib, name)(*args, sh), name)
@@ -156,6 +160,103 @@ class Program:
         for e in evs:
             lib.ft_event_destroy(e)
         return [(self.calls[i][0], acc[i] / iters) for i in range(len(self.calls))]
+
+    def time_conv_runs(self, iters: int = 5):
+        """GPU time of the conv launches of one step, with hipEvents only at the boundaries of each maximal run of
+        consecutive `ft_conv2d_fwd` calls (so the kernels run back to back exactly as in the graph and the intervals
+        carry no per-launch event overhead) and a device-side head start (no host launch latency).
+        Returns (conv_ms, other_ms) averaged over `iters` passes."""
+        lib, sh = self.lib, self.stream_handle
+        is_conv = [name == "ft_conv2d_fwd" for name, _ in self.calls]
+        bounds = [0] + [i for i in range(1, len(is_conv)) if is_conv[i] != is_conv[i - 1]] + [len(is_conv)]
+        evs = []
+        for _ in bounds:
+            e = ctypes.c_void_p()
+            check(lib.ft_event_create(ctypes.byref(e)), "ft_event_create")
+            evs.append(e)
+        conv_ms = other_ms = 0.0
+        for _ in range(iters):
+            with torch.cuda.stream(self.stream):
+                torch.cuda._sleep(4_000_000)
+            for b in range(len(bounds) - 1):
+                check(lib.ft_event_record(evs[b], sh))
+                for name, args in self.calls[bounds[b]:bounds[b + 1]]:
+                    check(getattr(lib, name)(*args, sh), name)
+            check(lib.ft_event_record(evs[-1], sh))
+            check(lib.ft_event_synchronize(evs[-1]))
+            for b in range(len(bounds) - 1):
+                ms = ctypes.c_float()
+                check(lib.ft_event_elapsed_ms(evs[b], evs[b + 1], ctypes.byref(ms)))
+                if is_conv[bounds[b]]:
+                    conv_ms += ms.value
+                else:
+                    other_ms += ms.value
+        for e in evs:
+            lib.ft_event_destroy(e)
+        return conv_ms / iters, other_ms / iters
+
+    def tune_tiles(self, reps: int = 3, verbose: bool = False) -> int:
+        """In-situ benchmark of the conv tile variants (the reference's `cudnn.benchmark = True`): the whole launch
+        list runs eagerly `reps` times per candidate round with hipEvents around every conv, so each variant is timed
+        with the cache state its real predecessors leave behind (isolated back-to-back timings of ONE layer flatter the
+        big tiles and did not carry over to the network).  A device-side spin ahead of each pass lets the host enqueue
+        everything before the first kernel starts, so the intervals hold no launch latency.  Returns #layers changed."""
+        if self.graph_exec is not None:
+            raise FlowtrackHipError("tune_tiles must run before the plan is captured into a graph")
+        lib, sh = self.lib, self.stream_handle
+        convs = [(i, rec[3]) for rec in self.conv_records for i in (rec[1],)]
+        if not convs:
+            return 0
+        cands = []
+        hints = (ctypes.c_int * 16)()
+        for _, d in convs:
+            n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 16)
+            if n < 0:
+                check(-n, "ft_conv_tile_candidates")
+            cands.append([0] + [int(h) for h in hints[:n]] if n > 1 else [0])
+        rounds = max(len(c) for c in cands)
+        if rounds == 1:
+            return 0
+        conv_pos = {i: k for k, (i, _) in enumerate(convs)}
+        ev = []
+        for _ in range(2 * len(convs)):
+            e = ctypes.c_void_p()
+            check(lib.ft_event_create(ctypes.byref(e)), "ft_event_create")
+            ev.append(e)
+        times = [[float("inf")] * len(c) for c in cands]
+        for r in range(rounds):
+            for k, (_, d) in enumerate(convs):
+                d.tile_hint = cands[k][r] if r < len(cands[k]) else 0
+            for _ in range(reps):
+                with torch.cuda.stream(self.stream):
+                    torch.cuda._sleep(4_000_000)          # ~2 ms head start for the host
+                for i, (name, args) in enumerate(self.calls):
+                    k = conv_pos.get(i)
+                    if k is not None:
+                        check(lib.ft_event_record(ev[2 * k], sh))
+                    check(getattr(lib, name)(*args, sh), name)
+                    if k is not None:
+                        check(lib.ft_event_record(ev[2 * k + 1], sh))
+                check(lib.ft_stream_synchronize(sh), "ft_stream_synchronize")
+                for k in range(len(convs)):
+                    if r < len(cands[k]):
+                        ms = ctypes.c_float()
+                        check(lib.ft_event_elapsed_ms(ev[2 * k], ev[2 * k + 1], ctypes.byref(ms)))
+                        times[k][r] = min(times[k][r], ms.value)
+        for e in ev:
+            lib.ft_event_destroy(e)
+        changed = 0
+        for k, (_, d) in enumerate(convs):
+            best = min(range(len(cands[k])), key=lambda r: times[k][r])
+            if times[k][best] > 0.97 * times[k][0]:
+                best = 0
+            d.tile_hint = cands[k][best]
+            changed += best != 0
+            if verbose:
+                h = cands[k][best]
+                print(f"[tile benchmark] {self.conv_records[k][0]:28s} heuristic {times[k][0] * 1e3:7.1f} us  best {times[k][best] * 1e3:7.1f} us"
+                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {h >> 24}", file=sys.stderr)
+        return changed
 
     def __del__(self):
         try:
@@ -229,6 +330,11 @@ def fold_scale_shift(cout: int, cout_pad: int, bias: Optional[torch.Tensor], bn:
     if shift is not None:
         shift = shift.to(device)
     return scale, shift
+
+
+#: first-run benchmark of the conv tile variants (Program.tune_tiles; the reference's `cudnn.benchmark = True`,
+#: tools/pose/main.py:59).  FT_CONV_BENCHMARK=0 turns it off (the library's heuristic picks every tile).
+benchmark = os.environ.get("FT_CONV_BENCHMARK", "1") != "0"
 
 
 class FusedConv:
@@ -307,7 +413,7 @@ class FusedConv:
         w, _, scale, shift = self._packed_for(d)
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
-        prog.conv_records.append((self.label, len(prog.calls), flops))
+        prog.conv_records.append((self.label, len(prog.calls), flops, d))
         prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
                  scale.data_ptr() if scale is not None else None,
                  shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(),

@@ -115,6 +115,11 @@ typedef struct ft_conv_desc {
    * ROW (kw taps x x_cstride channels, contiguous in memory) then is one K-run, so the direct-to-LDS
    * kernel applies although Cin is tiny.  0 = plain NHWC. */
   int x_lpad, x_wpitch;
+  /* 0 = let the library choose the workgroup tile; else one of the values ft_conv_tile_candidates()
+   * returned for this descriptor (the pick of a plan-build-time benchmark, the counterpart of the
+   * reference's `cudnn.benchmark = True`, tools/pose/main.py:59).  Only the speed depends on it, never
+   * the packed-weight layout; an inapplicable value falls back to the heuristic. */
+  int tile_hint;
 } ft_conv_desc;
 
 /* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,
@@ -141,6 +146,10 @@ int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int sub, int* 
 int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
                   const float* scale, const float* shift, const void* residual,
                   void* y, ft_stream_t stream);
+/* Writes up to `max` valid `tile_hint` values for `d` (pixel tile x channel tile x split-K variants of
+ * the implicit-GEMM kernel) into hints[] and returns their count (0: the layer runs on a kernel without
+ * tile variants); negative = error status. */
+int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int max);
 /* algorithmic FLOPs (2*MACs, unpadded) of one ft_conv2d_fwd call */
 double ft_conv_flops(const ft_conv_desc* d);
 

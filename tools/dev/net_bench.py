@@ -20,7 +20,7 @@ for _ in range(3): m(x)
 torch.cuda.synchronize()
 plan = next(iter(m._plans.values()))
 times = plan.prog.time_calls(iters=5)
-labels = {idx: lab for lab, idx, _ in plan.prog.conv_records}
+labels = {idx: lab for lab, idx, _, _ in plan.prog.conv_records}
 tot = 0.0
 for i, (nm, ms) in enumerate(times):
     tot += ms
