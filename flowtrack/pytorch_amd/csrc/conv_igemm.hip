@@ -517,7 +517,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // The K-loop of ONE wave is a ~600-cycle serial chain per K-step with 128-256 cycles of MFMA in it; what fills
 // the matrix pipe is other waves, and a small layer has no other tiles to offer — so the extra waves come from K.
 template <typename T, int BP, int BC, int WGP, int WGC, int BKB, int STAGES, bool HAS_RES, int KS>
-__global__ __launch_bounds__(64 * WGP * WGC * KS, (KS > 1 || WGP * WGC > 4 ? 1 : (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4)))
+__global__ __launch_bounds__(64 * WGP * WGC * KS,
+                             (KS > 1 || WGP * WGC > 4 ? 1 : (BKB > 64 ? 2 : (BP * BC >= 128 * 128 ? FT_DMA_WAVES_BIG : 4))))
 void conv_igemm_dma_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only types (__amdgpu_buffer_rsrc_t); the host pass only needs the stub
   constexpr int NW = WGP * WGC;             // waves per K-group: 4 (128x128 and smaller tiles) or 8 (256x128)
@@ -1274,14 +1275,14 @@ static void launch_generic(const ConvParams& p, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((conv_igemm_kernel<T, kBP, BC, WGP, WGC, kBKB>), grid, dim3(256), lds, s, p);
 }
 
-template <typename T, int BP, int BC, int WGP, int WGC, bool HAS_RES, int KS = 1>
+template <typename T, int BP, int BC, int WGP, int WGC, bool HAS_RES, int KS = 1, int BKB = kDmaBKB, int S = kDmaStages>
 static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t ring = (size_t)KS * kDmaStages * (BC + BP) * kDmaBKB;
+  constexpr size_t ring = (size_t)KS * S * (BC + BP) * BKB;
   constexpr size_t lds = ring + (size_t)BP * 8;
   static_assert((size_t)BP * BC * 2 <= ring, "fp16 output tile must fit in the ring");
   static_assert((size_t)(KS - 1) * BP * BC * 4 <= ring, "K-split partials must fit in the rings");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = conv_igemm_dma_kernel<T, BP, BC, WGP, WGC, kDmaBKB, kDmaStages, HAS_RES, KS>;
+  auto k = conv_igemm_dma_kernel<T, BP, BC, WGP, WGC, BKB, S, HAS_RES, KS>;
   if (lds > 64 * 1024) {
     static thread_local bool raised = false;
     if (!raised) {
@@ -1293,23 +1294,31 @@ static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
   return FT_OK;
 }
 
-template <typename T, int BP, int BC, int WGP, int WGC, int KS = 1>
+template <typename T, int BP, int BC, int WGP, int WGC, int KS = 1, int BKB = kDmaBKB, int S = kDmaStages>
 static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
   // the residual-prefetch variant exists for the fp16 LDS-transposed epilogue only
-  if (sizeof(T) == 2 && p.res && p.epi_lds) return launch_dma_r<T, BP, BC, WGP, WGC, true, KS>(p, grid, s);
-  return launch_dma_r<T, BP, BC, WGP, WGC, false, KS>(p, grid, s);
+  if (sizeof(T) == 2 && p.res && p.epi_lds) return launch_dma_r<T, BP, BC, WGP, WGC, true, KS, BKB, S>(p, grid, s);
+  return launch_dma_r<T, BP, BC, WGP, WGC, false, KS, BKB, S>(p, grid, s);
 }
 
+// "wide-K" variants (fp16): 128 bytes of K per tile row per step = whole 128-byte lines per row from L2, half the
+// barriers and K-steps; twice the LDS per stage, so fewer stages / workgroups per CU.  Offered to the tile benchmark
+// for the layers whose K-loop is latency-bound (few workgroups, long K).
+constexpr int kHintWideShift = 28;   // tile_hint bits 28-29: wide-K level w, BKB = 64 << w
+
 // Tile variants the dma kernel is instantiated for (ft_conv_tile_candidates / ft_conv_desc.tile_hint).
-static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks) {
+static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0) {
   if (!g.dma) return false;
+  if (wide < 0 || wide > 1) return false;   // (BKB = 256 was benchmarked too: never the fastest on any layer)
+  if (wide && !(d->dtype == FT_F16 && g.kc % (1 << wide) == 0)) return false;
+  if (wide && ks > 1) return false;         // (wide + split-K likewise)
   if (!((bp == 64 || bp == 128 || bp == 256) && (bc == 64 || bc == 128) && (ks == 1 || ks == 2 || ks == 4))) return false;
   if (g.cout_pad % bc != 0) return false;
   if (bp == 256 && !(bc == 128 && d->dtype == FT_F16 && ks == 1)) return false;
   if (ks > 1) {
     if (d->dtype != FT_F16 || (bp == 128 && bc == 64) || (ks == 4 && bp == 128)) return false;
-    if (g.nk < 2 * ks) return false;
-    if ((size_t)ks * kDmaStages * (bc + bp) * kDmaBKB + 2048 + (size_t)bp * 8 > 160 * 1024) return false;
+    if ((g.nk >> wide) < 2 * ks) return false;
+    if ((size_t)ks * kDmaStages * (bc + bp) * (kDmaBKB << wide) + 2048 + (size_t)bp * 8 > 160 * 1024) return false;
   }
   return true;
 }
@@ -1333,6 +1342,8 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
   for (const auto& t : kTiles)
     for (int ks = 1; ks <= 4; ks <<= 1)
       if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
+  for (const auto& t : kTiles)
+    if (n < max && tile_valid(d, g, t[0], t[1], 1, 1)) hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (1 << kHintWideShift);
   return n;
 }
 
@@ -1476,18 +1487,31 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     }
     // explicit choice: the caller's benchmarked hint, or the developer override from the environment
     static const int force = (env_int("FT_CONV_BP") & 0xfff) | ((env_int("FT_CONV_BC") & 0xfff) << 12) | (env_int("FT_CONV_KS") << 24);
-    const int hint = force ? force : d->tile_hint;
+    static const int force_wide = env_int("FT_CONV_WIDE");
+    const int hint = force ? (force | ((force_wide & 3) << kHintWideShift)) : d->tile_hint;
+    int wide = 0;
     if (hint) {
-      const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0xfff, hks = hint >> 24;
+      const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0xfff, hks = (hint >> 24) & 0xf;
+      const int hwide = (hint >> kHintWideShift) & 3;
       const int nbp = hbp ? hbp : bp, nbc = hbc ? hbc : bc, nks = hks ? hks : (hbp || hbc ? 1 : ks);
-      if (tile_valid(d, g, nbp, nbc, nks)) { bp = nbp; bc = nbc; ks = nks; }
+      if (tile_valid(d, g, nbp, nbc, nks, hwide)) { bp = nbp; bc = nbc; ks = nks; wide = hwide; }
+    }
+    if (wide) {
+      p.kc = g.kc >> wide;
+      p.nk = g.nk >> wide;
     }
     p.npt = ceil_div(p.M, bp);
     p.nct = g.cout_pad / bc;
     if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
     dim3 grid(p.npt * p.nct * p.nph);
     int rc;
-    if (d->dtype == FT_F16) {
+    if (wide == 1) {
+      if (bp == 256) rc = launch_dma<half_t, 256, 128, 4, 2, 1, 128, 2>(p, grid, s);
+      else if (bp == 128 && bc == 128) rc = launch_dma<half_t, 128, 128, 2, 2, 1, 128, 2>(p, grid, s);
+      else if (bp == 128) rc = launch_dma<half_t, 128, 64, 2, 2, 1, 128, 3>(p, grid, s);
+      else if (bc == 128) rc = launch_dma<half_t, 64, 128, 2, 2, 1, 128, 3>(p, grid, s);
+      else rc = launch_dma<half_t, 64, 64, 2, 2, 1, 128, 3>(p, grid, s);
+    } else if (d->dtype == FT_F16) {
       if (bp == 256) rc = launch_dma<half_t, 256, 128, 4, 2>(p, grid, s);
       else if (bp == 128 && bc == 128)
         rc = ks == 2 ? launch_dma<half_t, 128, 128, 2, 2, 2>(p, grid, s) : launch_dma<half_t, 128, 128, 2, 2>(p, grid, s);

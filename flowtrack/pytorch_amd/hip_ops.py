@@ -208,9 +208,9 @@ class Program:
         if not convs:
             return 0
         cands = []
-        hints = (ctypes.c_int * 16)()
+        hints = (ctypes.c_int * 32)()
         for _, d in convs:
-            n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 16)
+            n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
             if n < 0:
                 check(-n, "ft_conv_tile_candidates")
             cands.append([0] + [int(h) for h in hints[:n]] if n > 1 else [0])
@@ -255,7 +255,7 @@ class Program:
             if verbose:
                 h = cands[k][best]
                 print(f"[tile benchmark] {self.conv_records[k][0]:28s} heuristic {times[k][0] * 1e3:7.1f} us  best {times[k][best] * 1e3:7.1f} us"
-                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {h >> 24}", file=sys.stderr)
+                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}", file=sys.stderr)
         return changed
 
     def __del__(self):

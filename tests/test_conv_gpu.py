@@ -160,3 +160,61 @@ def test_rowpacked_conv_matches_oracle(hip_lib, case, dtype):
     scale = max(1.0, want.abs().max().item())
     err = (got - want).abs().max().item()
     assert err <= tol * scale, f"{name} {dtype}: max abs err {err:.3e} (scale {scale:.2f})"
+
+
+# ---- every tile variant the library offers (ft_conv_tile_candidates) must give the oracle's result ----------
+VARIANT_CASES = [
+    # (name, N, Cin, H, W, Cout, k, stride, pad, transposed, residual)
+    ("var_3x3_256", 3, 256, 16, 12, 256, 3, 1, 1, False, False),
+    ("var_1x1_res", 2, 128, 17, 13, 512, 1, 1, 0, False, True),
+    ("var_3x3_s2_ragged", 2, 128, 15, 11, 128, 3, 2, 1, False, False),
+    ("var_deconv_512", 2, 512, 8, 6, 256, 4, 2, 1, True, False),
+    ("var_1x1_cin64", 2, 64, 16, 12, 256, 1, 1, 0, False, True),
+    ("var_stem_rowpack", 2, 3, 64, 48, 64, 7, 2, 3, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=[c[0] for c in VARIANT_CASES])
+def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
+    import ctypes
+    from flowtrack.pytorch_amd.hip_ops import new_rowpacked_act
+    name, N, Cin, H, W, Cout, k, stride, pad, transposed, has_res = case
+    dev = torch.device("cuda:0")
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    fan = (Cin * 4) if transposed else Cin * k * k
+    w = synth.normal(5, name + ".w", wshape, std=(2.0 / fan) ** 0.5)
+    x = synth.normal(5, name + ".x", (N, Cin, H, W))
+    bn = {"weight": synth.uniform(5, name + ".g", (Cout,), 0.5, 1.5), "bias": synth.normal(5, name + ".be", (Cout,), 0.1),
+          "running_mean": synth.normal(5, name + ".m", (Cout,), 0.1), "running_var": synth.uniform(5, name + ".v", (Cout,), 0.5, 1.5),
+          "eps": 1e-5}
+    if dtype == torch.float16:
+        w, x = w.half().float(), x.half().float()
+    layer = FusedConv(w, dtype=dtype, device=dev, stride=stride, pad=pad, transposed=transposed, bn=bn, act="relu", label=name)
+    Ho, Wo = layer.out_hw(H, W)
+    res = synth.normal(5, name + ".r", (N, Cout, Ho, Wo)) if has_res else None
+    if res is not None and dtype == torch.float16:
+        res = res.half().float()
+    want = _reference(x, w, None, bn, stride, pad, transposed, "relu", res)
+    if Cin <= 4:
+        xv = new_rowpacked_act(N, H, W, Cin, pad, dtype, dev)
+        xv.t[:, :, xv.lpad:xv.lpad + W, :Cin] = x.permute(0, 2, 3, 1).to(device=dev, dtype=dtype)
+    else:
+        xv = nchw_to_view(x, dtype, dev, cstride=act_stride(Cin))
+    yv = ActView(torch.zeros((N, Ho, Wo, act_stride(Cout)), dtype=dtype, device=dev), Cout, 0)
+    prog = make_program()
+    layer.record(prog, xv, yv, residual=nchw_to_view(res, dtype, dev) if res is not None else None)
+    d = prog.conv_records[0][3]
+    hints = (ctypes.c_int * 32)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+    assert n >= 2, f"{name}: only {n} tile variants offered"
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    scale = max(1.0, want.abs().max().item())
+    for h in [0] + [int(v) for v in hints[:n]]:
+        d.tile_hint = h
+        yv.t.fill_(3.0)
+        run_program(prog)
+        err = (view_to_nchw(yv) - want).abs().max().item()
+        assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} "
+                                    f"wide {(h >> 28) & 3}: max abs err {err:.3e}")
+    assert torch.all(yv.t[..., Cout:] == 3.0) or act_stride(Cout) == Cout
