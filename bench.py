@@ -212,8 +212,16 @@ def main():
         workload = (f"{args.flow_model} {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU "
                     f"(BASELINE.json configs[3]{'' if default_cfg else ' shape, other stack'})")
 
-    for _ in range(max(args.warmup, 2)):   # >= 2: first run is eager + graph capture, second replays the graph
+    for _ in range(max(args.warmup, 2)):   # >= 2: first run is eager (+ tile benchmark) + graph capture, second replays the graph
         step()
+    # untimed: keep replaying until the GPU has been busy for ~0.5 s, so the timed region does not start on the
+    # idle clocks of a freshly woken GPU (observed: an occasional 2x slower 30-step region right after start-up)
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.5:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
