@@ -1,0 +1,92 @@
+"""Size-independent properties at BASELINE.json's FULL sizes (the oracle needs minutes there, so these cases are
+checked through properties instead of a CPU comparison):
+  * batch consistency: a crop's heatmaps / a pair's flow do not depend on which batch it rides in (eval-mode BN,
+    no cross-sample op) — rows [0:4] of the full batch equal the same 4 inputs run alone, and those 4 ARE pinned
+    against the imported reference (pose_golden.npz: config C1 = batch 4 of 256x192);
+  * determinism: two replays of the captured graph are bit-identical;
+  * fp16 (fast mode) vs fp32 (parity mode) of the same network: heatmap error small against the range, arg-max equal
+    except at near-ties."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from flowtrack.pytorch_amd import synth
+from flowtrack.pytorch_amd.flownet import models as flow_models
+from flowtrack.pytorch_amd.hip_ops import heatmap_max_preds
+from flowtrack.pytorch_amd.pose import models as pose_models
+
+pytestmark = pytest.mark.gpu
+PG = np.load(os.path.join(GOLDEN, "pose_golden.npz"))
+SEED = int(PG["seed"])
+ARGS = types.SimpleNamespace(rgb_max=255.0, fp16=False)
+
+
+def _pose(depth, dtype):
+    m = pose_models.deconv(f"resnet{depth}", 17, False)
+    m.load_state_dict(synth.fill_pose_state_dict(m.state_dict(), SEED))
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    return m
+
+
+def test_pose_r50_batch64_contains_the_pinned_batch4(hip_lib):
+    """BASELINE configs[1] (64 x 256x192): rows 0..3 are the crops of the reference golden (configs[0])."""
+    m = _pose(50, torch.float32)
+    x4 = synth.pose_crops(SEED, 4)
+    x = torch.cat((x4, synth.pose_crops(SEED + 1, 60)), 0).cuda()
+    hm = m(x)
+    assert tuple(hm.shape) == (64, 17, 64, 48)
+    err = np.abs(hm[:2].cpu().numpy() - PG["r50_heatmaps_b2"]).max()
+    assert err <= 1e-3, f"rows 0..1 of the 64-crop batch vs reference heatmaps: {err:.3e}"
+    idx, _, _ = heatmap_max_preds(hm[:4], adjust_coords=False)
+    assert np.array_equal(idx.cpu().numpy(), PG["r50_idx"]), "arg-max of rows 0..3 differs from the reference"
+    alone = m(x[:4])
+    assert (alone - hm[:4]).abs().max().item() <= 1e-4, "a crop's heatmaps depend on its batch"
+    again = m(x)
+    assert torch.equal(again, hm), "graph replay is not deterministic"
+
+
+def test_pose_r101_384x288_batch16_fp16_vs_fp32(hip_lib):
+    """BASELINE configs[2] (ResNet-101, 16 x 384x288): fast mode against parity mode on the same weights."""
+    x = synth.pose_crops(SEED + 2, 16, 384, 288).cuda()
+    hm32 = _pose(101, torch.float32)(x)
+    hm16 = _pose(101, torch.float16)(x)
+    assert tuple(hm32.shape) == (16, 17, 96, 72) and torch.isfinite(hm16).all()
+    rng = (hm32.max() - hm32.min()).item()
+    err = (hm16 - hm32).abs().max().item()
+    assert err <= 0.05 * rng, f"fp16 heatmap error {err:.3e} vs range {rng:.3f}"
+    i32, s32, _ = heatmap_max_preds(hm32, adjust_coords=False)
+    i16, _, _ = heatmap_max_preds(hm16, adjust_coords=False)
+    same = (i32 == i16).float().mean().item()
+    flat = hm32.flatten(2)
+    top2 = flat.topk(2, dim=2).values
+    margin = (top2[..., 0] - top2[..., 1])
+    flipped = (i32 != i16)
+    assert same >= 0.9 and (not flipped.any() or margin[flipped].max().item() <= 2 * err), \
+        f"{same:.3f} identical arg-max; a flip without a near-tie"
+
+
+def test_flownet2s_batch16_512x384_consistency(hip_lib):
+    """BASELINE configs[3] (16 pairs of 512x384): batch consistency, determinism, fp16 EPE against fp32."""
+    m = flow_models.FlowNet2S(ARGS)
+    sd = synth.fill_flow_state_dict(m.state_dict(), SEED)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = torch.float32
+    x = synth.frame_pairs(SEED, 16).cuda()
+    f32 = m(x)
+    assert tuple(f32.shape) == (16, 2, 384, 512)
+    assert (m(x[:2]) - f32[:2]).abs().max().item() <= 1e-3, "a pair's flow depends on its batch"
+    assert torch.equal(m(x), f32), "graph replay is not deterministic"
+    m16 = flow_models.FlowNet2S(ARGS)
+    m16.load_state_dict(sd)
+    m16 = m16.cuda().eval()
+    m16.compute_dtype = torch.float16
+    f16 = m16(x)
+    epe = torch.norm(f16 - f32, dim=1).mean().item()
+    mag = torch.norm(f32, dim=1).mean().item()
+    assert epe <= 0.02 * max(mag, 1.0) + 0.05, f"fp16 EPE {epe:.4f} px at mean |flow| {mag:.3f}"
