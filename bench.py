@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--res", default="256x192", help="pose crop HxW (multiples of 32)")
     ap.add_argument("--flow-model", default="FlowNet2S",
                     choices=["FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2CSS", "FlowNet2SD", "FlowNet2"])
+    ap.add_argument("--fixed-warmup", action="store_true", help="exactly max(W,2) untimed steps (profiling runs that count launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
@@ -218,7 +219,7 @@ def main():
     # idle clocks of a freshly woken GPU (observed: an occasional 2x slower 30-step region right after start-up)
     torch.cuda.synchronize()
     t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < 0.5:
+    while not args.fixed_warmup and time.perf_counter() - t_warm < 0.5:
         for _ in range(10):
             step()
         torch.cuda.synchronize()

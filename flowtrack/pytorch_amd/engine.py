@@ -84,10 +84,9 @@ class HipModule(nn.Module):
         prog.stream.wait_stream(cur)
         if first:
             prog.run_eager()          # surfaces argument errors before any capture
-            if hip_ops.benchmark:     # cudnn.benchmark counterpart: pick each conv's tile variant in situ
-                prog.stream.synchronize()
+            if hip_ops.benchmark:     # cudnn.benchmark counterpart: pick each conv's tile variant in situ (every
+                prog.stream.synchronize()   # pass is a complete, valid forward: the outputs stay those of this input)
                 prog.tune_tiles(verbose=bool(os.environ.get("FT_CONV_BENCHMARK_VERBOSE")))
-                prog.run_eager()      # the outputs of this call come from the chosen variants
             if self.use_graph:
                 prog.stream.synchronize()
                 prog.capture()

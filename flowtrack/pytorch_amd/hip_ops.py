@@ -11,6 +11,7 @@ reference graphs (lib/flownet/networks/FlowNetS.py:73-88) becomes "write into a 
 from __future__ import annotations
 
 import ctypes
+import json
 import os
 import sys
 from dataclasses import dataclass
@@ -207,6 +208,12 @@ class Program:
         convs = [(i, rec[3]) for rec in self.conv_records for i in (rec[1],)]
         if not convs:
             return 0
+        _load_tile_cache()
+        keys = [_desc_key(d) for _, d in convs]
+        if all(k in _TILE_CACHE for k in keys):          # every layer already benchmarked (this process or the file)
+            for (_, d), k in zip(convs, keys):
+                d.tile_hint = _TILE_CACHE[k]
+            return sum(1 for k in keys if _TILE_CACHE[k])
         cands = []
         hints = (ctypes.c_int * 32)()
         for _, d in convs:
@@ -251,11 +258,13 @@ class Program:
             if times[k][best] > 0.97 * times[k][0]:
                 best = 0
             d.tile_hint = cands[k][best]
+            _TILE_CACHE[keys[k]] = cands[k][best]
             changed += best != 0
             if verbose:
                 h = cands[k][best]
                 print(f"[tile benchmark] {self.conv_records[k][0]:28s} heuristic {times[k][0] * 1e3:7.1f} us  best {times[k][best] * 1e3:7.1f} us"
                       f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}", file=sys.stderr)
+        _save_tile_cache()
         return changed
 
     def __del__(self):
@@ -335,6 +344,40 @@ def fold_scale_shift(cout: int, cout_pad: int, bias: Optional[torch.Tensor], bn:
 #: first-run benchmark of the conv tile variants (Program.tune_tiles; the reference's `cudnn.benchmark = True`,
 #: tools/pose/main.py:59).  FT_CONV_BENCHMARK=0 turns it off (the library's heuristic picks every tile).
 benchmark = os.environ.get("FT_CONV_BENCHMARK", "1") != "0"
+#: optional JSON file that persists the benchmark's picks across processes (descriptor -> tile_hint), the role
+#: MIOpen's perf-db plays for the reference's cudnn/MIOpen path.  FT_TILE_CACHE=<path>; unset = in-process only.
+tile_cache_path = os.environ.get("FT_TILE_CACHE") or None
+_TILE_CACHE: dict = {}
+_TILE_CACHE_LOADED = False
+
+
+def _desc_key(d: ConvDesc) -> str:
+    return ",".join(str(getattr(d, f)) for f, _ in ConvDesc._fields_ if f != "tile_hint")
+
+
+def _load_tile_cache() -> None:
+    global _TILE_CACHE_LOADED
+    if _TILE_CACHE_LOADED:
+        return
+    _TILE_CACHE_LOADED = True
+    if tile_cache_path and os.path.isfile(tile_cache_path):
+        try:
+            with open(tile_cache_path) as f:
+                _TILE_CACHE.update({k: int(v) for k, v in json.load(f).items()})
+        except (OSError, ValueError):
+            pass
+
+
+def _save_tile_cache() -> None:
+    if not tile_cache_path:
+        return
+    tmp = f"{tile_cache_path}.{os.getpid()}.tmp"
+    try:
+        with open(tmp, "w") as f:
+            json.dump(_TILE_CACHE, f, indent=0, sort_keys=True)
+        os.replace(tmp, tile_cache_path)
+    except OSError:
+        pass
 
 
 class FusedConv:

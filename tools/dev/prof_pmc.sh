@@ -4,7 +4,7 @@ out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/$out
-run() { tag=$1; shift; rocprofv3 --pmc "$@" -d $R/gpurun_out/$out/$tag -o pmc --output-format csv -- "${CMD[@]}" > $R/gpurun_out/$out/$tag.log 2>&1; }
+run() { tag=$1; shift; timeout 180 rocprofv3 --pmc "$@" -d $R/gpurun_out/$out/$tag -o pmc --output-format csv -- "${CMD[@]}" > $R/gpurun_out/$out/$tag.log 2>&1; }
 CMD=("$@")
 cd $R
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: prof_round.sh <round tag, e.g. r01>   -- regenerates every file under profiles/ for pose and flow:
+#   1. one plain bench run per workload that benchmarks the tiles and persists the picks (FT_TILE_CACHE)
+#   2. rocprofv3 --kernel-trace --stats of the same command (kernels = the bench's kernels, no tuning launches)
+#   3. separate --pmc FETCH_SIZE / WRITE_SIZE passes of a short fixed-length run -> HBM bytes per conv launch
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+export FT_TILE_CACHE=$R/gpurun_out/tile_cache_$tag.json
+rm -f $FT_TILE_CACHE
+for w in pose flow; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline --steps 30 > gpurun_out/${tag}_${w}_bench.json 2> gpurun_out/${tag}_${w}_bench.err
+  timeout 600 tools/dev/prof_trace.sh ${tag}_${w}_bench python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --fixed-warmup > /dev/null 2>&1
+  timeout 900 tools/dev/prof_traffic.sh ${tag}_${w} python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --fixed-warmup
+  python tools/dev/pmc_traffic.py gpurun_out/traffic_${tag}_${w} 6 gpurun_out/${tag}_${w}_hbm_traffic_pmc.json
+done
+tail -c 600 gpurun_out/${tag}_pose_bench.json
