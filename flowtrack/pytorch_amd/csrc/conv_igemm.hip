@@ -74,6 +74,9 @@ struct ConvParams {
   float slope;
   int npt, nct, nph;  // pixel tiles, output-channel tiles, phases (grid = npt * nct * nph, 1-D)
   int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
+  int h_tx, h_ty;     // halo path: patch tiles per image row / column
+  int h_pw, h_npix;   // halo path: input-patch width and pixel count
+  int h_npww, h_pb;   // halo path: patch wave-loads per wave per chunk, bytes of one patch buffer
   int dbg;            // developer ablation (FT_CONV_DBG): 1 = no MFMA, 2 = no operand loads, 4 = no epilogue; 0 in production
 };
 
@@ -822,6 +825,10 @@ void conv_igemm_dma_kernel(const ConvParams p) {
       const unsigned tapbit = 1u << tap;
 #pragma unroll
       for (int t = 0; t < NIB; ++t) cur_voff[t] = (b_mask[t] & tapbit) ? (unsigned)(b_base[t] + delta) : kOOB;
+      if (p.dbg & 64) {   // dev probe: pixel-tile loads fetch nothing (upper bound of an LDS-resident halo patch)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) cur_voff[t] = kOOB;
+      }
     };
     if (i_ky < p.kh) refresh();
     else {
@@ -1045,6 +1052,238 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- halo path (fp16): 3x3/s1 convs and the 2x2-tap phases of ConvTranspose2d(4,2,1) -------------------
+// The implicit-GEMM kernel above re-reads every input pixel once per tap through L2 -> LDS (9x for a 3x3), and
+// that operand delivery, not the matrix pipe, bounds it.  Here a workgroup owns a TH x TW patch of ONE image,
+// keeps the (TH+kh-1) x (TW+kw-1) input patch of a 64-channel chunk resident in LDS (double-buffered across
+// chunks) and serves the pixel operand of every tap from it; only the weight tile still streams through the
+// ring.  L2 -> LDS bytes per K-step drop from (BC + 128) x 64 to BC x 64 + ~1/6 of the pixel tile.
+//   K order: chunk (64 channels) outermost, then tap, then 32-channel slice — the packed weight layout
+//   k = tap * cin_pad + ci is unchanged, only the walk differs.
+//   Every wave issues the same number of loads per K-step (weight loads + one patch "slot", filled with a load of
+//   the next chunk's patch or a zero-traffic out-of-range load), so the counted vmcnt stays a constant.
+template <int BC, int TW, int NTAPS, int KW, int S>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = half_t;
+  constexpr int BP = 128, TH = BP / TW, NW = 4;
+  constexpr int WGP = 2, WGC = 2;
+  constexpr int WT_P = BP / WGP, WT_C = BC / WGC, MT_P = WT_P / 32, MT_C = WT_C / 32;
+  constexpr int BKB = 64, A_STAGE = BC * BKB;
+  constexpr int NIAW = BC / 64;             // weight wave-loads per wave per K-step
+  constexpr int NLS = NIAW + 1;             // + the patch slot
+  constexpr int NPWW_MAX = NTAPS * 2 - (S - 1) < 6 ? NTAPS * 2 - (S - 1) : 6;   // patch wave-loads per wave per chunk (host checks)
+  constexpr int CH = 4, SWZ_DIV = 4, RPI = 16;
+  static_assert(BC == 64 || BC == 128, "channel tile");
+  static_assert((NTAPS * 2) % S == 0, "a full chunk must be a whole number of ring turns");
+  static_assert(NPWW_MAX <= NTAPS * 2 - (S - 1), "patch loads must be issued early enough in the chunk");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave % WGP, wc = wave / WGP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int ctile, phase, ptile;
+  {
+    const int total = p.npt * p.nct * p.nph;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    ctile = logical % p.nct;
+    const int t = logical / p.nct;
+    phase = t % p.nph;
+    ptile = t / p.nph;
+  }
+  const int py = phase >> 1, px = phase & 1;
+  const int co0 = ctile * BC;
+  const int tiles_per_img = p.h_ty * p.h_tx;
+  const int n = ptile / tiles_per_img;
+  const int trem = ptile - n * tiles_per_img;
+  const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+  const int qy0 = tyi * TH, qx0 = txi * TW;
+  const int Hq = p.HqWq / p.Wq;
+  // input patch origin (top-left input pixel any tap of the patch touches)
+  const int iy_org = p.transposed ? qy0 + py - (p.kh - 1) : qy0 - p.pad;
+  const int ix_org = p.transposed ? qx0 + px - (p.kw - 1) : qx0 - p.pad_x;
+  const int PW = p.h_pw;
+  const int npww = p.h_npww;
+
+  char* const ring = smem;
+  char* const patch0 = smem + S * A_STAGE;
+  const int PB = p.h_pb;
+  char* const scratch = patch0 + 2 * PB;                       // 4 KiB: destination of the zero-traffic slot loads
+  long long* s_opix = reinterpret_cast<long long*>(scratch + 4096);
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.w) + (size_t)(phase * p.Cout_pad + co0) * p.Kpad * 2, 0, BC * p.Kpad * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- loader constants ---------------------------------------------------------------------------------
+  unsigned a_voff[NIAW];
+  {
+    const int lrow = lane / CH, pos = lane % CH;
+#pragma unroll
+    for (int t = 0; t < NIAW; ++t) {
+      const int r = (wave + NW * t) * RPI + lrow;
+      const int lc = pos ^ ((r / SWZ_DIV) % CH);
+      a_voff[t] = (unsigned)(r * p.Kpad * 2 + lc * 16);
+    }
+  }
+  unsigned p_voff[NPWW_MAX];      // patch pixel rows of 128 B: 8 lanes per pixel, chunk position XOR (pixel & 7)
+  {
+    const int ppl = lane >> 3, pos = lane & 7;
+#pragma unroll
+    for (int t = 0; t < NPWW_MAX; ++t) {
+      const int pp = (t * NW + wave) * 8 + ppl;
+      unsigned v = kOOB;
+      if (pp < p.h_npix) {
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = iy_org + pr, ix = ix_org + pc;
+        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+          v = (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff) * 2 + ((pos ^ (pp & 7)) << 4));
+      }
+      p_voff[t] = v;
+    }
+  }
+  // pixel-operand fragment rows: tile pixel -> patch row of tap (0,0)
+  int r0[MT_P];
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j) {
+    const int m = wp * WT_P + j * 32 + l31;
+    r0[j] = (m / TW) * PW + (m % TW);
+  }
+  int a_off[MT_C];
+#pragma unroll
+  for (int i = 0; i < MT_C; ++i) {
+    const int r = wc * WT_C + i * 32 + l31;
+    a_off[i] = r * BKB + ((lhi ^ ((r / SWZ_DIV) % CH)) << 4);
+  }
+
+  // output pixel table for the epilogue (and -1 for the ragged part of the patch)
+  if (tid < BP) {
+    const int oy = qy0 + tid / TW, ox = qx0 + tid % TW;
+    long long o = -1;
+    if (oy < Hq && ox < p.Wq) o = ((long long)n * p.Ho + (oy * p.omul + py)) * p.Wo + (ox * p.omul + px);
+    s_opix[tid] = o;
+  }
+
+  float16_t acc[MT_C][MT_P];
+#pragma unroll
+  for (int i = 0; i < MT_C; ++i)
+#pragma unroll
+    for (int j = 0; j < MT_P; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kc = p.kc;                       // 32-channel slices per tap
+  const int nfull = kc >> 1, half = kc & 1;  // full 64-channel chunks, trailing 32-channel chunk
+  const int cin_b = p.kc * BKB;              // bytes of one tap's K-run in the packed weight row
+
+  auto load_a = [&](auto slot_c, bool live, int soff) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int t = 0; t < NIAW; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(ring + slot * A_STAGE + (wave + NW * t) * 1024), 16,
+                                               live ? a_voff[t] : kOOB, live ? soff : 0, 0, 0);
+  };
+  auto load_patch = [&](auto t_c, bool live, int buf, int soff) {
+    constexpr int t = decltype(t_c)::value;
+    if constexpr (t < NPWW_MAX) {
+      const bool on = live && t < npww;
+      char* dst = on ? patch0 + buf * PB + (t * NW + wave) * 1024 : scratch + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)dst, 16, on ? p_voff[t] : kOOB, on ? soff : 0, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(scratch + wave * 1024), 16, kOOB, 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: patch of chunk 0, then S-1 weight stages (each preceded by its patch slot) --------------
+  static_for<NPWW_MAX>([&](auto tc) {
+    if (decltype(tc)::value < npww) load_patch(tc, true, 0, 0);
+  });
+  const bool one_half_only = nfull == 0;     // cin_pad == 32: the only chunk is the half chunk
+  // weight offset of global K-step (chunk c, step st) for chunk kind NSL
+  auto a_soff_of = [&](int c, int st, int nsl) {
+    const int tap = nsl == 2 ? st >> 1 : st, sl = nsl == 2 ? st & 1 : 0;
+    return tap * cin_b + c * 128 + sl * 64;
+  };
+  const int total_steps = NTAPS * kc;
+  static_for<S - 1>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    load_patch(std::integral_constant<int, NPWW_MAX>{}, false, 0, 0);   // slot (nothing to prefetch yet)
+    load_a(sc, s < total_steps, a_soff_of(0, s, one_half_only ? 1 : 2));
+  });
+  __syncthreads();                           // s_opix visible (also orders nothing else: LDS-DMA uses vmcnt)
+
+  // ---- one chunk: NTAPS * NSL K-steps, fully unrolled ----------------------------------------------------
+  auto chunk_body = [&](auto nsl_c, int c, bool has_next, int next_nsl) {
+    constexpr int NSL = decltype(nsl_c)::value;
+    constexpr int SPC = NTAPS * NSL;
+    const char* pbuf = patch0 + (c & 1) * PB;
+    static_for<SPC>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      constexpr int tap = st / NSL, sl = st % NSL;
+      constexpr int slot = st % S, nslot = (st + S - 1) % S;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS * (S - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      // fragments: weights from the ring, pixels from the resident patch at this tap's offset
+      const char* sa = ring + slot * A_STAGE;
+      constexpr int ky = tap / KW, kx = tap % KW;
+      const int trow = p.transposed ? ((NTAPS / KW - 1 - ky) * PW + (KW - 1 - kx)) : (ky * PW + kx);
+      uint4_t fa[2][MT_C], fb[2][MT_P];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT_C; ++i) fa[kk][i] = *reinterpret_cast<const uint4_t*>(sa + (a_off[i] ^ (kk << 5)));
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j) {
+        const int r = r0[j] + trow;
+        const int lsw = lhi ^ (r & 7);
+        const char* rowp = pbuf + r * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          fb[kk][j] = *reinterpret_cast<const uint4_t*>(rowp + ((lsw ^ (sl * 4 + kk * 2)) << 4));
+      }
+      // loads of K-step (st + S - 1): patch slot first, then the weight stage
+      constexpr int la = st + S - 1;                     // lookahead step, may fall into the next chunk
+      constexpr int NM = 2 * MT_C * MT_P;
+      static_for<NM>([&](auto mi) {
+        constexpr int m = decltype(mi)::value;
+        constexpr int kk = m / (MT_C * MT_P), i = (m / MT_P) % MT_C, j = m % MT_P;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk][i]),
+                                                           __builtin_bit_cast(half8_t, fb[kk][j]), acc[i][j], 0, 0, 0);
+        if constexpr (m == 0) {
+          load_patch(std::integral_constant<int, (st < NPWW_MAX ? st : NPWW_MAX)>{}, has_next, (c + 1) & 1, (c + 1) * 128);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (m == 1 || (NM == 2 && m == 1)) {
+          if constexpr (la < SPC) {
+            load_a(std::integral_constant<int, nslot>{}, true, a_soff_of(c, la, NSL));
+          } else {
+            load_a(std::integral_constant<int, nslot>{}, has_next, a_soff_of(c + 1, la - SPC, next_nsl));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    });
+  };
+  using two = std::integral_constant<int, 2>;
+  using one = std::integral_constant<int, 1>;
+  for (int c = 0; c < nfull; ++c) {
+    const bool last_full = c + 1 == nfull;
+    chunk_body(two{}, c, !last_full || half, last_full ? 1 : 2);
+  }
+  if (half) chunk_body(one{}, nfull, false, 1);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_epilogue<T, BP, BC, WGP, WGC, true>(p, acc, smem, (int)(reinterpret_cast<char*>(s_opix) - smem), 0, co0, py, px, nullptr);
+#endif
+}
+
 // ---- few-output-channel conv (FlowNet predict_flow: Cout = 2, K up to 9 * 1026) -----------------------
 // A GEMM tile would leave 30/32 MFMA columns idle and serialise a 9k-long K loop in a handful of
 // workgroups.  Instead: one wave per group of PIX consecutive output pixels, the 64 lanes split the
@@ -1245,7 +1484,8 @@ static int geometry(const ft_conv_desc* d, Geometry* g) {
   }
   const int cin_bk = round_up(d->Cin, bk);
   const long long wbytes = (long long)128 * g->ntaps * cin_bk * esz;  // one co tile of packed weights
-  g->dma = d->Cout > 32 && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
+  static const int dma_min_cout = getenv("FT_CONV_DMA_MIN_COUT") ? atoi(getenv("FT_CONV_DMA_MIN_COUT")) : 33;  // dev knob
+  g->dma = d->Cout >= dma_min_cout && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
   if (g->dma) {
     g->cin_pad = cin_bk;
     g->cout_pad = round_up(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
@@ -1307,8 +1547,66 @@ static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
 constexpr int kHintWideShift = 28;   // tile_hint bits 28-29: wide-K level w, BKB = 64 << w
 
 // Tile variants the dma kernel is instantiated for (ft_conv_tile_candidates / ft_conv_desc.tile_hint).
-static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0) {
+template <int BC, int TW, int NTAPS, int KW, int S>
+static int launch_halo_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
+  auto k = conv_halo_kernel<BC, TW, NTAPS, KW, S>;
+  if (lds > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  return FT_OK;
+}
+
+static int launch_halo(ConvParams p, const ft_conv_desc* d, const Geometry& g, int bc, hipStream_t s) {
+  const int Hq = p.HqWq / p.Wq, Wq = p.Wq;
+  const int kq = d->transposed ? 2 : 3;                      // taps per dimension of one phase
+  // patch shape 8x16 or 16x8 output pixels: the one that wastes fewer pixels on this image size
+  const long long t16 = (long long)ceil_div(Hq, 8) * ceil_div(Wq, 16), t8 = (long long)ceil_div(Hq, 16) * ceil_div(Wq, 8);
+  const int tw = t16 <= t8 ? 16 : 8, th = 128 / tw;
+  p.h_ty = ceil_div(Hq, th);
+  p.h_tx = ceil_div(Wq, tw);
+  p.h_pw = tw + kq - 1;
+  p.h_npix = (th + kq - 1) * p.h_pw;
+  p.h_npww = ceil_div(ceil_div(p.h_npix, 8), 4);
+  if (p.h_npww > (d->transposed ? 5 : 6)) return FT_ERR_UNSUPPORTED;
+  p.h_pb = p.h_npww * 4 * 1024;
+  const int S = d->transposed ? 4 : 3;
+  const size_t lds = (size_t)S * bc * 64 + 2 * (size_t)p.h_pb + 4096 + 128 * 8;
+  const int N = p.M / p.HqWq;
+  p.npt = N * p.h_ty * p.h_tx;
+  p.nct = g.cout_pad / bc;
+  if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+  dim3 grid(p.npt * p.nct * p.nph);
+  int rc;
+  if (d->transposed) {
+    if (bc == 128) rc = tw == 16 ? launch_halo_k<128, 16, 4, 2, 4>(p, grid, lds, s) : launch_halo_k<128, 8, 4, 2, 4>(p, grid, lds, s);
+    else rc = tw == 16 ? launch_halo_k<64, 16, 4, 2, 4>(p, grid, lds, s) : launch_halo_k<64, 8, 4, 2, 4>(p, grid, lds, s);
+  } else {
+    if (bc == 128) rc = tw == 16 ? launch_halo_k<128, 16, 9, 3, 3>(p, grid, lds, s) : launch_halo_k<128, 8, 9, 3, 3>(p, grid, lds, s);
+    else rc = tw == 16 ? launch_halo_k<64, 16, 9, 3, 3>(p, grid, lds, s) : launch_halo_k<64, 8, 9, 3, 3>(p, grid, lds, s);
+  }
+  if (rc != FT_OK) return rc;
+  FT_LAUNCH_CHECK("conv_halo_kernel");
+  return FT_OK;
+}
+
+constexpr int kHintHalo = 1 << 30;   // tile_hint bit 30: LDS-resident input patch (conv_halo_kernel)
+
+// conv_halo_kernel: fp16, 3x3 / stride 1 or the 2x2-tap phases of ConvTranspose2d(4,2,1), NHWC fp16 8-aligned output,
+// no residual, channel-aligned (dma) weight layout
+static bool halo_ok(const ft_conv_desc* d, const Geometry& g) {
+  if (!g.dma || g.rowpack || d->dtype != FT_F16 || d->has_residual) return false;
+  if (!(d->transposed || (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1))) return false;
+  return d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0;
+}
+
+static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0, bool halo = false) {
   if (!g.dma) return false;
+  if (halo) return halo_ok(d, g) && bp == 128 && (bc == 64 || bc == 128) && g.cout_pad % bc == 0 && ks == 1 && wide == 0;
   if (wide < 0 || wide > 1) return false;   // (BKB = 256 was benchmarked too: never the fastest on any layer)
   if (wide && !(d->dtype == FT_F16 && g.kc % (1 << wide) == 0)) return false;
   if (wide && ks > 1) return false;         // (wide + split-K likewise)
@@ -1344,6 +1642,8 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
       if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
   for (const auto& t : kTiles)
     if (n < max && tile_valid(d, g, t[0], t[1], 1, 1)) hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (1 << kHintWideShift);
+  for (int bc = 128; bc >= 64; bc >>= 1)
+    if (n < max && tile_valid(d, g, 128, bc, 1, 0, true)) hints[n++] = 128 | (bc << 12) | (1 << 24) | kHintHalo;
   return n;
 }
 
@@ -1490,18 +1790,21 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     // few workgroups + long K: the K-loop is latency-bound (one barrier per step, <= 2 waves per SIMD), so take
     // 128 bytes of K per step instead of splitting K (measured in situ on R50 / FlowNet2S: 15-25 % on those layers)
     int wide = 0;
+    bool halo = false;
     if (d->dtype == FT_F16 && bp <= 128 && g.kc % 2 == 0 && g.ntaps * g.cin_pad >= 512 && blocks(bp, bc) <= 768) {
       wide = 1;
       ks = 1;
     }
-    static const int force_wide = env_int("FT_CONV_WIDE");
-    const int hint = force ? (force | ((force_wide & 3) << kHintWideShift)) : d->tile_hint;
+    static const int force_wide = env_int("FT_CONV_WIDE"), force_halo = env_int("FT_CONV_HALO");
+    const int hint = force ? (force | ((force_wide & 3) << kHintWideShift) | (force_halo ? kHintHalo : 0)) : d->tile_hint;
     if (hint) {
       const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0xfff, hks = (hint >> 24) & 0xf;
       const int hwide = (hint >> kHintWideShift) & 3;
+      const bool hhalo = (hint & kHintHalo) != 0;
       const int nbp = hbp ? hbp : bp, nbc = hbc ? hbc : bc, nks = hks ? hks : (hbp || hbc ? 1 : ks);
-      if (tile_valid(d, g, nbp, nbc, nks, hwide)) { bp = nbp; bc = nbc; ks = nks; wide = hwide; }
+      if (tile_valid(d, g, nbp, nbc, nks, hwide, hhalo)) { bp = nbp; bc = nbc; ks = nks; wide = hwide; halo = hhalo; }
     }
+    if (halo) return launch_halo(p, d, g, bc, s);
     if (wide) {
       p.kc = g.kc >> wide;
       p.nk = g.nk >> wide;

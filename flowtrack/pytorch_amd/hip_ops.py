@@ -263,7 +263,7 @@ class Program:
             if verbose:
                 h = cands[k][best]
                 print(f"[tile benchmark] {self.conv_records[k][0]:28s} heuristic {times[k][0] * 1e3:7.1f} us  best {times[k][best] * 1e3:7.1f} us"
-                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}", file=sys.stderr)
+                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}{' halo' if (h >> 30) & 1 else ''}", file=sys.stderr)
         _save_tile_cache()
         return changed
 

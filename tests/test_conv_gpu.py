@@ -171,6 +171,12 @@ VARIANT_CASES = [
     ("var_deconv_512", 2, 512, 8, 6, 256, 4, 2, 1, True, False),
     ("var_1x1_cin64", 2, 64, 16, 12, 256, 1, 1, 0, False, True),
     ("var_stem_rowpack", 2, 3, 64, 48, 64, 7, 2, 3, False, False),
+    # halo-patch kernel: ragged patches, one full + one half 64-channel chunk, half chunk only, BC = 64, many chunks
+    ("var_3x3_ragged_cin96", 2, 96, 17, 13, 128, 3, 1, 1, False, False),
+    ("var_3x3_cin32_cout64", 1, 32, 20, 37, 64, 3, 1, 1, False, False),
+    ("var_3x3_tall", 1, 64, 40, 9, 192, 3, 1, 1, False, False),
+    ("var_deconv_cin1026", 1, 1026, 5, 7, 256, 4, 2, 1, True, False),
+    ("var_deconv_cout64_wide_img", 1, 128, 6, 33, 64, 4, 2, 1, True, False),
 ]
 
 
@@ -216,5 +222,5 @@ def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
         run_program(prog)
         err = (view_to_nchw(yv) - want).abs().max().item()
         assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} "
-                                    f"wide {(h >> 28) & 3}: max abs err {err:.3e}")
+                                    f"wide {(h >> 28) & 3} halo {(h >> 30) & 1}: max abs err {err:.3e}")
     assert torch.all(yv.t[..., Cout:] == 3.0) or act_stride(Cout) == Cout

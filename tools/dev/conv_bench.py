@@ -33,6 +33,15 @@ POSE = [
     ("deconv6_256", 64, 256, 32, 24, 256, 4, 2, 1, 1, 0, 1),
     ("heatmap17", 64, 256, 64, 48, 17, 1, 1, 0, 0, 0, 1),
 ]
+FUSION = [
+    ("fu.conv0_11", 16, 16, 384, 512, 64, 3, 1, 1, 0, 0, 1),
+    ("fu.inter0_82_16", 16, 82, 384, 512, 16, 3, 1, 1, 0, 0, 1),
+    ("fu.inter1_162_32", 16, 162, 192, 256, 32, 3, 1, 1, 0, 0, 1),
+    ("fu.deconv0_162_16", 16, 162, 192, 256, 16, 4, 2, 1, 1, 0, 1),
+    ("fu.deconv1_128_32", 16, 128, 96, 128, 32, 4, 2, 1, 1, 0, 1),
+    ("fu.pflow0_16_2", 16, 16, 384, 512, 2, 3, 1, 1, 0, 0, 1),
+    ("fu.pflow1_32_2", 16, 32, 192, 256, 2, 3, 1, 1, 0, 0, 1),
+]
 FLOW = [
     ("f.conv1_7x7", 16, 6, 384, 512, 64, 7, 2, 3, 0, 0, 1),
     ("f.conv2_5x5", 16, 64, 192, 256, 128, 5, 2, 2, 0, 0, 1),
@@ -53,7 +62,7 @@ FLOW = [
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "pose"
     dtype = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "fp16") else torch.float32
-    cases = {"pose": POSE, "flow": FLOW, "all": POSE + FLOW}[which]
+    cases = {"pose": POSE, "flow": FLOW, "fusion": FUSION, "all": POSE + FLOW}[which]
     if len(sys.argv) > 3:
         keys = sys.argv[3].split(",")
         cases = [c for c in cases if any(k in c[0] for k in keys)]
