@@ -1062,8 +1062,8 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 //   k = tap * cin_pad + ci is unchanged, only the walk differs.
 //   Every wave issues the same number of loads per K-step (weight loads + one patch "slot", filled with a load of
 //   the next chunk's patch or a zero-traffic out-of-range load), so the counted vmcnt stays a constant.
-template <int BC, int TW, int NTAPS, int KW, int S>
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
+template <int BC, int TW, int NTAPS, int KW, int S, int CCH>
+__global__ __launch_bounds__(256, (CCH == 32 ? 3 : 2)) void conv_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = half_t;
   constexpr int BP = 128, TH = BP / TW, NW = 4;
@@ -1072,11 +1072,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   constexpr int BKB = 64, A_STAGE = BC * BKB;
   constexpr int NIAW = BC / 64;             // weight wave-loads per wave per K-step
   constexpr int NLS = NIAW + 1;             // + the patch slot
-  constexpr int NPWW_MAX = NTAPS * 2 - (S - 1) < 6 ? NTAPS * 2 - (S - 1) : 6;   // patch wave-loads per wave per chunk (host checks)
+  constexpr int NSLM = CCH / 32;            // 32-channel slices (K-steps per tap) in a regular chunk
+  constexpr int ROWB = CCH * 2;             // bytes of one patch pixel row
+  constexpr int LPP = ROWB / 16;            // lanes per patch pixel in a 1-KiB wave load
+  constexpr int PPW = 64 / LPP;             // patch pixels per wave load
+  constexpr int NPWW_MAX = NTAPS * NSLM - (S - 1) < 6 ? NTAPS * NSLM - (S - 1) : 6;   // patch wave-loads per wave per chunk (host checks)
   constexpr int CH = 4, SWZ_DIV = 4, RPI = 16;
   static_assert(BC == 64 || BC == 128, "channel tile");
-  static_assert((NTAPS * 2) % S == 0, "a full chunk must be a whole number of ring turns");
-  static_assert(NPWW_MAX <= NTAPS * 2 - (S - 1), "patch loads must be issued early enough in the chunk");
+  static_assert(CCH == 32 || CCH == 64, "channels per resident patch chunk");
+  static_assert((NTAPS * NSLM) % S == 0, "a regular chunk must be a whole number of ring turns");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -1113,8 +1117,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   char* const ring = smem;
   char* const patch0 = smem + S * A_STAGE;
   const int PB = p.h_pb;
-  char* const scratch = patch0 + 2 * PB;                       // 4 KiB: destination of the zero-traffic slot loads
-  long long* s_opix = reinterpret_cast<long long*>(scratch + 4096);
+  char* const scratch = patch0 + 2 * PB;                       // 1 KiB: destination of the zero-traffic slot loads
+  long long* s_opix = reinterpret_cast<long long*>(scratch + 1024);
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(p.w) + (size_t)(phase * p.Cout_pad + co0) * p.Kpad * 2, 0, BC * p.Kpad * 2, 0x00020000);
@@ -1132,18 +1136,21 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
       a_voff[t] = (unsigned)(r * p.Kpad * 2 + lc * 16);
     }
   }
-  unsigned p_voff[NPWW_MAX];      // patch pixel rows of 128 B: 8 lanes per pixel, chunk position XOR (pixel & 7)
+  // patch swizzle: the 16-byte chunk q of patch pixel r sits at position q ^ pswz(r) of its row (bank-conflict-free
+  // fragment reads: 16 consecutive pixels of a tile row hit 16 different bank groups)
+  auto pswz = [](int r) { return CCH == 64 ? (r & 7) : ((r >> 2) & 3); };
+  unsigned p_voff[NPWW_MAX];      // patch pixel rows of ROWB bytes: LPP lanes per pixel
   {
-    const int ppl = lane >> 3, pos = lane & 7;
+    const int ppl = lane / LPP, pos = lane % LPP;
 #pragma unroll
     for (int t = 0; t < NPWW_MAX; ++t) {
-      const int pp = (t * NW + wave) * 8 + ppl;
+      const int pp = (t * NW + wave) * PPW + ppl;
       unsigned v = kOOB;
       if (pp < p.h_npix) {
         const int pr = pp / PW, pc = pp - pr * PW;
         const int iy = iy_org + pr, ix = ix_org + pc;
         if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-          v = (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff) * 2 + ((pos ^ (pp & 7)) << 4));
+          v = (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff) * 2 + ((pos ^ pswz(pp)) << 4));
       }
       p_voff[t] = v;
     }
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int kc = p.kc;                       // 32-channel slices per tap
-  const int nfull = kc >> 1, half = kc & 1;  // full 64-channel chunks, trailing 32-channel chunk
+  const int nfull = kc / NSLM, half = kc % NSLM;   // regular chunks; trailing 32-channel chunk (CCH == 64 only)
   const int cin_b = p.kc * BKB;              // bytes of one tap's K-run in the packed weight row
 
   auto load_a = [&](auto slot_c, bool live, int soff) {
@@ -1193,10 +1200,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int t = decltype(t_c)::value;
     if constexpr (t < NPWW_MAX) {
       const bool on = live && t < npww;
-      char* dst = on ? patch0 + buf * PB + (t * NW + wave) * 1024 : scratch + wave * 1024;
+      char* dst = on ? patch0 + buf * PB + (t * NW + wave) * 1024 : scratch;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)dst, 16, on ? p_voff[t] : kOOB, on ? soff : 0, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(scratch + wave * 1024), 16, kOOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)scratch, 16, kOOB, 0, 0, 0);
     }
   };
 
@@ -1208,13 +1215,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
   // weight offset of global K-step (chunk c, step st) for chunk kind NSL
   auto a_soff_of = [&](int c, int st, int nsl) {
     const int tap = nsl == 2 ? st >> 1 : st, sl = nsl == 2 ? st & 1 : 0;
-    return tap * cin_b + c * 128 + sl * 64;
+    return tap * cin_b + c * ROWB + sl * 64;
   };
   const int total_steps = NTAPS * kc;
   static_for<S - 1>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     load_patch(std::integral_constant<int, NPWW_MAX>{}, false, 0, 0);   // slot (nothing to prefetch yet)
-    load_a(sc, s < total_steps, a_soff_of(0, s, one_half_only ? 1 : 2));
+    load_a(sc, s < total_steps, a_soff_of(0, s, one_half_only ? 1 : NSLM));
   });
   __syncthreads();                           // s_opix visible (also orders nothing else: LDS-DMA uses vmcnt)
 
@@ -1241,8 +1248,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
       for (int j = 0; j < MT_P; ++j) {
         const int r = r0[j] + trow;
-        const int lsw = lhi ^ (r & 7);
-        const char* rowp = pbuf + r * 128;
+        const int lsw = lhi ^ pswz(r);
+        const char* rowp = pbuf + r * ROWB;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           fb[kk][j] = *reinterpret_cast<const uint4_t*>(rowp + ((lsw ^ (sl * 4 + kk * 2)) << 4));
@@ -1256,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk][i]),
                                                            __builtin_bit_cast(half8_t, fb[kk][j]), acc[i][j], 0, 0, 0);
         if constexpr (m == 0) {
-          load_patch(std::integral_constant<int, (st < NPWW_MAX ? st : NPWW_MAX)>{}, has_next, (c + 1) & 1, (c + 1) * 128);
+          load_patch(std::integral_constant<int, (st < NPWW_MAX ? st : NPWW_MAX)>{}, has_next, (c + 1) & 1, (c + 1) * ROWB);
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (m == 1 || (NM == 2 && m == 1)) {
@@ -1270,13 +1277,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
       });
     });
   };
-  using two = std::integral_constant<int, 2>;
+  using regular = std::integral_constant<int, NSLM>;
   using one = std::integral_constant<int, 1>;
   for (int c = 0; c < nfull; ++c) {
     const bool last_full = c + 1 == nfull;
-    chunk_body(two{}, c, !last_full || half, last_full ? 1 : 2);
+    chunk_body(regular{}, c, !last_full || half, last_full && half ? 1 : NSLM);
   }
-  if (half) chunk_body(one{}, nfull, false, 1);
+  if constexpr (NSLM == 2) {
+    if (half) chunk_body(one{}, nfull, false, 1);
+  }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1547,9 +1556,12 @@ static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
 constexpr int kHintWideShift = 28;   // tile_hint bits 28-29: wide-K level w, BKB = 64 << w
 
 // Tile variants the dma kernel is instantiated for (ft_conv_tile_candidates / ft_conv_desc.tile_hint).
-template <int BC, int TW, int NTAPS, int KW, int S>
+#ifndef FT_HALO_CCH
+#define FT_HALO_CCH 32   // channels per resident patch chunk of the 3x3 variant (same-box A/B vs 64: +2.4 % R50, +0.8 % FlowNet2S)
+#endif
+template <int BC, int TW, int NTAPS, int KW, int S, int CCH>
 static int launch_halo_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
-  auto k = conv_halo_kernel<BC, TW, NTAPS, KW, S>;
+  auto k = conv_halo_kernel<BC, TW, NTAPS, KW, S, CCH>;
   if (lds > 64 * 1024) {
     static thread_local bool raised = false;
     if (!raised) {
@@ -1571,11 +1583,14 @@ static int launch_halo(ConvParams p, const ft_conv_desc* d, const Geometry& g, i
   p.h_tx = ceil_div(Wq, tw);
   p.h_pw = tw + kq - 1;
   p.h_npix = (th + kq - 1) * p.h_pw;
-  p.h_npww = ceil_div(ceil_div(p.h_npix, 8), 4);
+  // 3x3: 32-channel patch chunks (49 KiB of LDS = 3 workgroups per CU; 9 K-steps per chunk on a 3-slot weight ring);
+  // transposed phases: 64-channel chunks (8 K-steps per chunk on a 4-slot ring)
+  const int cch = d->transposed ? 64 : FT_HALO_CCH;
+  p.h_npww = ceil_div(ceil_div(p.h_npix, 1024 / (cch * 2)), 4);
   if (p.h_npww > (d->transposed ? 5 : 6)) return FT_ERR_UNSUPPORTED;
   p.h_pb = p.h_npww * 4 * 1024;
   const int S = d->transposed ? 4 : 3;
-  const size_t lds = (size_t)S * bc * 64 + 2 * (size_t)p.h_pb + 4096 + 128 * 8;
+  const size_t lds = (size_t)S * bc * 64 + 2 * (size_t)p.h_pb + 1024 + 128 * 8;
   const int N = p.M / p.HqWq;
   p.npt = N * p.h_ty * p.h_tx;
   p.nct = g.cout_pad / bc;
@@ -1583,11 +1598,11 @@ static int launch_halo(ConvParams p, const ft_conv_desc* d, const Geometry& g, i
   dim3 grid(p.npt * p.nct * p.nph);
   int rc;
   if (d->transposed) {
-    if (bc == 128) rc = tw == 16 ? launch_halo_k<128, 16, 4, 2, 4>(p, grid, lds, s) : launch_halo_k<128, 8, 4, 2, 4>(p, grid, lds, s);
-    else rc = tw == 16 ? launch_halo_k<64, 16, 4, 2, 4>(p, grid, lds, s) : launch_halo_k<64, 8, 4, 2, 4>(p, grid, lds, s);
+    if (bc == 128) rc = tw == 16 ? launch_halo_k<128, 16, 4, 2, 4, 64>(p, grid, lds, s) : launch_halo_k<128, 8, 4, 2, 4, 64>(p, grid, lds, s);
+    else rc = tw == 16 ? launch_halo_k<64, 16, 4, 2, 4, 64>(p, grid, lds, s) : launch_halo_k<64, 8, 4, 2, 4, 64>(p, grid, lds, s);
   } else {
-    if (bc == 128) rc = tw == 16 ? launch_halo_k<128, 16, 9, 3, 3>(p, grid, lds, s) : launch_halo_k<128, 8, 9, 3, 3>(p, grid, lds, s);
-    else rc = tw == 16 ? launch_halo_k<64, 16, 9, 3, 3>(p, grid, lds, s) : launch_halo_k<64, 8, 9, 3, 3>(p, grid, lds, s);
+    if (bc == 128) rc = tw == 16 ? launch_halo_k<128, 16, 9, 3, 3, FT_HALO_CCH>(p, grid, lds, s) : launch_halo_k<128, 8, 9, 3, 3, FT_HALO_CCH>(p, grid, lds, s);
+    else rc = tw == 16 ? launch_halo_k<64, 16, 9, 3, 3, FT_HALO_CCH>(p, grid, lds, s) : launch_halo_k<64, 8, 9, 3, 3, FT_HALO_CCH>(p, grid, lds, s);
   }
   if (rc != FT_OK) return rc;
   FT_LAUNCH_CHECK("conv_halo_kernel");
@@ -1642,7 +1657,8 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
       if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
   for (const auto& t : kTiles)
     if (n < max && tile_valid(d, g, t[0], t[1], 1, 1)) hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (1 << kHintWideShift);
-  for (int bc = 128; bc >= 64; bc >>= 1)
+  static const bool no_halo = getenv("FT_CONV_NO_HALO") != nullptr;   // dev: A/B the tile benchmark without the halo variants
+  for (int bc = 128; bc >= 64 && !no_halo; bc >>= 1)
     if (n < max && tile_valid(d, g, 128, bc, 1, 0, true)) hints[n++] = 128 | (bc << 12) | (1 << 24) | kHintHalo;
   return n;
 }
