@@ -1293,6 +1293,165 @@ __global__ __launch_bounds__(256, (CCH == 32 ? 3 : 2)) void conv_halo_kernel(con
 #endif
 }
 
+// ---- stem path (fp16): row-packed small-Cin convs (7x7/s2 on 3/6/12 channels, 3x3/s1 on 6/11) -> 64 channels ----
+// The input (physically x-padded NHWC, 4/8/16 channels per pixel) is so thin that an 8x16 output patch needs only
+// 6-26 KiB of it: the patch is loaded ONCE into LDS and every kernel row's pixel operand is a contiguous 16-byte read
+// from it (the taps of one kernel row ARE contiguous in a row-packed row).  Only the weight rows stream (one K-step
+// per kernel row).  The layer becomes HBM-bound (read the frame once, write the 64-channel map once) instead of
+// re-reading each input row kh times through L2 -> LDS.
+template <int KH, int STRIDE, int RUNB, int NT>
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = half_t;
+  constexpr int BP = 128, BC = 64, TW = 16, TH = 8, NW = 4, WGP = 2, WGC = 2;
+  constexpr int WT_P = BP / WGP, MT_P = WT_P / 32, MT_C = 1;
+  constexpr int S = 3, A_STAGE = BC * RUNB;
+  constexpr int CH = RUNB / 16, SWZ_DIV = 256 / RUNB >= 1 ? 256 / RUNB : 1, RPI = 64 / CH;
+  constexpr int NIA = BC / RPI / NW;          // weight wave-loads per wave per kernel row
+  constexpr int G = RUNB / 32;                // MFMA k-groups (16 halfs) per kernel row
+  constexpr int PH = (TH - 1) * STRIDE + KH;  // input rows of the patch
+  constexpr int NPLW_MAX = 12;
+  constexpr int TWS = TW * NT;                // output columns of the super-tile: NT tiles of 16 share one pass over the weights
+  static_assert(RUNB == 64 || RUNB == 128 || RUNB == 256, "bytes of one packed kernel row");
+  static_assert(NIA >= 1, "weight rows must split over the waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave % WGP, wc = wave / WGP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int ptile;
+  {
+    const int total = p.npt;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    ptile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tiles_per_img = p.h_ty * p.h_tx;
+  const int n = ptile / tiles_per_img;
+  const int trem = ptile - n * tiles_per_img;
+  const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+  const int oy0 = tyi * TH, ox0 = txi * TWS;
+  const int cpb = p.x_cstride * 2;                       // bytes per input pixel
+  const int CPR = p.h_pw;                                // 16-byte chunks per patch row
+  const int RBp = CPR * 16;                              // patch row pitch in LDS
+  const int iy_org = oy0 * STRIDE - p.pad;
+  const int col0 = ox0 * STRIDE - p.pad_x;               // physical column of the patch's first pixel (>= 0)
+
+  char* const ring = smem;
+  char* const patch = smem + S * A_STAGE;
+  long long* s_opix = reinterpret_cast<long long*>(patch + p.h_pb);
+
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, BC * p.Kpad * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- the whole input patch: PH rows of CPR 16-byte chunks, lane-linear (row-major) in LDS ---------------
+  const int nchunks = PH * CPR;
+#pragma unroll
+  for (int t = 0; t < NPLW_MAX; ++t) {
+    if (t < p.h_npww) {
+      const int gci = (t * NW + wave) * 64 + lane;
+      const int row = gci / CPR, ch = gci - row * CPR;
+      const int iy = iy_org + row;
+      unsigned v = kOOB;
+      if (gci < nchunks && (unsigned)iy < (unsigned)p.Hi)
+        v = (unsigned)(((n * p.Hi + iy) * p.Wi + col0) * cpb + ch * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(patch + (t * NW + wave) * 1024), 16, v, 0, 0, 0);
+    }
+  }
+  // ---- weight rows: [64 co][RUNB] tiles, XOR-swizzled on the source side as in the dma kernel ----------------
+  unsigned a_voff[NIA];
+  {
+    const int lrow = lane / CH, pos = lane % CH;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t) {
+      const int r = (wave + NW * t) * RPI + lrow;
+      const int lc = pos ^ ((r / SWZ_DIV) % CH);
+      a_voff[t] = (unsigned)(r * p.Kpad * 2 + lc * 16);
+    }
+  }
+  auto load_a = [&](auto slot_c, bool live, int ky) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(ring + slot * A_STAGE + (wave + NW * t) * 1024), 16,
+                                               live ? a_voff[t] : kOOB, live ? ky * RUNB : 0, 0, 0);
+  };
+  static_for<S - 1>([&](auto sc) { load_a(sc, decltype(sc)::value < KH, decltype(sc)::value); });
+
+  // fragment offsets
+  const int r_a = wc * 32 + l31;
+  const int a_off = r_a * RUNB + ((lhi ^ ((r_a / SWZ_DIV) % CH)) << 4);
+  int b_off[MT_P];              // tile 0; tile t adds t * 16 * STRIDE * cpb
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j) {
+    const int m = wp * WT_P + j * 32 + l31;
+    b_off[j] = (m / TW) * STRIDE * RBp + (m % TW) * STRIDE * cpb + lhi * 16;
+  }
+  const int tile_step = TW * STRIDE * cpb;
+  for (int idx = tid; idx < BP * NT; idx += 256) {
+    const int t = idx / BP, m = idx % BP;
+    const int oy = oy0 + m / TW, ox = ox0 + t * TW + m % TW;
+    long long o = -1;
+    if (oy < p.Ho && ox < p.Wo) o = ((long long)n * p.Ho + oy) * p.Wo + ox;
+    s_opix[idx] = o;
+  }
+
+  float16_t acc[NT][MT_C][MT_P];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < MT_P; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][0][j][r] = 0.f;
+
+  static_for<KH>([&](auto ky_c) {
+    constexpr int ky = decltype(ky_c)::value;
+    constexpr int slot = ky % S, nslot = (ky + S - 1) % S;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA * (S - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    load_a(std::integral_constant<int, nslot>{}, ky + S - 1 < KH, ky + S - 1);
+    const char* sa = ring + slot * A_STAGE;
+    const char* pb = patch + ky * RBp;
+    constexpr int GB = G > 2 ? 2 : G;       // k-groups per register batch
+    static_for<G / GB>([&](auto gb_c) {
+      constexpr int g0 = decltype(gb_c)::value * GB;
+      uint4_t fa[GB];
+#pragma unroll
+      for (int g = 0; g < GB; ++g) fa[g] = *reinterpret_cast<const uint4_t*>(sa + (a_off ^ ((g0 + g) << 5)));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        uint4_t fb[GB][MT_P];
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+#pragma unroll
+          for (int j = 0; j < MT_P; ++j)
+            fb[g][j] = *reinterpret_cast<const uint4_t*>(pb + b_off[j] + t * tile_step + (g0 + g) * 32);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+#pragma unroll
+          for (int j = 0; j < MT_P; ++j)
+            acc[t][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[g]),
+                                                                  __builtin_bit_cast(half8_t, fb[g][j]), acc[t][0][j], 0, 0, 0);
+      }
+    });
+  });
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int opix_off = (int)(reinterpret_cast<char*>(s_opix) - smem);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    conv_epilogue<T, BP, BC, WGP, WGC, true>(p, acc[t], smem, opix_off + t * BP * 8, 0, 0, 0, 0, nullptr);
+    if (t + 1 < NT) __syncthreads();          // the next tile reuses the LDS output tile
+  }
+#endif
+}
+
 // ---- few-output-channel conv (FlowNet predict_flow: Cout = 2, K up to 9 * 1026) -----------------------
 // A GEMM tile would leave 30/32 MFMA columns idle and serialise a 9k-long K loop in a handful of
 // workgroups.  Instead: one wave per group of PIX consecutive output pixels, the 64 lanes split the
@@ -1573,7 +1732,62 @@ static int launch_halo_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t
   return FT_OK;
 }
 
+template <int KH, int STRIDE, int RUNB, int NT>
+static int launch_stem_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
+  auto k = conv_stem_kernel<KH, STRIDE, RUNB, NT>;
+  if (lds > 64 * 1024) {
+    static thread_local bool raised = false;
+    if (!raised) {
+      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+  return FT_OK;
+}
+
+template <int KH, int STRIDE, int RUNB>
+static int launch_stem_nt(const ConvParams& p, int nt, dim3 grid, size_t lds, hipStream_t s) {
+  if (nt == 2) return launch_stem_k<KH, STRIDE, RUNB, 2>(p, grid, lds, s);
+  return launch_stem_k<KH, STRIDE, RUNB, 1>(p, grid, lds, s);
+}
+
+static int launch_stem(ConvParams p, const ft_conv_desc* d, const Geometry& g, hipStream_t s) {
+  const int runb = g.cin_pad * 2, cpb = d->x_cstride * 2;
+  const int ph = 7 * d->stride + d->kh;
+  // super-tile = nt tiles of 8x16 outputs side by side share one pass over the weights.  Measured (in situ, us):
+  // pose stem (64-byte rows) nt 1/2/4 = 47.5 / 53.6 / 73; FlowNet stem (128-byte rows) 72.2 / 67.6 / 81.4
+  static const int force_nt = getenv("FT_STEM_NT") ? atoi(getenv("FT_STEM_NT")) : 0;   // dev knob (1 or 2)
+  int nt = force_nt == 1 || force_nt == 2 ? force_nt : (runb >= 128 ? 2 : 1);
+  if (nt == 2 && ((ceil_div(d->Wo, 32) * 32 - d->Wo) * 100 / d->Wo >= 10 || ph * round_up(31 * d->stride * cpb + runb, 16) > 56 * 1024))
+    nt = 1;
+  const int tws = 16 * nt;
+  const int rb = (tws - 1) * d->stride * cpb + runb;     // bytes of one patch row
+  p.h_pw = ceil_div(rb, 16);
+  p.h_npww = ceil_div(ceil_div(ph * p.h_pw, 64), 4);
+  if (p.h_npww > 12) return FT_ERR_UNSUPPORTED;
+  p.h_pb = p.h_npww * 4 * 1024;
+  p.h_ty = ceil_div(d->Ho, 8);
+  p.h_tx = ceil_div(d->Wo, tws);
+  p.npt = d->N * p.h_ty * p.h_tx;
+  p.nct = 1;
+  const size_t ring = (size_t)3 * 64 * runb;
+  if (ring + p.h_pb < 16384) p.h_pb = 16384 - (int)ring;  // the epilogue's 16 KiB output tile must not reach the row table
+  const size_t lds = ring + p.h_pb + (size_t)nt * 128 * 8;
+  dim3 grid(p.npt);
+  int rc;
+  if (d->kh == 7)
+    rc = runb == 64 ? launch_stem_nt<7, 2, 64>(p, nt, grid, lds, s) : runb == 128 ? launch_stem_nt<7, 2, 128>(p, nt, grid, lds, s)
+                                                                                  : launch_stem_nt<7, 2, 256>(p, nt, grid, lds, s);
+  else
+    rc = runb == 64 ? launch_stem_nt<3, 1, 64>(p, nt, grid, lds, s) : launch_stem_nt<3, 1, 128>(p, nt, grid, lds, s);
+  if (rc != FT_OK) return rc;
+  FT_LAUNCH_CHECK("conv_stem_kernel");
+  return FT_OK;
+}
+
 static int launch_halo(ConvParams p, const ft_conv_desc* d, const Geometry& g, int bc, hipStream_t s) {
+  if (g.rowpack) return launch_stem(p, d, g, s);
   const int Hq = p.HqWq / p.Wq, Wq = p.Wq;
   const int kq = d->transposed ? 2 : 3;                      // taps per dimension of one phase
   // patch shape 8x16 or 16x8 output pixels: the one that wastes fewer pixels on this image size
@@ -1613,15 +1827,25 @@ constexpr int kHintHalo = 1 << 30;   // tile_hint bit 30: LDS-resident input pat
 
 // conv_halo_kernel: fp16, 3x3 / stride 1 or the 2x2-tap phases of ConvTranspose2d(4,2,1), NHWC fp16 8-aligned output,
 // no residual, channel-aligned (dma) weight layout
+static bool stem_ok(const ft_conv_desc* d, const Geometry& g) {
+  if (!g.rowpack || d->dtype != FT_F16 || d->has_residual || d->Cout != 64 || d->x_coff != 0) return false;
+  if (!((d->kh == 7 && d->stride == 2) || (d->kh == 3 && d->stride == 1))) return false;
+  const int runb = g.cin_pad * 2;
+  if (!(runb == 64 || runb == 128 || (runb == 256 && d->kh == 7))) return false;
+  if ((d->stride * d->x_cstride * 2) % 16 != 0 || d->pad - d->x_lpad > 0) return false;   // 16-byte aligned pixel steps
+  return d->out_layout == FT_LAYOUT_NHWC && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0;
+}
+
 static bool halo_ok(const ft_conv_desc* d, const Geometry& g) {
-  if (!g.dma || g.rowpack || d->dtype != FT_F16 || d->has_residual) return false;
+  if (g.rowpack) return stem_ok(d, g);
+  if (!g.dma || d->dtype != FT_F16 || d->has_residual) return false;
   if (!(d->transposed || (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1))) return false;
   return d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0;
 }
 
 static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0, bool halo = false) {
   if (!g.dma) return false;
-  if (halo) return halo_ok(d, g) && bp == 128 && (bc == 64 || bc == 128) && g.cout_pad % bc == 0 && ks == 1 && wide == 0;
+  if (halo) return halo_ok(d, g) && bp == 128 && (bc == 64 || (bc == 128 && !g.rowpack)) && g.cout_pad % bc == 0 && ks == 1 && wide == 0;
   if (wide < 0 || wide > 1) return false;   // (BKB = 256 was benchmarked too: never the fastest on any layer)
   if (wide && !(d->dtype == FT_F16 && g.kc % (1 << wide) == 0)) return false;
   if (wide && ks > 1) return false;         // (wide + split-K likewise)

@@ -18,6 +18,7 @@ def view_to_nchw(v: ActView) -> torch.Tensor:
 
 
 def run_program(prog: Program):
+    torch.cuda.synchronize()      # buffers were filled on torch's current stream; the program runs on its own
     prog.run_eager()
     prog.stream.synchronize()
 
