@@ -1577,6 +1577,148 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvParams p, in
 // ---- host side ---------------------------------------------------------------------------------
 constexpr int kBKB = 64;       // generic kernel: bytes of K per tile row per step
 constexpr int kBP = 128;       // generic kernel: pixel tile
+// ---- predict_flow path (fp16): 3x3/s1/p1 conv to <= 2 output channels from an LDS-resident input patch ------
+// The few-output kernel above re-reads each input pixel for its 9 taps from L2; at 96x128 x 224 channels that is
+// ~0.8 GB of L2 traffic for 88 MB of input.  Here a workgroup owns an 8x16 (or 16x8) output patch: the 10x18 input
+// patch of a 64-channel chunk is DMA'd once into LDS (double-buffered over chunks, XOR-swizzled like the halo
+// kernel), thread (pixel, channel half) accumulates both outputs with v_dot2_f32_f16 against weights read as LDS
+// broadcasts, and the two channel halves are summed through LDS.  Uses the generic packed layout [Cout_pad][Kpad].
+template <int TW>
+__global__ __launch_bounds__(256, 3) void conv_pflow_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BP = 128, TH = BP / TW, NW = 4;
+  constexpr int PW = TW + 2, NPIX = (TH + 2) * PW;
+  constexpr int NPWW = (NPIX + 31) / 32;                 // patch wave-loads per wave per chunk (8 pixels per load, 4 waves)
+  constexpr int PB = NPWW * NW * 1024;
+  constexpr int WB = 9 * 2 * 128;                        // weights of one chunk: [tap][co][64 ch] fp16
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* const patch0 = smem;
+  char* const wts0 = smem + 2 * PB;
+  float* const red = reinterpret_cast<float*>(wts0 + 2 * WB);
+
+  int ptile;
+  {
+    const int total = p.npt;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    ptile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tiles_per_img = p.h_ty * p.h_tx;
+  const int n = ptile / tiles_per_img;
+  const int trem = ptile - n * tiles_per_img;
+  const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+  const int qy0 = tyi * TH, qx0 = txi * TW;
+  const int iy_org = qy0 - 1, ix_org = qx0 - 1;
+
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+  unsigned p_voff[NPWW];
+  {
+    const int ppl = lane >> 3, pos = lane & 7;
+#pragma unroll
+    for (int t = 0; t < NPWW; ++t) {
+      const int pp = (t * NW + wave) * 8 + ppl;
+      unsigned v = kOOB;
+      if (pp < NPIX) {
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = iy_org + pr, ix = ix_org + pc;
+        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+          v = (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff) * 2 + ((pos ^ (pp & 7)) << 4));
+      }
+      p_voff[t] = v;
+    }
+  }
+  const int nchunks = (p.cin_groups + 7) >> 3;           // 64-channel chunks (cin_groups = 8-channel groups)
+  const int cin8 = p.cin_groups * 8;
+  auto load_patch = [&](int c) {
+#pragma unroll
+    for (int t = 0; t < NPWW; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(patch0 + (c & 1) * PB + (t * NW + wave) * 1024), 16, p_voff[t],
+                                               c * 128, 0, 0);
+  };
+  // weights of a chunk: 18 (tap, co) rows of 8 x 16 bytes; threads 0..143 carry one piece each
+  const int w_tapco = tid >> 3, w_piece = tid & 7;
+  const bool w_thread = tid < 144;
+  auto fetch_w = [&](int c) {
+    uint4_t v = {0u, 0u, 0u, 0u};
+    const int cg = c * 8 + w_piece, tap = w_tapco >> 1, co = w_tapco & 1;
+    if (w_thread && cg < p.cin_groups && co < p.Cout)
+      v = *reinterpret_cast<const uint4_t*>(p.w + ((size_t)co * p.Kpad + (size_t)tap * cin8 + cg * 8) * 2);
+    return v;
+  };
+  auto store_w = [&](int c, const uint4_t& v) {
+    if (w_thread) *reinterpret_cast<uint4_t*>(wts0 + (c & 1) * WB + w_tapco * 128 + w_piece * 16) = v;
+  };
+
+  const int m = tid & (BP - 1), half = tid >> 7;        // pixel of the patch, channel half of the chunk (wave-uniform)
+  const int r0 = (m / TW) * PW + (m % TW);
+  float acc0 = 0.f, acc1 = 0.f;
+
+  load_patch(0);
+  store_w(0, fetch_w(0));
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint4_t wnext = {0u, 0u, 0u, 0u};
+    const bool more = c + 1 < nchunks;
+    if (more) {
+      load_patch(c + 1);
+      wnext = fetch_w(c + 1);
+    }
+    const char* pb = patch0 + (c & 1) * PB;
+    const char* wb = wts0 + (c & 1) * WB + half * 64;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {     // not unrolled: the scheduler would hoist all 108 fragment reads and spill
+      const int r = r0 + (tap / 3) * PW + (tap % 3);
+      const char* rowp = pb + r * 128;
+      const int sw = r & 7;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint4_t xv = *reinterpret_cast<const uint4_t*>(rowp + (((half * 4 + k) ^ sw) << 4));
+        const uint4_t w0 = *reinterpret_cast<const uint4_t*>(wb + (tap * 2 + 0) * 128 + k * 16);
+        const uint4_t w1 = *reinterpret_cast<const uint4_t*>(wb + (tap * 2 + 1) * 128 + k * 16);
+        acc0 = dot8(xv, w0, acc0, (half_t*)nullptr);
+        acc1 = dot8(xv, w1, acc1, (half_t*)nullptr);
+      }
+    }
+    if (more) store_w(c + 1, wnext);
+  }
+  // sum the two channel halves, then bias / activation and the store
+  if (half == 1) {
+    red[m * 2] = acc0;
+    red[m * 2 + 1] = acc1;
+  }
+  __syncthreads();
+  if (half == 0) {
+    const int oy = qy0 + m / TW, ox = qx0 + m % TW;
+    if (oy < p.Ho && ox < p.Wo) {
+      float v[2] = {acc0 + red[m * 2], acc1 + red[m * 2 + 1]};
+#pragma unroll
+      for (int co = 0; co < 2; ++co) {
+        if (co < p.Cout) {
+          if (p.scale) v[co] *= p.scale[co];
+          if (p.shift) v[co] += p.shift[co];
+          v[co] = apply_act(v[co], p.act, p.slope);
+        }
+      }
+      if (p.out_layout == FT_LAYOUT_NHWC) {
+        half_t* yp = reinterpret_cast<half_t*>(p.y) + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.y_cstride + p.y_coff;
+        yp[0] = (half_t)v[0];
+        if (p.Cout > 1) yp[1] = (half_t)v[1];
+      } else {
+        float* yp = reinterpret_cast<float*>(p.y);
+        const size_t hw = (size_t)p.Ho * p.Wo, pix = (size_t)oy * p.Wo + ox;
+        yp[((size_t)n * p.Cout) * hw + pix] = v[0];
+        if (p.Cout > 1) yp[((size_t)n * p.Cout + 1) * hw + pix] = v[1];
+      }
+    }
+  }
+#endif
+}
+
 constexpr int kDmaBKB = FT_DMA_BKB;        // dma kernel: bytes of K per tile row per step (64 -> 32 fp16 / 16 fp32 channels)
 constexpr int kDmaStages = FT_DMA_STAGES;  // dma kernel: LDS ring depth
 
@@ -2085,6 +2227,27 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   }
   if (g.dma) return FT_ERR_UNSUPPORTED;  // packed for the dma layout but the activation buffer is >= 2 GiB
 
+  static const bool no_pflow = getenv("FT_CONV_NO_PFLOW") != nullptr;   // dev: A/B against the few-output kernel
+  if (!no_pflow && !d->transposed && d->Cout <= 2 && d->dtype == FT_F16 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
+      d->pad == 1 && !d->has_residual && d->x_wpitch == 0 && d->x_cstride % 8 == 0 && d->x_coff % 8 == 0 && x_bytes < (1ull << 31)) {
+    p.x_bytes = (unsigned)x_bytes;
+    const long long t16 = (long long)ceil_div(d->Ho, 8) * ceil_div(d->Wo, 16), t8 = (long long)ceil_div(d->Ho, 16) * ceil_div(d->Wo, 8);
+    const int tw = t16 <= t8 ? 16 : 8, th = 128 / tw;
+    p.h_ty = ceil_div(d->Ho, th);
+    p.h_tx = ceil_div(d->Wo, tw);
+    p.npt = d->N * p.h_ty * p.h_tx;
+    // one patch per workgroup walks ALL channels serially: only worth it with at least one patch per CU (measured on
+    // FlowNet2S: predict_flow2/3 75 -> 49 us, 37 -> 28 us; the deep low-resolution predict_flow4..6 stay on the
+    // few-output kernel below, which splits K over the lanes)
+    if (p.npt >= 256) {
+      const size_t lds = 2 * (size_t)6 * 4 * 1024 + 2 * 9 * 2 * 128 + 128 * 2 * 4;
+      dim3 grid(p.npt);
+      if (tw == 16) hipLaunchKernelGGL(conv_pflow_kernel<16>, grid, dim3(256), lds, s, p);
+      else hipLaunchKernelGGL(conv_pflow_kernel<8>, grid, dim3(256), lds, s, p);
+      FT_LAUNCH_CHECK("conv_pflow_kernel");
+      return FT_OK;
+    }
+  }
   if (!d->transposed && d->Cout <= 4) {
     const int nco = d->Cout <= 2 ? 2 : 4;
     const size_t lds = (size_t)nco * g.ntaps * g.cin_groups * 16;

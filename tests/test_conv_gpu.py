@@ -38,6 +38,9 @@ CASES = [
     ("1x1_cin2048", 3, 2048, 8, 6, 512, 1, 1, 0, False, False, True, "relu", False),
     ("deconv_770_cout128", 1, 770, 6, 8, 128, 4, 2, 1, True, True, False, "leaky", False),
     ("predict_flow_cin1026", 2, 1026, 6, 8, 2, 3, 1, 1, False, True, False, None, False),
+    # >= 256 patches of 8x16: the LDS-patch predict_flow kernel (conv_pflow_kernel), 3.03 chunks of 64 channels / ragged, Cout 1
+    ("predict_flow_patch_cin194", 4, 194, 64, 128, 2, 3, 1, 1, False, True, False, None, False),
+    ("predict_flow_patch_ragged_cout1", 3, 40, 70, 150, 1, 3, 1, 1, False, True, False, "leaky", False),
     ("fewout_cout3_5x5_s2", 1, 40, 11, 9, 3, 5, 2, 2, False, True, False, "leaky", False),
     ("fewout_cout4_1x1_res", 2, 64, 7, 5, 4, 1, 1, 0, False, False, True, "relu", True),
 ]
