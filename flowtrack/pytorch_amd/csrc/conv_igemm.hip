@@ -1794,8 +1794,12 @@ static int geometry(const ft_conv_desc* d, Geometry* g) {
   }
   const int cin_bk = round_up(d->Cin, bk);
   const long long wbytes = (long long)128 * g->ntaps * cin_bk * esz;  // one co tile of packed weights
-  static const int dma_min_cout = getenv("FT_CONV_DMA_MIN_COUT") ? atoi(getenv("FT_CONV_DMA_MIN_COUT")) : 33;  // dev knob
-  g->dma = d->Cout >= dma_min_cout && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
+  // Cout <= 32 runs on the generic kernel (a 64-wide channel tile would idle half of it) — except 3x3/s1 layers with
+  // 16..32 outputs at high resolution (FlowNetFusion inter_conv0/1): channel-aligned layout + LDS-patch (halo) kernel
+  // cut their operand traffic so much that the idle half does not matter (inter_conv1: 680 -> 324 us before the patch)
+  // (the transposed 16..32-output layers were tried too: fusion deconv0 578 -> 514 us, deconv1 91 -> 103 us: left alone)
+  const bool small_3x3 = d->Cout >= 16 && !d->transposed && d->kh == 3 && d->kw == 3 && d->stride == 1;
+  g->dma = (d->Cout > 32 || small_3x3) && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
   if (g->dma) {
     g->cin_pad = cin_bk;
     g->cout_pad = round_up(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
