@@ -131,9 +131,12 @@ class Program:
         check(st, "ft_graph_end_capture")
         self.graph_exec = exec_
 
-    def run(self) -> None:
+    def run(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Replay the captured graph on `stream` (default: the program's own stream; a graph may be launched on any
+        stream, only the capture needed a private one), or run eagerly on the program's stream if not captured."""
         if self.graph_exec is not None:
-            check(self.lib.ft_graph_launch(self.graph_exec, self.stream_handle), "ft_graph_launch")
+            sh = self.stream_handle if stream is None else ctypes.c_void_p(stream.cuda_stream)
+            check(self.lib.ft_graph_launch(self.graph_exec, sh), "ft_graph_launch")
         else:
             self.run_eager()
 
