@@ -459,6 +459,11 @@ class _FlowBase(HipModule):
             self._plans[key] = plan
         return plan
 
+    def static_input(self, B: int, H: int, W: int) -> torch.Tensor:
+        """The plan's own input buffer [B,3,2,H,W] fp32 (the fixed address its graph reads): write the batch here and
+        pass this tensor to forward() to skip the staging copy (75 MB at 16 x 512x384)."""
+        return self.plan_for(B, H, W).x_static
+
     @torch.no_grad()
     def forward(self, inputs: torch.Tensor, copy_output: bool = True) -> torch.Tensor:
         """inputs [B,3,2,H,W] (RGB, 0..rgb_max) -> flow [B,2,H,W] fp32 in pixels."""
@@ -469,7 +474,8 @@ class _FlowBase(HipModule):
         plan = self.plan_for(B, H, W)
         if inputs.device != plan.x_static.device:
             raise FlowtrackHipError("input and model are on different devices")
-        plan.x_static.copy_(inputs)
+        if inputs.data_ptr() != plan.x_static.data_ptr():   # zero-copy when the caller filled static_input() in place
+            plan.x_static.copy_(inputs)
         self._run_plan(plan.prog, first=plan.runs == 0)
         plan.runs += 1
         return plan.out.clone() if copy_output else plan.out

@@ -90,3 +90,15 @@ def test_flownet2s_batch16_512x384_consistency(hip_lib):
     epe = torch.norm(f16 - f32, dim=1).mean().item()
     mag = torch.norm(f32, dim=1).mean().item()
     assert epe <= 0.02 * max(mag, 1.0) + 0.05, f"fp16 EPE {epe:.4f} px at mean |flow| {mag:.3f}"
+
+
+def test_static_input_binding_is_zero_copy_and_equivalent(hip_lib):
+    """forward(static_input) must give the same heatmaps as forward(a copy of it) — the binding only skips the staging copy."""
+    m = _pose(50, torch.float32)
+    x = synth.pose_crops(SEED + 5, 8).cuda()
+    ref = m(x)
+    buf = m.static_input(8, 256, 192)
+    assert buf.data_ptr() != x.data_ptr()
+    buf.copy_(x)
+    out = m(buf)
+    assert torch.equal(out, ref)
