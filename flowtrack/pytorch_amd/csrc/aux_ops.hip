@@ -167,7 +167,14 @@ __global__ __launch_bounds__(256) void rgb_partial_sum_kernel(const float* __res
   const size_t hi = lo + per < L ? lo + per : L;
   const float* p = x + (size_t)bc * L;
   float s = 0.f;
-  for (size_t i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+  if ((L & 3) == 0 && (per & 3) == 0) {      // 16-byte loads, four independent partial sums per lane
+    float4_t a = {0.f, 0.f, 0.f, 0.f};
+    const float4_t* p4 = reinterpret_cast<const float4_t*>(p);
+    for (size_t i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) a += p4[i];
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   __shared__ float sw[4];
@@ -221,25 +228,33 @@ __global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __rest
 
 // ---- nn.Upsample(scale_factor=4, mode='bilinear'), align_corners=False, times `mul` -------------
 __global__ __launch_bounds__(256) void upsample_bilinear4x_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                  int h, int w, size_t total, float mul) {
-  const int H = 4 * h, W = 4 * w;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % W);
-    const size_t t = i / W;
+                                                                  int h, int w, size_t total4, float mul) {
+  // one thread = 4 consecutive outputs of a row (one 16-byte store): they blend the same three source columns
+  const int H = 4 * h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int jx = (int)(i % w);                 // source column the 4 outputs straddle
+    const size_t t = i / w;
     const int oy = (int)(t % H);
     const size_t nc = t / H;
     float sy = ((float)oy + 0.5f) * 0.25f - 0.5f;
-    float sx = ((float)ox + 0.5f) * 0.25f - 0.5f;
     sy = sy < 0.f ? 0.f : sy;
-    sx = sx < 0.f ? 0.f : sx;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* p = x + nc * (size_t)h * w;
-    const float v00 = p[y0 * w + x0] * mul, v01 = p[y0 * w + x1] * mul;
-    const float v10 = p[y1 * w + x0] * mul, v11 = p[y1 * w + x1] * mul;
-    y[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const float* p0 = x + nc * (size_t)h * w + (size_t)y0 * w;
+    const float* p1 = x + nc * (size_t)h * w + (size_t)y1 * w;
+    float4_t out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sx = ((float)(4 * jx + e) + 0.5f) * 0.25f - 0.5f;
+      sx = sx < 0.f ? 0.f : sx;
+      const int x0 = (int)sx;
+      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = sx - (float)x0, hx = 1.f - lx;
+      const float v00 = p0[x0] * mul, v01 = p0[x1] * mul, v10 = p1[x0] * mul, v11 = p1[x1] * mul;
+      out[e] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+    *reinterpret_cast<float4_t*>(y + i * 4) = out;
   }
 }
 
@@ -393,9 +408,9 @@ extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float r
 extern "C" int ft_upsample_bilinear4x(const float* x, float* y, int N, int C, int h, int w, float mul,
                                       ft_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0) return FT_ERR_INVALID_ARG;
-  const size_t total = (size_t)N * C * 16 * h * w;
-  hipLaunchKernelGGL(upsample_bilinear4x_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, h, w,
-                     total, mul);
+  const size_t total4 = (size_t)N * C * 4 * h * w;    // 16 h w outputs per plane, 4 per thread
+  hipLaunchKernelGGL(upsample_bilinear4x_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, y, h, w,
+                     total4, mul);
   FT_LAUNCH_CHECK("upsample_bilinear4x_kernel");
   return FT_OK;
 }
