@@ -35,6 +35,7 @@ class ConvDesc(ctypes.Structure):
         ("y_cstride", c_int), ("y_coff", c_int), ("out_layout", c_int), ("has_residual", c_int),
         ("res_cstride", c_int), ("res_coff", c_int), ("act", c_int), ("slope", c_float),
         ("x_lpad", c_int), ("x_wpitch", c_int), ("tile_hint", c_int),
+        ("x2_cin", c_int), ("x2_hi", c_int), ("x2_wi", c_int), ("x2_cstride", c_int), ("x2_coff", c_int), ("x2_stride", c_int),
     ]
 
 
@@ -42,7 +43,7 @@ class ConvGeometry(ctypes.Structure):
     """Mirror of `ft_conv_geometry`."""
 
     _fields_ = [("nphases", c_int), ("ntaps", c_int), ("cin_pad", c_int), ("cout_pad", c_int), ("kpad", c_int),
-                ("run_taps", c_int), ("run_cpad", c_int)]
+                ("run_taps", c_int), ("run_cpad", c_int), ("cin2_pad", c_int)]
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)

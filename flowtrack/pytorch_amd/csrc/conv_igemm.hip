@@ -74,6 +74,10 @@ struct ConvParams {
   float slope;
   int npt, nct, nph;  // pixel tiles, output-channel tiles, phases (grid = npt * nct * nph, 1-D)
   int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
+  const char* x2;     // second input (K-concat), or nullptr
+  int kc2;            // its K-steps (0: none)
+  int x2_hi, x2_wi, x2_cstride, x2_coff, x2_stride;
+  unsigned x2_bytes;
   int h_tx, h_ty;     // halo path: patch tiles per image row / column
   int h_pw, h_npix;   // halo path: input-patch width and pixel count
   int h_npww, h_pb;   // halo path: patch wave-loads per wave per chunk, bytes of one patch buffer
@@ -615,6 +619,29 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     b_mask[t] = mask;
   }
 
+  // second input (K-concat): one more K-run per pixel row, read from another tensor at (n, qy * s2, qx * s2)
+  const bool dual = p.kc2 > 0;
+  const __amdgpu_buffer_rsrc_t rsrc_b2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dual ? p.x2 : p.x), 0, dual ? p.x2_bytes : p.x_bytes, 0x00020000);
+  unsigned b2_voff[NIB];
+#pragma unroll
+  for (int t = 0; t < NIB; ++t) {
+    unsigned v = kOOB;
+    if (dual) {
+      const int r = (wave + NW * t) * RPI + lrow;
+      const int lc = pos ^ ((r / SWZ_DIV) % CH);
+      const int m = m0 + r;
+      if (m < p.M) {
+        const int n = m / p.HqWq;
+        const int rem = m - n * p.HqWq;
+        const int qy = rem / p.Wq;
+        const int qx = rem - qy * p.Wq;
+        v = (unsigned)((((n * p.x2_hi + qy * p.x2_stride) * p.x2_wi + qx * p.x2_stride) * p.x2_cstride + p.x2_coff) * esz + lc * 16);
+      }
+    }
+    b2_voff[t] = v;
+  }
+
   // ---- K position of the NEXT stage to issue (wave-uniform, lives in SGPRs) -----------------------------
   int i_ks = ks_begin, i_cc, i_ky, i_kx;
   {
@@ -830,8 +857,14 @@ void conv_igemm_dma_kernel(const ConvParams p) {
         for (int t = 0; t < NIB; ++t) cur_voff[t] = kOOB;
       }
     };
+    int src = 0, kc_cur = p.kc;              // K-run being walked: 0 = the taps of x, 1 = the second input
     if (i_ky < p.kh) refresh();
-    else {
+    else if (dual) {                          // the prologue already consumed all of x's K-run
+      src = 1;
+      kc_cur = p.kc2;
+#pragma unroll
+      for (int t = 0; t < NIB; ++t) cur_voff[t] = b2_voff[t];
+    } else {
 #pragma unroll
       for (int t = 0; t < NIB; ++t) cur_voff[t] = kOOB;
     }
@@ -844,18 +877,26 @@ void conv_igemm_dma_kernel(const ConvParams p) {
                                                  soff_a, 0, 0);
       } else {
         constexpr int u = t - NIA;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(smem + slot * STAGE + A_BYTES + (wave + NW * u) * 1024), 16,
-                                                 cur_voff[u], soff_b, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src ? rsrc_b2 : rsrc_b, (lds_ptr)(smem + slot * STAGE + A_BYTES + (wave + NW * u) * 1024),
+                                                 16, cur_voff[u], soff_b, 0, 0);
       }
     };
     auto advance = [&]() {
       soff_a += BKB;
       soff_b += BKB;
-      if (++i_cc == p.kc) {
+      if (++i_cc == kc_cur) {
         i_cc = 0;
         soff_b = 0;
-        if (++i_kx == p.kw) { i_kx = 0; ++i_ky; }
-        if (i_ky < p.kh) refresh();
+        if (src == 0) {
+          if (++i_kx == p.kw) { i_kx = 0; ++i_ky; }
+          if (i_ky < p.kh) refresh();
+          else if (dual) {
+            src = 1;
+            kc_cur = p.kc2;
+#pragma unroll
+            for (int t = 0; t < NIB; ++t) cur_voff[t] = b2_voff[t];
+          }
+        }
       }
     };
     constexpr int NM = (sizeof(T) == 2 ? 1 : 4) * KK * MT_C * MT_P;   // MFMAs per K-step
@@ -1753,6 +1794,15 @@ static int validate(const ft_conv_desc* d) {
     if (d->res_cstride < d->res_coff + d->Cout) return FT_ERR_INVALID_ARG;
   }
   if (d->act < FT_ACT_NONE || d->act > FT_ACT_LEAKY) return FT_ERR_INVALID_ARG;
+  if (d->x2_cin < 0) return FT_ERR_INVALID_ARG;
+  if (d->x2_cin > 0) {   // second input (K-concat): 1x1 / stride 1 main conv, no residual, plain NHWC views
+    if (d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->has_residual || d->x_wpitch > 0)
+      return FT_ERR_UNSUPPORTED;
+    if (d->x2_stride <= 0 || d->x2_hi <= 0 || d->x2_wi <= 0 || d->x2_cstride % 8 || d->x2_coff % 8 || d->x2_coff < 0)
+      return FT_ERR_INVALID_ARG;
+    if (d->x2_cstride < d->x2_coff + round_up(d->x2_cin, 8)) return FT_ERR_INVALID_ARG;
+    if (d->Ho != (d->x2_hi - 1) / d->x2_stride + 1 || d->Wo != (d->x2_wi - 1) / d->x2_stride + 1) return FT_ERR_INVALID_ARG;
+  }
   return FT_OK;
 }
 
@@ -1764,6 +1814,7 @@ struct Geometry {
   int dma;                        // 1: conv_igemm_dma_kernel, 0: generic conv_igemm_kernel
   int rowpack;
   int nk, cin_groups, vec, kc;    // K-loop bookkeeping of the chosen kernel
+  int cin2_pad, kc2;              // second input (K-concat): its padded K-run and K-steps
 };
 
 static int geometry(const ft_conv_desc* d, Geometry* g) {
@@ -1775,6 +1826,7 @@ static int geometry(const ft_conv_desc* d, Geometry* g) {
   g->ntaps = d->transposed ? 4 : d->kh * d->kw;
   const int bk = kDmaBKB / esz;
   g->rowpack = 0;
+  g->cin2_pad = g->kc2 = 0;
   if (d->x_wpitch > 0) {
     // one K-run = one kernel row: kw taps x x_cstride channels, padded to whole K-steps with zero weights
     if (d->Cout <= 32 || d->kh > 32) return FT_ERR_UNSUPPORTED;
@@ -1800,12 +1852,18 @@ static int geometry(const ft_conv_desc* d, Geometry* g) {
   // (the transposed 16..32-output layers were tried too: fusion deconv0 578 -> 514 us, deconv1 91 -> 103 us: left alone)
   const bool small_3x3 = d->Cout >= 16 && !d->transposed && d->kh == 3 && d->kw == 3 && d->stride == 1;
   g->dma = (d->Cout > 32 || small_3x3) && g->ntaps <= 32 && d->x_cstride >= d->x_coff + cin_bk && wbytes < (1LL << 31);
+  if (d->x2_cin > 0) {     // K-concat needs the channel-aligned kernel for both inputs
+    const int cin2_bk = round_up(d->x2_cin, bk);
+    if (!g->dma || d->x2_cstride < d->x2_coff + cin2_bk || cin_bk / bk < 2) return FT_ERR_UNSUPPORTED;
+    g->cin2_pad = cin2_bk;
+    g->kc2 = cin2_bk / bk;
+  }
   if (g->dma) {
     g->cin_pad = cin_bk;
     g->cout_pad = round_up(d->Cout, d->Cout % 128 == 0 ? 128 : 64);
     g->kc = cin_bk / bk;
-    g->nk = g->ntaps * g->kc;
-    g->kpad = g->ntaps * cin_bk;
+    g->nk = g->ntaps * g->kc + g->kc2;
+    g->kpad = g->ntaps * cin_bk + g->cin2_pad;
     g->cin_groups = 0;
   } else {
     g->cin_pad = round_up(d->Cin, 8);
@@ -1991,6 +2049,10 @@ static bool halo_ok(const ft_conv_desc* d, const Geometry& g) {
 
 static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0, bool halo = false) {
   if (!g.dma) return false;
+  if (g.kc2 > 0) {   // K-concat runs in the lean loop only: no split-K, no halo; wide-K needs whole wide steps of both runs
+    if (ks != 1 || halo) return false;
+    if (wide && (g.kc2 % 2 != 0 || (g.kc >> 1) < 2)) return false;
+  }
   if (halo) return halo_ok(d, g) && bp == 128 && (bc == 64 || (bc == 128 && !g.rowpack)) && g.cout_pad % bc == 0 && ks == 1 && wide == 0;
   if (wide < 0 || wide > 1) return false;   // (BKB = 256 was benchmarked too: never the fastest on any layer)
   if (wide && !(d->dtype == FT_F16 && g.kc % (1 << wide) == 0)) return false;
@@ -2045,6 +2107,7 @@ extern "C" int ft_conv_pack_geometry(const ft_conv_desc* d, ft_conv_geometry* ou
   out->kpad = g.kpad;
   out->run_taps = g.run_taps;
   out->run_cpad = g.run_cpad;
+  out->cin2_pad = g.cin2_pad;
   return FT_OK;
 }
 
@@ -2072,7 +2135,7 @@ extern "C" int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int
 extern "C" double ft_conv_flops(const ft_conv_desc* d) {
   if (validate(d) != FT_OK) return 0.0;
   const double taps = d->transposed ? 4.0 : (double)d->kh * d->kw;  // per output pixel
-  return 2.0 * d->N * (double)d->Ho * d->Wo * d->Cout * d->Cin * taps;
+  return 2.0 * d->N * (double)d->Ho * d->Wo * d->Cout * ((double)d->Cin * taps + (double)d->x2_cin);
 }
 
 extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
@@ -2119,6 +2182,16 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.cin_groups = g.cin_groups;
   p.kc = g.kc;
   p.nk = g.nk;
+  p.x2 = nullptr;
+  p.kc2 = g.kc2;
+  if (g.kc2 > 0) {
+    if (!residual) return FT_ERR_INVALID_ARG;
+    const unsigned long long x2b = (unsigned long long)d->N * d->x2_hi * d->x2_wi * d->x2_cstride * dtype_size(d->dtype);
+    if (x2b >= (1ull << 31)) return FT_ERR_UNSUPPORTED;
+    p.x2 = static_cast<const char*>(residual);
+    p.x2_bytes = (unsigned)x2b;
+    p.x2_hi = d->x2_hi; p.x2_wi = d->x2_wi; p.x2_cstride = d->x2_cstride; p.x2_coff = d->x2_coff; p.x2_stride = d->x2_stride;
+  }
   p.Kpad = g.kpad;
   p.Cout = d->Cout;
   p.Cout_pad = g.cout_pad;
@@ -2181,6 +2254,10 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
       wide = 1;
       ks = 1;
     }
+    if (g.kc2 > 0) {   // K-concat: lean loop only
+      ks = 1;
+      if (wide && !tile_valid(d, g, bp, bc, 1, wide)) wide = 0;
+    }
     static const int force_wide = env_int("FT_CONV_WIDE"), force_halo = env_int("FT_CONV_HALO");
     const int hint = force ? (force | ((force_wide & 3) << kHintWideShift) | (force_halo ? kHintHalo : 0)) : d->tile_hint;
     if (hint) {
@@ -2193,6 +2270,7 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     if (halo) return launch_halo(p, d, g, bc, s);
     if (wide) {
       p.kc = g.kc >> wide;
+      p.kc2 = g.kc2 >> wide;
       p.nk = g.nk >> wide;
     }
     p.npt = ceil_div(p.M, bp);

@@ -466,6 +466,67 @@ class FusedConv:
                  keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None))
 
 
+class FusedShortcutConv:
+    """conv3 + bn3 of a bottleneck block and its projection shortcut (`downsample` = 1x1 stride-s conv + bn,
+    lib/pose/models/blocks.py:104-119) as ONE launch:  out = relu(bn3(conv3(t2)) + bn_d(conv_d(x))).
+    Both BatchNorms are folded into the weights (W' = diag(scale) W), the two 1x1 convs become one GEMM over the
+    concatenated K = [channels of t2 | channels of x] (`ft_conv_desc.x2_*`), the shifts add up.  The shortcut tensor
+    is never written to / re-read from HBM and its launch disappears."""
+
+    def __init__(self, w3: torch.Tensor, bn3: dict, wd: torch.Tensor, bnd: dict, stride_d: int, *, dtype: torch.dtype,
+                 device: torch.device, act: Optional[str] = "relu", label: str = ""):
+        require_gpu(device)
+        self.lib = _lib.load()
+        self.dtype, self.device, self.code = dtype, device, _lib.dtype_code(dtype)
+        self.cout, self.cin = w3.shape[0], w3.shape[1]
+        self.cin2, self.stride_d = wd.shape[1], stride_d
+        if wd.shape[0] != self.cout or w3.shape[2:] != (1, 1) or wd.shape[2:] != (1, 1):
+            raise FlowtrackHipError(f"{label}: conv3 / downsample must be 1x1 convs with the same output channels")
+        self.act, self.label = ACT_CODES[act], label
+
+        def folded(w, bn):
+            s, sh = fold_scale_shift(self.cout, self.cout, None, bn, torch.device("cpu"))
+            return w.detach().to(torch.float32).cpu()[:, :, 0, 0] * s[:, None], sh
+        self._w3, sh3 = folded(w3, bn3)
+        self._wd, shd = folded(wd, bnd)
+        self._shift = sh3 + shd
+        self._packed = {}
+
+    def _packed_for(self, d: ConvDesc):
+        g = conv_geometry(d)
+        key = g.key()
+        hit = self._packed.get(key)
+        if hit is None:
+            w = torch.zeros((1, g.cout_pad, g.kpad), dtype=torch.float32)
+            w[0, :self.cout, :self.cin] = self._w3
+            w[0, :self.cout, g.cin_pad:g.cin_pad + self.cin2] = self._wd
+            shift = torch.zeros(g.cout_pad, dtype=torch.float32)
+            shift[:self.cout] = self._shift
+            hit = self._packed[key] = (w.to(device=self.device, dtype=self.dtype).contiguous(), shift.to(self.device))
+        return hit
+
+    def record(self, prog: "Program", t2: ActView, x: ActView, y: ActView) -> None:
+        if t2.C != self.cin or x.C != self.cin2 or y.C != self.cout:
+            raise FlowtrackHipError(f"{self.label}: channel mismatch")
+        if (x.N, (x.H - 1) // self.stride_d + 1, (x.W - 1) // self.stride_d + 1) != (t2.N, t2.H, t2.W) or (y.N, y.H, y.W) != (t2.N, t2.H, t2.W):
+            raise FlowtrackHipError(f"{self.label}: shortcut / main / output sizes do not line up")
+        d = ConvDesc()
+        d.dtype = self.code
+        d.N, d.Hi, d.Wi = t2.N, t2.H, t2.W
+        d.Cin, d.x_cstride, d.x_coff = self.cin, t2.cstride, t2.coff
+        d.Cout, d.kh, d.kw, d.stride, d.pad, d.transposed = self.cout, 1, 1, 1, 0, 0
+        d.Ho, d.Wo = t2.H, t2.W
+        d.y_cstride, d.y_coff, d.out_layout = y.cstride, y.coff, FT_LAYOUT_NHWC
+        d.act, d.slope = self.act, 0.0
+        d.x2_cin, d.x2_hi, d.x2_wi, d.x2_cstride, d.x2_coff, d.x2_stride = self.cin2, x.H, x.W, x.cstride, x.coff, self.stride_d
+        w, shift = self._packed_for(d)
+        flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
+        prog.flops += flops
+        prog.conv_records.append((self.label, len(prog.calls), flops, d))
+        prog.add("ft_conv2d_fwd", ctypes.byref(d), t2.t.data_ptr(), w.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
+                 y.t.data_ptr(), keep=(d, t2.t, x.t, y.t, w, shift))
+
+
 # --------------------------------------------------------------------------------------------
 # thin wrappers for the remaining entry points (recorded into a Program)
 # --------------------------------------------------------------------------------------------

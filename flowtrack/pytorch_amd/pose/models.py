@@ -24,8 +24,8 @@ import torch
 import torch.nn as nn
 
 from ..engine import HipModule
-from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, Program, new_act, new_rowpacked_act, record_maxpool,
-                       record_pack_input)
+from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, new_act, new_rowpacked_act,
+                       record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
 # depth -> blocks per stage; only Bottleneck nets are valid because the head hard-codes 2048
@@ -61,6 +61,9 @@ class _PosePlan:
 
 
 class DeconvResnet(HipModule):
+    #: fold each block-0 projection shortcut into its conv3 launch (FusedShortcutConv); FT_FUSE_SHORTCUT=0 keeps them apart
+    fuse_shortcut: bool = os.environ.get("FT_FUSE_SHORTCUT", "1") != "0"
+
     def __init__(self, layers: List[int], num_classes: int):
         super().__init__()
         self.layers_cfg = list(layers)
@@ -146,14 +149,24 @@ class DeconvResnet(HipModule):
                 out = new_act(B, Ho, Wo, planes * 4, dtype, device)
                 c1.record(prog, cur, t1)
                 c2.record(prog, t1, t2)
-                if len(blk.downsample):
+                if len(blk.downsample) and self.fuse_shortcut:
+                    # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
+                    # the shortcut tensor never exists in HBM
+                    key = (name + ".conv3+downsample", dtype, str(device))
+                    fused = self._layers.get(key)
+                    if fused is None:
+                        fused = self._layers[key] = FusedShortcutConv(
+                            blk.conv3.weight, blk.bn3.as_dict(), blk.downsample[0].weight, blk.downsample[1].as_dict(), s,
+                            dtype=dtype, device=device, act="relu", label=name + ".conv3+downsample")
+                    fused.record(prog, t2, cur, out)
+                elif len(blk.downsample):
                     ds = self.fused(name + ".downsample", blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(),
                                     act=None, **mk)
                     res = new_act(B, Ho, Wo, planes * 4, dtype, device)
                     ds.record(prog, cur, res)
+                    c3.record(prog, t2, out, residual=res)
                 else:
-                    res = cur
-                c3.record(prog, t2, out, residual=res)  # relu(bn3(conv3) + residual), blocks.py:114-119
+                    c3.record(prog, t2, out, residual=cur)  # relu(bn3(conv3) + residual), blocks.py:114-119
                 cur = out
 
         for i in (0, 3, 6):

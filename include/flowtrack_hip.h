@@ -120,6 +120,15 @@ typedef struct ft_conv_desc {
    * reference's `cudnn.benchmark = True`, tools/pose/main.py:59).  Only the speed depends on it, never
    * the packed-weight layout; an inapplicable value falls back to the heuristic. */
   int tile_hint;
+  /* Optional SECOND input summed into the same accumulator ("K-concat"):
+   *   y = act(scale .* (W1 . x + W2 . x2[n, q*x2_stride]) + shift),   W = [W1 | W2] packed along K (K-run 1 = Cin
+   * channels of x, K-run 2 = x2_cin channels of x2, each padded as ft_conv_pack_geometry reports).
+   * It fuses the projection shortcut of a bottleneck block (`downsample` conv + bn, lib/pose/models/blocks.py:
+   * 104-119) into its conv3: the caller folds both BatchNorms into the weights (scale = NULL) and sums the shifts.
+   * Requirements: 1x1 / stride 1 / pad 0 main conv, has_residual = 0 — x2 is passed in ft_conv2d_fwd's `residual`
+   * argument — x2 is NHWC `dtype` [N, x2_hi, x2_wi, x2_cstride] with Ho = (x2_hi - 1) / x2_stride + 1 (same for Wo).
+   * x2_cin = 0: no second input. */
+  int x2_cin, x2_hi, x2_wi, x2_cstride, x2_coff, x2_stride;
 } ft_conv_desc;
 
 /* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,
@@ -133,6 +142,7 @@ typedef struct ft_conv_geometry {
   int cin_pad;   /* elements per K-run (channels padded; row-packed: roundup(kw * x_cstride)) */
   int cout_pad, kpad;
   int run_taps, run_cpad;
+  int cin2_pad;  /* elements of the second input's K-run (x2_cin padded), 0 without one; kpad = ntaps * cin_pad + cin2_pad */
 } ft_conv_geometry;
 
 /* The layout depends only on (dtype, Cin, Cout, kernel, transposed, x_cstride - x_coff, row-packing):

@@ -235,3 +235,56 @@ def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
         assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} "
                                     f"wide {(h >> 28) & 3} halo {(h >> 30) & 1}: max abs err {err:.3e}")
     assert torch.all(yv.t[..., Cout:] == 3.0) or act_stride(Cout) == Cout
+
+
+# ---- conv3 + projection shortcut as one K-concatenated GEMM (ft_conv_desc.x2_*, FusedShortcutConv) -----------
+SHORTCUT_CASES = [
+    # (name, N, planes (conv3 input channels), Cin of the block input, H, W of the block input, stride of the shortcut)
+    ("layer1_like", 2, 64, 64, 16, 12, 1),
+    ("layer2_like_s2", 2, 128, 256, 16, 12, 2),
+    ("layer3_like_s2_ragged", 3, 256, 512, 9, 7, 2),
+    ("odd_channels", 1, 96, 160, 10, 6, 2),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", SHORTCUT_CASES, ids=[c[0] for c in SHORTCUT_CASES])
+def test_fused_shortcut_conv_matches_oracle(hip_lib, case, dtype):
+    """relu(bn3(conv3(t2)) + bn_d(conv_d(x))) (blocks.py:104-119) in one launch, every tile variant the library offers."""
+    import ctypes
+    from flowtrack.pytorch_amd.hip_ops import FusedShortcutConv
+    name, N, planes, cin, H, W, s = case
+    dev = torch.device("cuda:0")
+    cout = planes * 4
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    w3 = synth.normal(9, name + ".w3", (cout, planes, 1, 1), std=(2.0 / planes) ** 0.5)
+    wd = synth.normal(9, name + ".wd", (cout, cin, 1, 1), std=(2.0 / cin) ** 0.5)
+    t2 = synth.normal(9, name + ".t2", (N, planes, Ho, Wo))
+    x = synth.normal(9, name + ".x", (N, cin, H, W))
+    mkbn = lambda tag: {"weight": synth.uniform(9, name + tag + "g", (cout,), 0.5, 1.5), "bias": synth.normal(9, name + tag + "b", (cout,), 0.1),
+                        "running_mean": synth.normal(9, name + tag + "m", (cout,), 0.1),
+                        "running_var": synth.uniform(9, name + tag + "v", (cout,), 0.5, 1.5), "eps": 1e-5}
+    bn3, bnd = mkbn(".bn3"), mkbn(".bnd")
+    if dtype == torch.float16:
+        t2, x = t2.half().float(), x.half().float()
+    want = F.relu(_reference(t2, w3, None, bn3, 1, 0, False, None, None) + _reference(x, wd, None, bnd, s, 0, False, None, None))
+    layer = FusedShortcutConv(w3, bn3, wd, bnd, s, dtype=dtype, device=dev, label=name)
+    t2v = nchw_to_view(t2, dtype, dev, cstride=act_stride(planes))
+    xv = nchw_to_view(x, dtype, dev, cstride=act_stride(cin))
+    yv = ActView(torch.zeros((N, Ho, Wo, act_stride(cout)), dtype=dtype, device=dev), cout, 0)
+    prog = make_program()
+    layer.record(prog, t2v, xv, yv)
+    d = prog.conv_records[0][3]
+    hints = (ctypes.c_int * 32)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+    assert n >= 2
+    # fp16: BatchNorm is folded into fp16 weights here (one more rounding than scale-after-accumulate)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    scale = max(1.0, want.abs().max().item())
+    for h in [0] + [int(v) for v in hints[:n]]:
+        assert h == 0 or ((h >> 24) & 0xf == 1 and not (h >> 30) & 1), "K-concat offers no split-K / halo variants"
+        d.tile_hint = h
+        yv.t.fill_(3.0)
+        run_program(prog)
+        err = (view_to_nchw(yv) - want).abs().max().item()
+        assert err <= tol * scale, f"{name} {dtype} hint {h:#x}: max abs err {err:.3e}"
