@@ -74,6 +74,8 @@ struct ConvParams {
   float slope;
   int npt, nct, nph;  // pixel tiles, output-channel tiles, phases (grid = npt * nct * nph, 1-D)
   int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
+  const char* tail_w; // fused tail 1x1 conv: fp16 [32][Cout] weights + fp32 [32] bias, or nullptr
+  int tail_cout;
   const char* x2;     // second input (K-concat), or nullptr
   int kc2;            // its K-steps (0: none)
   int x2_hi, x2_wi, x2_cstride, x2_coff, x2_stride;
@@ -256,6 +258,41 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
         }
       }
       __syncthreads();
+      if (p.tail_w) {
+        // fused tail 1x1 conv on the LDS-resident tile (BC == Cout: every channel of these pixels is here):
+        // out2[co2][pix] = sum_c Wt[co2][c] * tile[pix][c]; one 32-pixel group per wave, K = BC in steps of 16
+        const half_t* wt = reinterpret_cast<const half_t*>(p.tail_w);
+        const float* bt = reinterpret_cast<const float*>(p.tail_w + (size_t)32 * BC * 2);
+        for (int g = wave; g < BP / 32; g += NT / 64) {
+          const int pl = g * 32 + l31;
+          float16_t a2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll 4
+          for (int k0 = 0; k0 < BC; k0 += 16) {
+            const uint4_t wa = *reinterpret_cast<const uint4_t*>(wt + l31 * BC + k0 + lhi * 8);
+            const uint4_t tb = *reinterpret_cast<const uint4_t*>(s_tile + pl * ROWB + ((((k0 >> 3) + lhi) ^ (pl & (NCH - 1))) << 4));
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wa), __builtin_bit_cast(half8_t, tb), a2, 0, 0, 0);
+          }
+          const long long o = s_opix[pl];
+          if (o >= 0) {
+            const long long hw = (long long)p.Ho * p.Wo;
+            const long long n = o / hw, pix = o - n * hw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co2 = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+              if (co2 < p.tail_cout) {
+                const float v = a2[r] + bt[co2];
+                if (p.out_layout == FT_LAYOUT_NHWC)
+                  reinterpret_cast<half_t*>(p.y)[o * p.y_cstride + p.y_coff + co2] = (half_t)v;
+                else
+                  reinterpret_cast<float*>(p.y)[(n * p.tail_cout + co2) * hw + pix] = v;
+              }
+            }
+          }
+        }
+        return;
+      }
       half_t* ybase = reinterpret_cast<half_t*>(p.y) + p.y_coff + co0;
       for (int idx = tid; idx < BP * NCH; idx += NT) {
         const int pl = idx / NCH, ch = idx % NCH;
@@ -1785,7 +1822,7 @@ static int validate(const ft_conv_desc* d) {
   }
   if (d->out_layout == FT_LAYOUT_NHWC) {
     if (d->y_cstride % 4 || d->y_coff % 4 || d->y_coff < 0) return FT_ERR_INVALID_ARG;
-    if (d->y_cstride < d->y_coff + d->Cout) return FT_ERR_INVALID_ARG;
+    if (d->y_cstride < d->y_coff + (d->tail_cout > 0 ? d->tail_cout : d->Cout)) return FT_ERR_INVALID_ARG;
   } else if (d->out_layout != FT_LAYOUT_NCHW_F32) {
     return FT_ERR_INVALID_ARG;
   }
@@ -1794,6 +1831,11 @@ static int validate(const ft_conv_desc* d) {
     if (d->res_cstride < d->res_coff + d->Cout) return FT_ERR_INVALID_ARG;
   }
   if (d->act < FT_ACT_NONE || d->act > FT_ACT_LEAKY) return FT_ERR_INVALID_ARG;
+  if (d->tail_cout < 0 || d->tail_cout > 32) return FT_ERR_INVALID_ARG;
+  if (d->tail_cout > 0) {   // fused tail 1x1 conv: the whole channel dimension of a pixel tile must sit in one workgroup
+    if (d->dtype != FT_F16 || d->has_residual || d->x2_cin != 0 || !(d->Cout == 64 || d->Cout == 128 || d->Cout == 256))
+      return FT_ERR_UNSUPPORTED;
+  }
   if (d->x2_cin < 0) return FT_ERR_INVALID_ARG;
   if (d->x2_cin > 0) {   // second input (K-concat): 1x1 / stride 1 main conv, no residual, plain NHWC views
     if (d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->has_residual || d->x_wpitch > 0)
@@ -2082,6 +2124,7 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
   int st = geometry(d, &g);
   if (st != FT_OK) return -st;
   if (!hints || max <= 0) return -FT_ERR_INVALID_ARG;
+  if (d->tail_cout > 0) return 0;   // one variant: pixel tile x ALL channels
   static const int kTiles[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
   int n = 0;
   for (const auto& t : kTiles)
@@ -2135,7 +2178,7 @@ extern "C" int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int
 extern "C" double ft_conv_flops(const ft_conv_desc* d) {
   if (validate(d) != FT_OK) return 0.0;
   const double taps = d->transposed ? 4.0 : (double)d->kh * d->kw;  // per output pixel
-  return 2.0 * d->N * (double)d->Ho * d->Wo * d->Cout * ((double)d->Cin * taps + (double)d->x2_cin);
+  return 2.0 * d->N * (double)d->Ho * d->Wo * d->Cout * ((double)d->Cin * taps + (double)d->x2_cin + (double)d->tail_cout);
 }
 
 extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
@@ -2182,6 +2225,8 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.cin_groups = g.cin_groups;
   p.kc = g.kc;
   p.nk = g.nk;
+  p.tail_w = nullptr;
+  p.tail_cout = 0;
   p.x2 = nullptr;
   p.kc2 = g.kc2;
   if (g.kc2 > 0) {
@@ -2215,6 +2260,23 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   const unsigned long long x_bytes =
       (unsigned long long)d->N * d->Hi * (d->x_wpitch > 0 ? d->x_wpitch : d->Wi) * d->x_cstride * esz;
 
+  if (d->tail_cout > 0) {   // conv + fused tail 1x1 conv: 128 pixels x all Cout channels per workgroup
+    if (!g.dma || g.rowpack || x_bytes >= (1ull << 31) || g.cout_pad != d->Cout) return FT_ERR_UNSUPPORTED;
+    if (!residual) return FT_ERR_INVALID_ARG;
+    p.x_bytes = (unsigned)x_bytes;
+    p.tail_w = static_cast<const char*>(residual);
+    p.tail_cout = d->tail_cout;
+    p.epi_lds = 1;
+    p.npt = ceil_div(p.M, 128);
+    p.nct = 1;
+    if ((long long)p.npt * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+    dim3 grid(p.npt * p.nph);
+    const int rc = d->Cout == 256 ? launch_dma<half_t, 128, 256, 2, 4>(p, grid, s)
+                   : d->Cout == 128 ? launch_dma<half_t, 128, 128, 2, 2>(p, grid, s) : launch_dma<half_t, 128, 64, 2, 2>(p, grid, s);
+    if (rc != FT_OK) return rc;
+    FT_LAUNCH_CHECK("conv_igemm_dma_kernel (tail)");
+    return FT_OK;
+  }
   if (g.dma && x_bytes < (1ull << 31)) {
     p.x_bytes = (unsigned)x_bytes;
     // tile choice (launch-time only; the packed layout does not depend on it): fill the 256 CUs

@@ -388,7 +388,10 @@ class FusedConv:
 
     def __init__(self, weight: torch.Tensor, *, dtype: torch.dtype, device: torch.device, stride: int = 1,
                  pad: int = 0, transposed: bool = False, bias: Optional[torch.Tensor] = None,
-                 bn: Optional[dict] = None, act: Optional[str] = None, slope: float = 0.0, label: str = ""):
+                 bn: Optional[dict] = None, act: Optional[str] = None, slope: float = 0.0, label: str = "",
+                 tail_weight: Optional[torch.Tensor] = None, tail_bias: Optional[torch.Tensor] = None):
+        """tail_weight [n <= 32, Cout, 1, 1] (+ tail_bias [n]): a 1x1 conv fused behind this layer's activation
+        (ft_conv_desc.tail_cout); record() then writes the TAIL's output and this layer's own output never exists."""
         require_gpu(device)
         self.lib = _lib.load()
         self.dtype, self.device = dtype, device
@@ -407,6 +410,18 @@ class FusedConv:
         self._bn = None if bn is None else {k: (v.detach().to(torch.float32).cpu() if torch.is_tensor(v) else v)
                                             for k, v in bn.items()}
         self._packed = {}  # (cin_pad-dependent) geometry key -> (w, cout_pad, scale, shift)
+        self.tail_cout, self._tail = 0, None
+        if tail_weight is not None:
+            n = tail_weight.shape[0]
+            if dtype != torch.float16 or tuple(tail_weight.shape[1:]) != (self.cout, 1, 1) or n > 32 or self.cout not in (64, 128, 256):
+                raise FlowtrackHipError(f"{label}: the fused tail needs fp16, a 1x1 conv to <= 32 channels on 64/128/256 inputs")
+            w16 = torch.zeros((32, self.cout), dtype=torch.float16)
+            w16[:n] = tail_weight.detach().float().cpu()[:, :, 0, 0].half()
+            b32 = torch.zeros(32, dtype=torch.float32)
+            if tail_bias is not None:
+                b32[:n] = tail_bias.detach().float().cpu()
+            self._tail = torch.cat((w16.view(torch.uint8).flatten(), b32.view(torch.uint8).flatten())).to(device)
+            self.tail_cout = n
 
     def _packed_for(self, d: ConvDesc):
         """Packed weights + folded scale/shift for the kernel the library picks for `d` (cached per layout)."""
@@ -439,14 +454,15 @@ class FusedConv:
         d.Cout, d.kh, d.kw = self.cout, self.k, self.k
         d.stride, d.pad, d.transposed = self.stride, self.pad, int(self.transposed)
         d.Ho, d.Wo = Ho, Wo
+        out_c = self.tail_cout or self.cout
         if isinstance(y, ActView):
-            if (y.N, y.H, y.W) != (x.N, Ho, Wo) or y.C != self.cout or y.t.dtype != self.dtype:
+            if (y.N, y.H, y.W) != (x.N, Ho, Wo) or y.C != out_c or y.t.dtype != self.dtype:
                 raise FlowtrackHipError(f"{self.label}: output view mismatch {tuple(y.t.shape)} C={y.C}")
             d.y_cstride, d.y_coff, d.out_layout = y.cstride, y.coff, FT_LAYOUT_NHWC
             yt = y.t
         else:
-            if tuple(y.shape) != (x.N, self.cout, Ho, Wo) or y.dtype != torch.float32 or not y.is_contiguous():
-                raise FlowtrackHipError(f"{self.label}: NCHW output must be contiguous fp32 {(x.N, self.cout, Ho, Wo)}")
+            if tuple(y.shape) != (x.N, out_c, Ho, Wo) or y.dtype != torch.float32 or not y.is_contiguous():
+                raise FlowtrackHipError(f"{self.label}: NCHW output must be contiguous fp32 {(x.N, out_c, Ho, Wo)}")
             d.y_cstride, d.y_coff, d.out_layout = 0, 0, FT_LAYOUT_NCHW_F32
             yt = y
         res_ptr = None
@@ -456,6 +472,11 @@ class FusedConv:
             d.has_residual, d.res_cstride, d.res_coff = 1, residual.cstride, residual.coff
             res_ptr = residual.t.data_ptr()
         d.act, d.slope = self.act, self.slope
+        if self.tail_cout:
+            if residual is not None:
+                raise FlowtrackHipError(f"{self.label}: a fused tail excludes a residual input")
+            d.tail_cout = self.tail_cout
+            res_ptr = self._tail.data_ptr()
         w, _, scale, shift = self._packed_for(d)
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
@@ -463,7 +484,7 @@ class FusedConv:
         prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
                  scale.data_ptr() if scale is not None else None,
                  shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(),
-                 keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None))
+                 keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
 
 
 class FusedShortcutConv:

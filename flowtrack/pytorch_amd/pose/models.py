@@ -63,6 +63,8 @@ class _PosePlan:
 class DeconvResnet(HipModule):
     #: fold each block-0 projection shortcut into its conv3 launch (FusedShortcutConv); FT_FUSE_SHORTCUT=0 keeps them apart
     fuse_shortcut: bool = os.environ.get("FT_FUSE_SHORTCUT", "1") != "0"
+    #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
+    fuse_heatmap: bool = os.environ.get("FT_FUSE_HEATMAP", "1") != "0"
 
     def __init__(self, layers: List[int], num_classes: int):
         super().__init__()
@@ -169,16 +171,26 @@ class DeconvResnet(HipModule):
                     c3.record(prog, t2, out, residual=cur)  # relu(bn3(conv3) + residual), blocks.py:114-119
                 cur = out
 
+        # head: 3 x (ConvTranspose 4/2/1 + bn + relu), then the 1x1 heatmap conv (pose_deconv.py:43-45) — fused behind
+        # the last deconv as its tail in fp16 mode: the [B, 64, 48, 256] map, the largest tensor of the head, never
+        # reaches HBM
+        fuse_tail = self.fuse_heatmap and dtype == torch.float16 and self.num_classes <= 32 and self.deconv[6].cout in (64, 128, 256)
+        heatmaps = None
         for i in (0, 3, 6):
-            dc = self.fused(f"deconv.{i}", self.deconv[i].weight, transposed=True, stride=2, pad=1, bias=self.deconv[i].bias,
-                            bn=self.deconv[i + 1].as_dict(), act="relu", **mk)
-            nxt = new_act(B, cur.H * 2, cur.W * 2, dc.cout, dtype, device)
-            dc.record(prog, cur, nxt)
-            cur = nxt
-
-        hm = self.fused("heatmap", self.heatmap.weight, bias=self.heatmap.bias, act=None, **mk)
-        heatmaps = torch.empty((B, self.num_classes, cur.H, cur.W), dtype=torch.float32, device=device)
-        hm.record(prog, cur, heatmaps)
+            tail = dict(tail_weight=self.heatmap.weight, tail_bias=self.heatmap.bias) if (i == 6 and fuse_tail) else {}
+            dc = self.fused(f"deconv.{i}" + ("+heatmap" if tail else ""), self.deconv[i].weight, transposed=True, stride=2, pad=1,
+                            bias=self.deconv[i].bias, bn=self.deconv[i + 1].as_dict(), act="relu", **tail, **mk)
+            if tail:
+                heatmaps = torch.empty((B, self.num_classes, cur.H * 2, cur.W * 2), dtype=torch.float32, device=device)
+                dc.record(prog, cur, heatmaps)
+            else:
+                nxt = new_act(B, cur.H * 2, cur.W * 2, dc.cout, dtype, device)
+                dc.record(prog, cur, nxt)
+                cur = nxt
+        if heatmaps is None:
+            hm = self.fused("heatmap", self.heatmap.weight, bias=self.heatmap.bias, act=None, **mk)
+            heatmaps = torch.empty((B, self.num_classes, cur.H, cur.W), dtype=torch.float32, device=device)
+            hm.record(prog, cur, heatmaps)
         return _PosePlan(prog, x_static, heatmaps)
 
     def plan_for(self, B: int, H: int, W: int) -> _PosePlan:

@@ -129,6 +129,14 @@ typedef struct ft_conv_desc {
    * argument — x2 is NHWC `dtype` [N, x2_hi, x2_wi, x2_cstride] with Ho = (x2_hi - 1) / x2_stride + 1 (same for Wo).
    * x2_cin = 0: no second input. */
   int x2_cin, x2_hi, x2_wi, x2_cstride, x2_coff, x2_stride;
+  /* Optional fused TAIL 1x1 conv: y = Wt . act(scale .* conv(x) + shift) + bt with tail_cout <= 32 outputs.  The
+   * intermediate (all Cout channels of a pixel tile) stays in LDS and is never written: it fuses the pose head's
+   * last layers, `heatmap(deconv(...))` (lib/pose/models/pose_deconv.py:43-45), and saves the round trip of the
+   * largest tensor of the head.  Requirements: FT_F16, Cout in {64, 128, 256}, has_residual = 0, x2_cin = 0; the
+   * tail pack — fp16 [32][Cout] weights (rows >= tail_cout zero) followed by fp32 [32] bias — is passed in
+   * ft_conv2d_fwd's `residual` argument; `y` / out_layout / y_cstride / y_coff describe the TAIL output
+   * (Ho x Wo x tail_cout).  tail_cout = 0: none. */
+  int tail_cout;
 } ft_conv_desc;
 
 /* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,

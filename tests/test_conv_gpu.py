@@ -288,3 +288,52 @@ def test_fused_shortcut_conv_matches_oracle(hip_lib, case, dtype):
         run_program(prog)
         err = (view_to_nchw(yv) - want).abs().max().item()
         assert err <= tol * scale, f"{name} {dtype} hint {h:#x}: max abs err {err:.3e}"
+
+
+# ---- conv / deconv + fused tail 1x1 conv (ft_conv_desc.tail_cout): the pose head's deconv -> heatmap pair ------
+TAIL_CASES = [
+    # (name, N, Cin, H, W, Cout, k, stride, pad, transposed, tail_cout)
+    ("deconv256_heatmap17", 2, 256, 8, 6, 256, 4, 2, 1, True, 17),
+    ("deconv128_tail32_ragged", 1, 64, 5, 7, 128, 4, 2, 1, True, 32),
+    ("conv3x3_64_tail5", 2, 64, 9, 11, 64, 3, 1, 1, False, 5),
+    ("conv1x1_256_tail1", 1, 512, 12, 10, 256, 1, 1, 0, False, 1),
+]
+
+
+@pytest.mark.parametrize("nchw", [True, False], ids=["nchw_f32", "nhwc_f16"])
+@pytest.mark.parametrize("case", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_fused_tail_conv_matches_oracle(hip_lib, case, nchw):
+    """Wt . relu(bn(conv(x))) + bt in one launch; the oracle rounds the intermediate to fp16 as the unfused path does."""
+    name, N, Cin, H, W, Cout, k, stride, pad, transposed, nt = case
+    dev, dtype = torch.device("cuda:0"), torch.float16
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    fan = (Cin * 4) if transposed else Cin * k * k
+    w = synth.normal(13, name + ".w", wshape, std=(2.0 / fan) ** 0.5).half().float()
+    x = synth.normal(13, name + ".x", (N, Cin, H, W)).half().float()
+    bn = {"weight": synth.uniform(13, name + ".g", (Cout,), 0.5, 1.5), "bias": synth.normal(13, name + ".be", (Cout,), 0.1),
+          "running_mean": synth.normal(13, name + ".m", (Cout,), 0.1), "running_var": synth.uniform(13, name + ".v", (Cout,), 0.5, 1.5),
+          "eps": 1e-5}
+    wt = synth.normal(13, name + ".wt", (nt, Cout, 1, 1), std=(1.0 / Cout) ** 0.5).half().float()
+    bt = synth.normal(13, name + ".bt", (nt,), 0.2)
+    mid = _reference(x, w, None, bn, stride, pad, transposed, "relu", None).half().float()
+    want = F.conv2d(mid, wt, bt)
+    layer = FusedConv(w, dtype=dtype, device=dev, stride=stride, pad=pad, transposed=transposed, bn=bn, act="relu", label=name,
+                      tail_weight=wt, tail_bias=bt)
+    Ho, Wo = layer.out_hw(H, W)
+    xv = nchw_to_view(x, dtype, dev, cstride=act_stride(Cin))
+    prog = make_program()
+    if nchw:
+        y = torch.full((N, nt, Ho, Wo), 5.0, dtype=torch.float32, device=dev)
+        layer.record(prog, xv, y)
+        run_program(prog)
+        got = y.cpu()
+    else:
+        ybuf = torch.full((N, Ho, Wo, 40), 7.0, dtype=dtype, device=dev)
+        yv = ActView(ybuf, nt, 4)
+        layer.record(prog, xv, yv)
+        run_program(prog)
+        got = view_to_nchw(yv)
+        assert torch.all(ybuf[..., :4] == 7.0) and torch.all(ybuf[..., 4 + nt:] == 7.0), "wrote outside its channel slice"
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= (2e-3 if nchw else 1e-2) * scale, f"{name}: max abs err {err:.3e} (scale {scale:.2f})"
