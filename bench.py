@@ -77,7 +77,7 @@ def conv_roofline(prog, dtype_name, iters=5):
         ms = times[call_idx][1]
         per_layer.append((label, fl, ms))
     return {
-        "bound": "mfma", "kernel": "conv_igemm_dma_kernel (+ generic / few-output variants): every ft_conv2d_fwd launch of the step", "achieved": round(achieved, 2), "peak": peak,
+        "bound": "mfma", "kernel": "every ft_conv2d_fwd launch of the step: conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow), generic and few-output variants", "achieved": round(achieved, 2), "peak": peak,
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
         "launches_per_step": n_conv, "flop_per_launch_avg": flops / max(n_conv, 1),
         "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
@@ -221,7 +221,12 @@ def main():
     # idle clocks of a freshly woken GPU (observed: an occasional 2x slower 30-step region right after start-up)
     torch.cuda.synchronize()
     t_warm = time.perf_counter()
-    while not args.fixed_warmup and time.perf_counter() - t_warm < 0.5:
+    while not args.fixed_warmup:
+        # every rank must run the same number of steps (step() holds a collective when world > 1): the ranks agree
+        # on "keep going" through a MAX all-reduce of their own elapsed-time verdict
+        more = 1.0 if time.perf_counter() - t_warm < 0.5 else 0.0
+        if parallel.max_over_ranks(more, device=device) < 0.5:
+            break
         for _ in range(10):
             step()
         torch.cuda.synchronize()
