@@ -65,10 +65,10 @@ def conv_roofline(prog, dtype_name, iters=5):
     of consecutive conv launches (kernels back to back as in the graph); the per-launch pass (an event after every
     launch, ~1 us of overhead each) only feeds the --layers table and the cross-check field."""
     times = prog.time_calls(iters=iters)
-    per_launch_conv_ms = sum(ms for name, ms in times if name == "ft_conv2d_fwd")
+    per_launch_conv_ms = sum(ms for name, ms in times if name.startswith("ft_conv2d_fwd"))
     conv_ms, other_ms = prog.time_conv_runs(iters=iters)
     total_ms = conv_ms + other_ms
-    n_conv = sum(1 for name, _ in times if name == "ft_conv2d_fwd")
+    n_conv = sum(1 for name, _ in times if name.startswith("ft_conv2d_fwd"))
     flops = prog.flops
     achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[dtype_name]

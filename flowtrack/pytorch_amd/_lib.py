@@ -68,6 +68,9 @@ _PROTOTYPES = {
     "ft_stream_synchronize": (c_int, [c_void_p]),
     "ft_conv_pack_geometry": (c_int, [POINTER(ConvDesc), POINTER(ConvGeometry)]),
     "ft_conv_tile_candidates": (c_int, [POINTER(ConvDesc), POINTER(c_int), c_int]),
+    "ft_conv_workspace_bytes": (ctypes.c_size_t, [POINTER(ConvDesc)]),
+    "ft_conv2d_fwd_ws": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 ctypes.c_size_t, c_void_p]),
     "ft_conv_tap_source": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "ft_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),

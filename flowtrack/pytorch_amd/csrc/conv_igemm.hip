@@ -74,6 +74,8 @@ struct ConvParams {
   float slope;
   int npt, nct, nph;  // pixel tiles, output-channel tiles, phases (grid = npt * nct * nph, 1-D)
   int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
+  int sk;             // split-K across workgroups (1: none): grid = tiles * sk, fp32 partial tiles go to `ws`
+  float* ws;          // [sk][nph * M][Cout_pad] partial sums, reduced by conv_splitk_reduce_kernel
   const char* tail_w; // fused tail 1x1 conv: fp16 [32][Cout] weights + fp32 [32] bias, or nullptr
   int tail_cout;
   const char* x2;     // second input (K-concat), or nullptr
@@ -593,12 +595,15 @@ void conv_igemm_dma_kernel(const ConvParams p) {
   const int wp = wave % WGP, wc = wave / WGP;
   char* const gsm = smem + grp * (STAGES * STAGE);   // this group's ring
 
-  int ctile, phase, ptile;
+  int ctile, phase, ptile, ksplit;
   {
-    const int total = p.npt * p.nct * p.nph;
+    const int tiles = p.npt * p.nct * p.nph;
+    const int total = tiles * p.sk;
     const int b = blockIdx.x;
     const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    ksplit = logical / tiles;               // cross-workgroup K split: this workgroup's share of the K-steps
+    logical -= ksplit * tiles;
     ctile = logical % p.nct;
     const int t = logical / p.nct;
     phase = t % p.nph;
@@ -610,10 +615,13 @@ void conv_igemm_dma_kernel(const ConvParams p) {
   const int dbase_y = p.transposed ? py : -p.pad;
   const int dbase_x = p.transposed ? px : -p.pad_x;
   constexpr int esz = (int)sizeof(T);
-  // K-steps of this group: [ks_begin, ks_end); every group iterates nk_g times so the barriers line up
-  const int nk_g = (p.nk + KS - 1) / KS;
-  const int ks_begin = grp * nk_g;
-  const int ks_end = ks_begin + nk_g < p.nk ? ks_begin + nk_g : p.nk;
+  // K-steps of this group: [ks_begin, ks_end); every group iterates nk_g times so the barriers line up.
+  // With p.sk > 1 (KS == 1) the workgroup owns the ksplit-th slice of the K-steps instead.
+  const int nk_sk = (p.nk + p.sk - 1) / p.sk;
+  const int sk_lo = ksplit * nk_sk, sk_hi = sk_lo + nk_sk < p.nk ? sk_lo + nk_sk : p.nk;
+  const int nk_g = KS > 1 ? (p.nk + KS - 1) / KS : (sk_hi > sk_lo ? sk_hi - sk_lo : 0);
+  const int ks_begin = KS > 1 ? grp * nk_g : sk_lo;
+  const int ks_end = KS > 1 ? (ks_begin + nk_g < p.nk ? ks_begin + nk_g : p.nk) : sk_hi;
 
   // buffer descriptors: weights of this (phase, co tile); the whole activation buffer
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -1126,8 +1134,83 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     }
     __syncthreads();   // group 0 only: the partial region is about to be reused by the epilogue
   }
+  if (p.sk > 1) {
+    // cross-workgroup split-K: raw fp32 partial tile -> workspace [ksplit][phase * M + pixel][Cout_pad]; the scale /
+    // shift / residual / activation epilogue runs in conv_splitk_reduce_kernel once every slice has landed
+    const int l31 = lane & 31, lhi = lane >> 5;
+    float* wsb = p.ws + ((size_t)ksplit * p.nph + phase) * (size_t)p.M * p.Cout_pad;
+#pragma unroll
+    for (int j = 0; j < MT_P; ++j) {
+      const int m = m0 + wp * WT_P + j * 32 + l31;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < MT_C; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int cb = co0 + wc * WT_C + i * 32 + 8 * rg + 4 * lhi;
+          const float4_t v = {acc[i][j][rg * 4], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+          *reinterpret_cast<float4_t*>(wsb + (size_t)m * p.Cout_pad + cb) = v;
+        }
+    }
+    return;
+  }
   conv_epilogue<T, BP, BC, WGP, WGC, PRE, NT>(p, acc, smem, KS * STAGES * STAGE, m0, co0, py, px, rpre);
 #endif
+}
+
+// Sum of the split-K partial tiles + the fused epilogue (folded BN / bias, residual, activation), 4 channels per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+  const int c4n = p.Cout_pad / 4;
+  const size_t total = (size_t)p.nph * p.M * c4n;
+  const size_t slice = (size_t)p.nph * p.M * p.Cout_pad;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(idx % c4n);
+    const size_t pm = idx / c4n;
+    const int cb = c4 * 4;
+    if (cb >= p.Cout) continue;
+    float4_t a = *reinterpret_cast<const float4_t*>(p.ws + pm * p.Cout_pad + cb);
+    for (int s = 1; s < p.sk; ++s) a += *reinterpret_cast<const float4_t*>(p.ws + s * slice + pm * p.Cout_pad + cb);
+    const int phase = (int)(pm / p.M), m = (int)(pm - (size_t)phase * p.M);
+    const int n = m / p.HqWq, rem = m - n * p.HqWq, qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    const int oy = qy * p.omul + (phase >> 1), ox = qx * p.omul + (phase & 1);
+    const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.scale) {
+      const float4_t sc = *reinterpret_cast<const float4_t*>(p.scale + cb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= sc[e];
+    }
+    if (p.shift) {
+      const float4_t sh = *reinterpret_cast<const float4_t*>(p.shift + cb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += sh[e];
+    }
+    const bool full = cb + 3 < p.Cout;
+    if (p.res) {
+      const T* rp = reinterpret_cast<const T*>(p.res) + opix * p.res_cstride + p.res_coff + cb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (cb + e < p.Cout) v[e] += (float)rp[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+    if (p.out_layout == FT_LAYOUT_NHWC) {
+      T* yp = reinterpret_cast<T*>(p.y) + opix * p.y_cstride + p.y_coff + cb;
+      if (full) store4(yp, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + e < p.Cout) yp[e] = (T)v[e];
+      }
+    } else {
+      float* yp = reinterpret_cast<float*>(p.y);
+      const size_t hw = (size_t)p.Ho * p.Wo, pix = (size_t)oy * p.Wo + ox;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (cb + e < p.Cout) yp[((size_t)n * p.Cout + cb + e) * hw + pix] = v[e];
+    }
+  }
 }
 
 // ---- halo path (fp16): 3x3/s1 convs and the 2x2-tap phases of ConvTranspose2d(4,2,1) -------------------
@@ -2089,8 +2172,15 @@ static bool halo_ok(const ft_conv_desc* d, const Geometry& g) {
   return d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0;
 }
 
-static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0, bool halo = false) {
+constexpr int kHintSkShift = 21;     // tile_hint bits 21-23: log2 of the cross-workgroup K split (needs a workspace)
+
+static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0, bool halo = false,
+                       int sk = 1) {
   if (!g.dma) return false;
+  if (sk != 1) {     // split-K across workgroups: fp32 partial tiles in a workspace + a reduce launch
+    if (!(sk == 2 || sk == 4 || sk == 8) || ks != 1 || halo || g.kc2 > 0 || d->tail_cout > 0 || g.rowpack || bp > 128) return false;
+    if ((g.nk >> wide) / sk < 4) return false;
+  }
   if (g.kc2 > 0) {   // K-concat runs in the lean loop only: no split-K, no halo; wide-K needs whole wide steps of both runs
     if (ks != 1 || halo) return false;
     if (wide && (g.kc2 % 2 != 0 || (g.kc >> 1) < 2)) return false;
@@ -2132,6 +2222,21 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
       if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
   for (const auto& t : kTiles)
     if (n < max && tile_valid(d, g, t[0], t[1], 1, 1)) hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (1 << kHintWideShift);
+  // cross-workgroup split-K where the layer has less than ~one workgroup per CU even on 64-wide tiles (long K, few
+  // pixels: layer4 / FlowNet conv5..6 / every deep layer at small batch).  Needs ft_conv2d_fwd_ws.
+  {
+    const int Hq = d->transposed ? d->Hi : d->Ho, Wq = d->transposed ? d->Wi : d->Wo;
+    const long long M = (long long)d->N * Hq * Wq;
+    static const int kSkTiles[3][2] = {{128, 128}, {64, 128}, {64, 64}};
+    for (const auto& t : kSkTiles) {
+      if (g.cout_pad % t[1] != 0) continue;
+      const long long nblk = (long long)ceil_div((int)M, t[0]) * (g.cout_pad / t[1]) * g.nphases;
+      const int wide = tile_valid(d, g, t[0], t[1], 1, 1) ? 1 : 0;
+      for (int lg = 1; lg <= 3; ++lg)
+        if (n < max && nblk <= 256 && (nblk << lg) <= 1536 && tile_valid(d, g, t[0], t[1], 1, wide, false, 1 << lg))
+          hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (wide << kHintWideShift) | (lg << kHintSkShift);
+    }
+  }
   static const bool no_halo = getenv("FT_CONV_NO_HALO") != nullptr;   // dev: A/B the tile benchmark without the halo variants
   for (int bc = 128; bc >= 64 && !no_halo; bc >>= 1)
     if (n < max && tile_valid(d, g, 128, bc, 1, 0, true)) hints[n++] = 128 | (bc << 12) | (1 << 24) | kHintHalo;
@@ -2181,9 +2286,39 @@ extern "C" double ft_conv_flops(const ft_conv_desc* d) {
   return 2.0 * d->N * (double)d->Ho * d->Wo * d->Cout * ((double)d->Cin * taps + (double)d->x2_cin + (double)d->tail_cout);
 }
 
+extern "C" size_t ft_conv_workspace_bytes(const ft_conv_desc* d) {
+  int hints[32];
+  const int n = ft_conv_tile_candidates(d, hints, 32);
+  int max_sk = 1;
+  for (int i = 0; i < n; ++i) {
+    const int sk = 1 << ((hints[i] >> kHintSkShift) & 7);
+    if (sk > max_sk) max_sk = sk;
+  }
+  if (max_sk == 1) return 0;                 // no split-K variant is offered for this layer
+  Geometry g;
+  if (geometry(d, &g) != FT_OK) return 0;
+  const int Hq = d->transposed ? d->Hi : d->Ho, Wq = d->transposed ? d->Wi : d->Wo;
+  return (size_t)max_sk * g.nphases * d->N * Hq * Wq * g.cout_pad * sizeof(float);
+}
+
+static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                           const void* residual, void* y, void* workspace, size_t workspace_bytes, ft_stream_t stream);
+
 extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
                              const float* scale, const float* shift, const void* residual, void* y,
                              ft_stream_t stream) {
+  return conv2d_fwd_impl(d, x, w_packed, scale, shift, residual, y, nullptr, 0, stream);
+}
+
+extern "C" int ft_conv2d_fwd_ws(const ft_conv_desc* d, const void* x, const void* w_packed,
+                                const float* scale, const float* shift, const void* residual, void* y,
+                                void* workspace, size_t workspace_bytes, ft_stream_t stream) {
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return FT_ERR_INVALID_ARG;
+  return conv2d_fwd_impl(d, x, w_packed, scale, shift, residual, y, workspace, workspace_bytes, stream);
+}
+
+static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                           const void* residual, void* y, void* workspace, size_t workspace_bytes, ft_stream_t stream) {
   Geometry g;
   int st = geometry(d, &g);
   if (st != FT_OK) return st;
@@ -2225,6 +2360,8 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
   p.cin_groups = g.cin_groups;
   p.kc = g.kc;
   p.nk = g.nk;
+  p.sk = 1;
+  p.ws = nullptr;
   p.tail_w = nullptr;
   p.tail_cout = 0;
   p.x2 = nullptr;
@@ -2310,7 +2447,7 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     static const int force = (env_int("FT_CONV_BP") & 0xfff) | ((env_int("FT_CONV_BC") & 0xfff) << 12) | (env_int("FT_CONV_KS") << 24);
     // few workgroups + long K: the K-loop is latency-bound (one barrier per step, <= 2 waves per SIMD), so take
     // 128 bytes of K per step instead of splitting K (measured in situ on R50 / FlowNet2S: 15-25 % on those layers)
-    int wide = 0;
+    int wide = 0, sk = 1;
     bool halo = false;
     if (d->dtype == FT_F16 && bp <= 128 && g.kc % 2 == 0 && g.ntaps * g.cin_pad >= 512 && blocks(bp, bc) <= 768) {
       wide = 1;
@@ -2323,12 +2460,14 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     static const int force_wide = env_int("FT_CONV_WIDE"), force_halo = env_int("FT_CONV_HALO");
     const int hint = force ? (force | ((force_wide & 3) << kHintWideShift) | (force_halo ? kHintHalo : 0)) : d->tile_hint;
     if (hint) {
-      const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0xfff, hks = (hint >> 24) & 0xf;
+      const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0x1ff, hks = (hint >> 24) & 0xf;
       const int hwide = (hint >> kHintWideShift) & 3;
       const bool hhalo = (hint & kHintHalo) != 0;
+      const int hsk = 1 << ((hint >> kHintSkShift) & 7);
       const int nbp = hbp ? hbp : bp, nbc = hbc ? hbc : bc, nks = hks ? hks : (hbp || hbc ? 1 : ks);
-      if (tile_valid(d, g, nbp, nbc, nks, hwide, hhalo)) { bp = nbp; bc = nbc; ks = nks; wide = hwide; halo = hhalo; }
+      if (tile_valid(d, g, nbp, nbc, nks, hwide, hhalo, hsk)) { bp = nbp; bc = nbc; ks = nks; wide = hwide; halo = hhalo; sk = hsk; }
     }
+    if (sk > 1 && (!workspace || workspace_bytes < (size_t)sk * g.nphases * p.M * g.cout_pad * sizeof(float))) sk = 1;
     if (halo) return launch_halo(p, d, g, bc, s);
     if (wide) {
       p.kc = g.kc >> wide;
@@ -2337,8 +2476,14 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     }
     p.npt = ceil_div(p.M, bp);
     p.nct = g.cout_pad / bc;
-    if ((long long)p.npt * p.nct * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
-    dim3 grid(p.npt * p.nct * p.nph);
+    if ((long long)p.npt * p.nct * p.nph * sk > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+    dim3 grid(p.npt * p.nct * p.nph * sk);
+    const char* const res_saved = p.res;
+    if (sk > 1) {          // partial tiles only: the residual belongs to the reduce launch
+      p.sk = sk;
+      p.ws = static_cast<float*>(workspace);
+      p.res = nullptr;
+    }
     int rc;
     if (wide == 1) {
       if (bp == 256) rc = launch_dma<half_t, 256, 128, 4, 2, 1, 128, 2>(p, grid, s);
@@ -2367,6 +2512,14 @@ extern "C" int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w
     }
     if (rc != FT_OK) return rc;
     FT_LAUNCH_CHECK("conv_igemm_dma_kernel");
+    if (sk > 1) {
+      p.res = res_saved;
+      const size_t total = (size_t)p.nph * p.M * (p.Cout_pad / 4);
+      const unsigned rgrid = (unsigned)(total / 256 + 1 > 4096 ? 4096 : total / 256 + 1);
+      if (d->dtype == FT_F16) hipLaunchKernelGGL(conv_splitk_reduce_kernel<half_t>, dim3(rgrid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL(conv_splitk_reduce_kernel<float>, dim3(rgrid), dim3(256), 0, s, p);
+      FT_LAUNCH_CHECK("conv_splitk_reduce_kernel");
+    }
     return FT_OK;
   }
   if (g.dma) return FT_ERR_UNSUPPORTED;  // packed for the dma layout but the activation buffer is >= 2 GiB

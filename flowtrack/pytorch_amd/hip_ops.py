@@ -102,6 +102,10 @@ class Program:
         self.graph_exec = None
         self.flops = 0.0
         self.conv_records: list = []  # (label, call index, flops, ConvDesc) for per-layer timing / roofline / tuning
+        # one scratch buffer shared by every conv of the plan (split-K partial tiles, ft_conv2d_fwd_ws); the calls hold
+        # these two ctypes objects, whose values are filled in by _ensure_workspace() before the first launch
+        self._ws_ptr, self._ws_size = ctypes.c_void_p(None), ctypes.c_size_t(0)
+        self._ws_need, self._ws_tensor = 0, None
 
     @property
     def stream_handle(self) -> ctypes.c_void_p:
@@ -111,7 +115,19 @@ class Program:
         self.calls.append((name, args))
         self.keepalive.extend(keep)
 
+    def need_workspace(self, nbytes: int) -> None:
+        self._ws_need = max(self._ws_need, int(nbytes))
+
+    def _ensure_workspace(self) -> None:
+        if self._ws_need > self._ws_size.value:
+            if self.graph_exec is not None:
+                raise FlowtrackHipError("the plan's workspace cannot grow after graph capture")
+            self._ws_tensor = torch.empty(self._ws_need, dtype=torch.uint8, device=self.stream.device)
+            self._ws_ptr.value = self._ws_tensor.data_ptr()
+            self._ws_size.value = self._ws_need
+
     def run_eager(self) -> None:
+        self._ensure_workspace()
         sh = self.stream_handle
         lib = self.lib
         for name, args in self.calls:
@@ -142,6 +158,7 @@ class Program:
 
     def time_calls(self, iters: int = 5):
         """Per-call hipEvent timing on the program's stream (eager). Returns [(name, ms_avg)]."""
+        self._ensure_workspace()
         lib, sh = self.lib, self.stream_handle
         evs = []
         for _ in range(len(self.calls) + 1):
@@ -170,8 +187,9 @@ class Program:
         consecutive `ft_conv2d_fwd` calls (so the kernels run back to back exactly as in the graph and the intervals
         carry no per-launch event overhead) and a device-side head start (no host launch latency).
         Returns (conv_ms, other_ms) averaged over `iters` passes."""
+        self._ensure_workspace()
         lib, sh = self.lib, self.stream_handle
-        is_conv = [name == "ft_conv2d_fwd" for name, _ in self.calls]
+        is_conv = [name.startswith("ft_conv2d_fwd") for name, _ in self.calls]
         bounds = [0] + [i for i in range(1, len(is_conv)) if is_conv[i] != is_conv[i - 1]] + [len(is_conv)]
         evs = []
         for _ in bounds:
@@ -207,6 +225,7 @@ class Program:
         everything before the first kernel starts, so the intervals hold no launch latency.  Returns #layers changed."""
         if self.graph_exec is not None:
             raise FlowtrackHipError("tune_tiles must run before the plan is captured into a graph")
+        self._ensure_workspace()
         lib, sh = self.lib, self.stream_handle
         convs = [(i, rec[3]) for rec in self.conv_records for i in (rec[1],)]
         if not convs:
@@ -266,7 +285,8 @@ class Program:
             if verbose:
                 h = cands[k][best]
                 print(f"[tile benchmark] {self.conv_records[k][0]:28s} heuristic {times[k][0] * 1e3:7.1f} us  best {times[k][best] * 1e3:7.1f} us"
-                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}{' halo' if (h >> 30) & 1 else ''}", file=sys.stderr)
+                      f"  -> bp {h & 0xfff} bc {(h >> 12) & 0x1ff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}{' halo' if (h >> 30) & 1 else ''}"
+                      f"{' splitK x%d' % (1 << ((h >> 21) & 7)) if (h >> 21) & 7 else ''}", file=sys.stderr)
         _save_tile_cache()
         return changed
 
@@ -481,9 +501,10 @@ class FusedConv:
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
-        prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
+        prog.need_workspace(self.lib.ft_conv_workspace_bytes(ctypes.byref(d)))
+        prog.add("ft_conv2d_fwd_ws", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
                  scale.data_ptr() if scale is not None else None,
-                 shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(),
+                 shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(), prog._ws_ptr, prog._ws_size,
                  keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
 
 

@@ -164,6 +164,14 @@ int ft_conv_tap_source(const ft_conv_desc* d, int phase, int tap, int sub, int* 
 int ft_conv2d_fwd(const ft_conv_desc* d, const void* x, const void* w_packed,
                   const float* scale, const float* shift, const void* residual,
                   void* y, ft_stream_t stream);
+/* Same as ft_conv2d_fwd with a scratch buffer (>= ft_conv_workspace_bytes(d), 16-byte aligned, contents don't care):
+ * unlocks the tile variants that split K across workgroups (fp32 partial tiles in the workspace + a reduce launch) for
+ * layers with few pixels and a long K (layer4, FlowNet conv5..6, every deep layer at small batch).  Without a
+ * workspace those hints fall back to the unsplit variant of the same tile. */
+int ft_conv2d_fwd_ws(const ft_conv_desc* d, const void* x, const void* w_packed,
+                     const float* scale, const float* shift, const void* residual,
+                     void* y, void* workspace, size_t workspace_bytes, ft_stream_t stream);
+size_t ft_conv_workspace_bytes(const ft_conv_desc* d);
 /* Writes up to `max` valid `tile_hint` values for `d` (pixel tile x channel tile x split-K variants of
  * the implicit-GEMM kernel) into hints[] and returns their count (0: the layer runs on a kernel without
  * tile variants); negative = error status. */

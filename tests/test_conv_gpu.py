@@ -180,6 +180,10 @@ VARIANT_CASES = [
     ("var_3x3_tall", 1, 64, 40, 9, 192, 3, 1, 1, False, False),
     ("var_deconv_cin1026", 1, 1026, 5, 7, 256, 4, 2, 1, True, False),
     ("var_deconv_cout64_wide_img", 1, 128, 6, 33, 64, 4, 2, 1, True, False),
+    # few pixels + long K: the cross-workgroup split-K variants (workspace + reduce launch), with residual / transposed
+    ("var_splitk_3x3_512", 2, 512, 8, 6, 512, 3, 1, 1, False, False),
+    ("var_splitk_1x1_res_k2048", 2, 2048, 8, 6, 512, 1, 1, 0, False, True),
+    ("var_splitk_deconv_1024", 1, 1024, 6, 8, 512, 4, 2, 1, True, False),
     # stem patch kernel: every row-packed stem of the networks (pose 3 ch, FlowNetS/C 6 / 3 ch, stacked nets 12 ch,
     # FlowNetSD 3x3 on 6 ch, FlowNetFusion 3x3 on 11 ch), ragged tiles
     ("var_stem_flow6", 1, 6, 64, 96, 64, 7, 2, 3, False, False),
@@ -224,6 +228,8 @@ def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
     hints = (ctypes.c_int * 32)()
     n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
     assert n >= 2, f"{name}: only {n} tile variants offered"
+    if "splitk" in name:
+        assert any((int(v) >> 21) & 7 for v in hints[:n]), f"{name}: no split-K variant offered"
     tol = 2e-4 if dtype == torch.float32 else 2e-2
     scale = max(1.0, want.abs().max().item())
     for h in [0] + [int(v) for v in hints[:n]]:
@@ -232,7 +238,7 @@ def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
         torch.cuda.synchronize()      # the fill runs on torch's stream, the program on its own
         run_program(prog)
         err = (view_to_nchw(yv) - want).abs().max().item()
-        assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0xfff} ks {(h >> 24) & 0xf} "
+        assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0x1ff} splitK {1 << ((h >> 21) & 7)} ks {(h >> 24) & 0xf} "
                                     f"wide {(h >> 28) & 3} halo {(h >> 30) & 1}: max abs err {err:.3e}")
     assert torch.all(yv.t[..., Cout:] == 3.0) or act_stride(Cout) == Cout
 
