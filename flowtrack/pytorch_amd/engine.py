@@ -90,6 +90,8 @@ class HipModule(nn.Module):
                 if hip_ops.benchmark:     # cudnn.benchmark counterpart: pick each conv's tile variant in situ (every
                     prog.stream.synchronize()   # pass is a complete, valid forward: the outputs stay those of this input)
                     prog.tune_tiles(verbose=bool(os.environ.get("FT_CONV_BENCHMARK_VERBOSE")))
+                    prog.run_eager()      # outputs of this call come from the chosen variants (split-K variants sum in
+                                          # another order: the first call must be bit-identical to the replays)
                 if self.use_graph:
                     prog.stream.synchronize()
                     prog.capture()
