@@ -2189,6 +2189,10 @@ static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc,
   if (wide < 0 || wide > 1) return false;   // (BKB = 256 was benchmarked too: never the fastest on any layer)
   if (wide && !(d->dtype == FT_F16 && g.kc % (1 << wide) == 0)) return false;
   if (wide && ks > 1) return false;         // (wide + split-K likewise)
+  if (bc == 256) {   // all-256-channel tiles (8 waves at 128 pixels, 4 at 64): the pixel tile is loaded once per 256 outputs
+    if (!(d->dtype == FT_F16 && (bp == 64 || bp == 128) && ks == 1 && sk == 1 && g.cout_pad % 256 == 0)) return false;
+    return true;
+  }
   if (!((bp == 64 || bp == 128 || bp == 256) && (bc == 64 || bc == 128) && (ks == 1 || ks == 2 || ks == 4))) return false;
   if (g.cout_pad % bc != 0) return false;
   if (bp == 256 && !(bc == 128 && d->dtype == FT_F16 && ks == 1)) return false;
@@ -2222,6 +2226,9 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
       if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
   for (const auto& t : kTiles)
     if (n < max && tile_valid(d, g, t[0], t[1], 1, 1)) hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (1 << kHintWideShift);
+  for (int bp = 128; bp >= 64; bp >>= 1)
+    for (int wide = 0; wide <= 1; ++wide)
+      if (n < max && tile_valid(d, g, bp, 256, 1, wide)) hints[n++] = bp | (256 << 12) | (1 << 24) | (wide << kHintWideShift);
   // cross-workgroup split-K where the layer has less than ~one workgroup per CU even on 64-wide tiles (long K, few
   // pixels: layer4 / FlowNet conv5..6 / every deep layer at small batch).  Needs ft_conv2d_fwd_ws.
   {
@@ -2485,7 +2492,10 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
       p.res = nullptr;
     }
     int rc;
-    if (wide == 1) {
+    if (bc == 256) {
+      if (wide == 1) rc = bp == 128 ? launch_dma<half_t, 128, 256, 2, 4, 1, 128, 2>(p, grid, s) : launch_dma<half_t, 64, 256, 1, 4, 1, 128, 2>(p, grid, s);
+      else rc = bp == 128 ? launch_dma<half_t, 128, 256, 2, 4>(p, grid, s) : launch_dma<half_t, 64, 256, 1, 4>(p, grid, s);
+    } else if (wide == 1) {
       if (bp == 256) rc = launch_dma<half_t, 256, 128, 4, 2, 1, 128, 2>(p, grid, s);
       else if (bp == 128 && bc == 128) rc = launch_dma<half_t, 128, 128, 2, 2, 1, 128, 2>(p, grid, s);
       else if (bp == 128) rc = launch_dma<half_t, 128, 64, 2, 2, 1, 128, 3>(p, grid, s);
