@@ -21,8 +21,10 @@ for k in sorted(set(fetch) | set(write)):
     w = write.get(k, 0.0) * 1024.0 / nforward
     short = k.split("(")[0][:100]
     res["kernels"][short] = {"launches_per_forward": fc.get(k, wc.get(k, 0)) / nforward, "read_MB_per_forward": round(r / 1e6, 2), "write_MB_per_forward": round(w / 1e6, 2)}
-    if any(t in k for t in ("conv_igemm", "conv_fewout", "conv_halo", "conv_stem", "conv_pflow")):
-        conv_r += r; conv_w += w; n_conv += fc.get(k, 0) / nforward
+    if any(t in k for t in ("conv_igemm", "conv_fewout", "conv_halo", "conv_stem", "conv_pflow", "conv_splitk")):
+        conv_r += r; conv_w += w
+        if "conv_splitk" not in k:      # the reduce launch belongs to the ft_conv2d_fwd call of its split-K conv
+            n_conv += fc.get(k, 0) / nforward
 res["conv_kernels"] = {"launches_per_forward": n_conv, "hbm_read_MB_per_forward": round(conv_r / 1e6, 1), "hbm_write_MB_per_forward": round(conv_w / 1e6, 1),
                        "hbm_bytes_per_launch_avg": (conv_r + conv_w) / max(n_conv, 1)}
 json.dump(res, open(out, "w"), indent=1)

@@ -12,6 +12,8 @@ for w in pose flow; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --steps 30 > gpurun_out/${tag}_${w}_bench.json 2> gpurun_out/${tag}_${w}_bench.err
   timeout 600 tools/dev/prof_trace.sh ${tag}_${w}_bench python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --fixed-warmup > /dev/null 2>&1
   timeout 900 tools/dev/prof_traffic.sh ${tag}_${w} python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --fixed-warmup
-  python tools/dev/pmc_traffic.py gpurun_out/traffic_${tag}_${w} 6 gpurun_out/${tag}_${w}_hbm_traffic_pmc.json
+  # forwards in that run: the first call runs the launch list twice eagerly (plain + after the tile picks), then 1
+  # warm-up replay + 4 timed replays
+  python tools/dev/pmc_traffic.py gpurun_out/traffic_${tag}_${w} 7 gpurun_out/${tag}_${w}_hbm_traffic_pmc.json
 done
 tail -c 600 gpurun_out/${tag}_pose_bench.json
