@@ -15,5 +15,8 @@ for w in pose flow; do
   # forwards in that run: the first call runs the launch list twice eagerly (plain + after the tile picks), then 1
   # warm-up replay + 4 timed replays
   python tools/dev/pmc_traffic.py gpurun_out/traffic_${tag}_${w} 7 gpurun_out/${tag}_${w}_hbm_traffic_pmc.json
+  # 4. MFMA-busy fraction per kernel (its own --pmc pass)
+  ( cd /tmp && export TMPDIR=/tmp && cd $R && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/mfma_${tag}_${w} -o pmc --output-format csv -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --fixed-warmup > gpurun_out/mfma_${tag}_${w}.log 2>&1 )
+  python tools/dev/pmc_mfma.py gpurun_out/mfma_${tag}_${w} gpurun_out/${tag}_${w}_mfma_busy_pmc.json
 done
 tail -c 600 gpurun_out/${tag}_pose_bench.json
