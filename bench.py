@@ -187,14 +187,14 @@ def main():
         depth = args.backbone[len("resnet"):]
         default_cfg = args.backbone == "resnet50" and (H, W) == (256, 192)
         model = build_pose(device, dtype, backbone=args.backbone)
+        model.keypoints_in_plan = True                          # arg-max + 0.25 px nudge run inside the plan's graph
         x = model.static_input(B, H, W)                         # zero-copy binding: the batch is resident in HBM at the
         x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
         unit, metric = "crops/s", f"pose crops/sec (ResNet-{depth} + 3-deconv head, {H}x{W})"
         kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
 
         def step():
-            hm = model(x, copy_output=False)
-            _, score, coords = heatmap_max_preds(hm, adjust_coords=True)
+            _, _, score, coords = model.forward_keypoints(x)
             rows = torch.cat((coords, score), dim=2)            # [B,17,3] keypoint rows
             rows = parallel.all_gather_rows(rows, B * world) if world > 1 else rows
             kp_host.copy_(rows[rank * B:(rank + 1) * B] if world > 1 else rows, non_blocking=True)

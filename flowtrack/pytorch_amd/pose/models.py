@@ -63,6 +63,9 @@ class _PosePlan:
 class DeconvResnet(HipModule):
     #: fold each block-0 projection shortcut into its conv3 launch (FusedShortcutConv); FT_FUSE_SHORTCUT=0 keeps them apart
     fuse_shortcut: bool = os.environ.get("FT_FUSE_SHORTCUT", "1") != "0"
+    #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
+    #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
+    keypoints_in_plan = None
     #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
     fuse_heatmap: bool = os.environ.get("FT_FUSE_HEATMAP", "1") != "0"
 
@@ -191,11 +194,21 @@ class DeconvResnet(HipModule):
             hm = self.fused("heatmap", self.heatmap.weight, bias=self.heatmap.bias, act=None, **mk)
             heatmaps = torch.empty((B, self.num_classes, cur.H, cur.W), dtype=torch.float32, device=device)
             hm.record(prog, cur, heatmaps)
-        return _PosePlan(prog, x_static, heatmaps)
+        plan = _PosePlan(prog, x_static, heatmaps)
+        if self.keypoints_in_plan is not None:
+            # max_preds (+ the 0.25 px nudge of final_preds) as the last launch of the plan: no extra stream work per call
+            K, hh, hw = self.num_classes, heatmaps.shape[2], heatmaps.shape[3]
+            plan.kp_idx = torch.empty((B, K), dtype=torch.int32, device=device)
+            plan.kp_score = torch.empty((B, K, 1), dtype=torch.float32, device=device)
+            plan.kp_coords = torch.empty((B, K, 2), dtype=torch.float32, device=device)
+            prog.add("ft_heatmap_max_preds", heatmaps.data_ptr(), B, K, hh, hw, int(bool(self.keypoints_in_plan)),
+                     plan.kp_idx.data_ptr(), plan.kp_score.data_ptr(), plan.kp_coords.data_ptr(),
+                     keep=(plan.kp_idx, plan.kp_score, plan.kp_coords))
+        return plan
 
     def plan_for(self, B: int, H: int, W: int) -> _PosePlan:
         device, dtype = self._resolve()
-        key = (B, H, W, device, dtype)
+        key = (B, H, W, device, dtype, self.keypoints_in_plan)
         plan = self._plans.get(key)
         if plan is None:
             with torch.no_grad():
@@ -222,7 +235,18 @@ class DeconvResnet(HipModule):
             plan.x_static.copy_(x)  # dtype cast + staging into the graph's fixed input address
         self._run_plan(plan.prog, first=plan.runs == 0)
         plan.runs += 1
+        self._last_plan = plan
         return plan.heatmaps.clone() if copy_output else plan.heatmaps
+
+    @torch.no_grad()
+    def forward_keypoints(self, x: torch.Tensor):
+        """forward() with max_preds inside the plan (set `keypoints_in_plan` first): returns the plan's static buffers
+        (heatmaps [B,K,h,w], idx int32 [B,K], scores [B,K,1], coords [B,K,2] in heatmap pixels), valid until the next call."""
+        if self.keypoints_in_plan is None:
+            raise FlowtrackHipError("set model.keypoints_in_plan = True / False (adjust_coords) before forward_keypoints()")
+        hm = self.forward(x, copy_output=False)
+        plan = self._last_plan
+        return hm, plan.kp_idx, plan.kp_score, plan.kp_coords
 
 
 def deconv(backbone: str, num_classes: int, pretrained: bool) -> DeconvResnet:

@@ -119,3 +119,20 @@ def test_bn_batch_statistics(hip_lib, dtype):
     want_m = x.mean(dim=(0, 2, 3))
     want_v = x.var(dim=(0, 2, 3), unbiased=False)
     assert (mean.cpu() - want_m).abs().max() <= 1e-4 and (var.cpu() - want_v).abs().max() <= 1e-3
+
+
+@pytest.mark.parametrize("adjust", [False, True])
+def test_keypoints_inside_the_plan_match_the_separate_call(hip_lib, adjust):
+    """forward_keypoints (max_preds recorded in the plan / graph) == forward + heatmap_max_preds."""
+    from flowtrack.pytorch_amd.hip_ops import heatmap_max_preds
+    m = models.deconv("resnet50", 17, False)
+    m.load_state_dict(synth.fill_pose_state_dict(m.state_dict(), SEED))
+    m = m.cuda().eval()
+    m.compute_dtype = torch.float16
+    x = synth.pose_crops(SEED + 9, 3).cuda()
+    hm_ref = m(x)
+    idx_r, score_r, coords_r = heatmap_max_preds(hm_ref, adjust_coords=adjust)
+    m.keypoints_in_plan = adjust
+    for _ in range(2):          # eager first call, then the graph replay
+        hm, idx, score, coords = m.forward_keypoints(x)
+        assert torch.equal(hm, hm_ref) and torch.equal(idx, idx_r) and torch.equal(score, score_r) and torch.equal(coords, coords_r)
