@@ -166,3 +166,54 @@ def test_pose_config_parse_warns_on_unknown():
         warnings.simplefilter("always")
         o.parse({"backbone": "resnet101", "not_an_option": 1})
     assert o.backbone == "resnet101" and any("not_an_option" in str(x.message) for x in w)
+
+
+def _hints(hip_lib, d):
+    buf = (ctypes.c_int * 32)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), buf, 32)
+    assert n >= 0
+    return [int(v) for v in buf[:n]]
+
+
+def _decode(h):
+    return dict(bp=h & 0xfff, bc=(h >> 12) & 0x1ff, sk=1 << ((h >> 21) & 7), ks=(h >> 24) & 0xf, wide=(h >> 28) & 3, halo=(h >> 30) & 1)
+
+
+def test_tile_candidates_and_fusion_descriptors(hip_lib):
+    """Host-side contract of the tile benchmark (ft_conv_tile_candidates / tile_hint), the K-concat second input, the
+    fused tail and the split-K workspace — pure host code, no launch."""
+    # a big fp16 3x3 (layer1-like at batch 64): halo variants offered, no split-K (plenty of tiles), no workspace
+    big = _desc(dtype=_lib.FT_F16, N=64, Hi=64, Wi=48, Ho=64, Wo=48)
+    hs = [_decode(h) for h in _hints(hip_lib, big)]
+    assert any(h["halo"] for h in hs) and all(h["sk"] == 1 for h in hs) and hip_lib.ft_conv_workspace_bytes(ctypes.byref(big)) == 0
+    assert all(h["bc"] == 64 for h in hs), "Cout = 64 offers 64-wide channel tiles only"
+    # few pixels + long K (FlowNet conv6_1-like): split-K variants + a workspace of max_sk x M x Cout_pad fp32
+    deep = _desc(dtype=_lib.FT_F16, N=16, Hi=6, Wi=8, Ho=6, Wo=8, Cin=1024, x_cstride=1024, Cout=1024, y_cstride=1024)
+    hs = [_decode(h) for h in _hints(hip_lib, deep)]
+    sks = sorted({h["sk"] for h in hs})
+    assert sks[-1] >= 4 and all(h["ks"] == 1 and not h["halo"] for h in hs if h["sk"] > 1)
+    assert hip_lib.ft_conv_workspace_bytes(ctypes.byref(deep)) == sks[-1] * 16 * 6 * 8 * 1024 * 4
+    assert any(h["bc"] == 256 for h in hs), "Cout % 256 == 0 offers the all-256-channel tiles"
+    # fp32 (parity mode): no wide-K, no halo, no in-workgroup split-K
+    f32 = _desc(dtype=_lib.FT_F32, N=8, Hi=32, Wi=24, Ho=32, Wo=24, Cin=128, x_cstride=128, Cout=128, y_cstride=128)
+    assert all(h["wide"] == 0 and h["halo"] == 0 and h["ks"] == 1 for h in map(_decode, _hints(hip_lib, f32)))
+    # K-concat second input: 1x1 only, geometry = [cin_pad | cin2_pad], FLOPs of both GEMMs, no split-K / halo variants
+    kc = _desc(dtype=_lib.FT_F16, N=2, Hi=8, Wi=6, Ho=8, Wo=6, Cin=128, x_cstride=128, Cout=512, y_cstride=512, kh=1, kw=1, pad=0,
+               x2_cin=256, x2_hi=16, x2_wi=12, x2_cstride=256, x2_coff=0, x2_stride=2)
+    st, g = _geom(hip_lib, kc)
+    assert st == 0 and (g.cin_pad, g.cin2_pad, g.kpad) == (128, 256, 384)
+    assert hip_lib.ft_conv_flops(ctypes.byref(kc)) == 2.0 * 2 * 8 * 6 * 512 * (128 + 256)
+    assert all(h["ks"] == 1 and h["sk"] == 1 and not h["halo"] for h in map(_decode, _hints(hip_lib, kc)))
+    kc.kh = kc.kw = 3; kc.pad = 1
+    assert _geom(hip_lib, kc)[0] == 2                    # a second input needs a 1x1 main conv: unsupported
+    kc.kh = kc.kw = 1; kc.pad = 0; kc.x2_hi = 18
+    assert _geom(hip_lib, kc)[0] == 1                    # second input does not line up with the output grid
+    # fused tail: fp16, Cout in {64,128,256}, <= 32 tail outputs; one variant only; FLOPs include the tail GEMM
+    tl = _desc(dtype=_lib.FT_F16, N=2, Hi=8, Wi=6, Cin=256, x_cstride=256, Cout=256, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=16, Wo=12,
+               out_layout=1, y_cstride=0, tail_cout=17)
+    assert _geom(hip_lib, tl)[0] == 0 and _hints(hip_lib, tl) == []
+    assert hip_lib.ft_conv_flops(ctypes.byref(tl)) == 2.0 * 2 * 16 * 12 * 256 * (256 * 4 + 17)
+    tl.tail_cout = 33
+    assert _geom(hip_lib, tl)[0] == 1
+    tl.tail_cout = 17; tl.dtype = _lib.FT_F32
+    assert _geom(hip_lib, tl)[0] == 2                    # the fused tail is an fp16-mode feature
