@@ -62,6 +62,7 @@ _PROTOTYPES = {
     "ft_graph_destroy": (c_int, [c_void_p]),
     "ft_event_create": (c_int, [POINTER(c_void_p)]),
     "ft_event_record": (c_int, [c_void_p, c_void_p]),
+    "ft_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "ft_event_synchronize": (c_int, [c_void_p]),
     "ft_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "ft_event_destroy": (c_int, [c_void_p]),

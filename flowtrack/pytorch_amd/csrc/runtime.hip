@@ -92,6 +92,12 @@ extern "C" int ft_event_record(void* event, ft_stream_t stream) {
   return FT_OK;
 }
 
+extern "C" int ft_stream_wait_event(ft_stream_t stream, void* event) {
+  if (!event) return FT_ERR_INVALID_ARG;
+  FT_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(event), 0));
+  return FT_OK;
+}
+
 extern "C" int ft_event_synchronize(void* event) {
   if (!event) return FT_ERR_INVALID_ARG;
   FT_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(event)));

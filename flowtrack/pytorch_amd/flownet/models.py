@@ -239,29 +239,24 @@ def _record_decoder(prog: Program, p: _Decoder, conv6: ActView, cc5, cc4, cc3, c
     cc5..cc2: NHWC buffers [B,h,w,act_stride(1026|770|386|194)] whose channel slice 0 already holds the skip
     feature; returns flow2 as NCHW fp32 [B,2,H/4,W/4]."""
     B, dtype, device = conv6.N, mk["dtype"], mk["device"]
-    flow6 = new_act(B, conv6.H, conv6.W, 2, dtype, device)
-    _fp(p.predict_flow6, prefix + "predict_flow6", mk).record(prog, conv6, flow6)
-    _fu(p.upsampled_flow6_to_5, prefix + "upsampled_flow6_to_5", mk).record(prog, flow6, ActView(cc5, 2, 1024))
-    _fd(p.deconv5, prefix + "deconv5", mk).record(prog, conv6, ActView(cc5, 512, 512))
-    concat5 = ActView(cc5, 1026, 0)
-
-    flow5 = new_act(B, concat5.H, concat5.W, 2, dtype, device)
-    _fp(p.predict_flow5, prefix + "predict_flow5", mk).record(prog, concat5, flow5)
-    _fu(p.upsampled_flow5_to_4, prefix + "upsampled_flow5_to_4", mk).record(prog, flow5, ActView(cc4, 2, 768))
-    _fd(p.deconv4, prefix + "deconv4", mk).record(prog, concat5, ActView(cc4, 256, 512))
-    concat4 = ActView(cc4, 770, 0)
-
-    flow4 = new_act(B, concat4.H, concat4.W, 2, dtype, device)
-    _fp(p.predict_flow4, prefix + "predict_flow4", mk).record(prog, concat4, flow4)
-    _fu(p.upsampled_flow4_to_3, prefix + "upsampled_flow4_to_3", mk).record(prog, flow4, ActView(cc3, 2, 384))
-    _fd(p.deconv3, prefix + "deconv3", mk).record(prog, concat4, ActView(cc3, 128, 256))
-    concat3 = ActView(cc3, 386, 0)
-
-    flow3 = new_act(B, concat3.H, concat3.W, 2, dtype, device)
-    _fp(p.predict_flow3, prefix + "predict_flow3", mk).record(prog, concat3, flow3)
-    _fu(p.upsampled_flow3_to_2, prefix + "upsampled_flow3_to_2", mk).record(prog, flow3, ActView(cc2, 2, 192))
-    _fd(p.deconv2, prefix + "deconv2", mk).record(prog, concat3, ActView(cc2, 64, 128))
-    concat2 = ActView(cc2, 194, 0)
+    # At every level predict_flow -> upsampled_flow and the deconv are independent (both read the level's feature map,
+    # they write different channel slices of the next concat buffer) and each is too small to fill the GPU: they are
+    # recorded as two parallel branches (Program.fork / side / join -> parallel branches of the captured graph).
+    levels = ((conv6, cc5, 1024, 512, 512, p.predict_flow6, p.upsampled_flow6_to_5, p.deconv5, "6", "6_to_5", "5", 1026),
+              (None, cc4, 768, 512, 256, p.predict_flow5, p.upsampled_flow5_to_4, p.deconv4, "5", "5_to_4", "4", 770),
+              (None, cc3, 384, 256, 128, p.predict_flow4, p.upsampled_flow4_to_3, p.deconv3, "4", "4_to_3", "3", 386),
+              (None, cc2, 192, 128, 64, p.predict_flow3, p.upsampled_flow3_to_2, p.deconv2, "3", "3_to_2", "2", 194))
+    feat = conv6
+    for _, cc, foff, doff, dch, pf, upf, dec, ptag, utag, dtag, ctot in levels:
+        flow = new_act(B, feat.H, feat.W, 2, dtype, device)
+        prog.fork()
+        with prog.side():
+            _fp(pf, prefix + "predict_flow" + ptag, mk).record(prog, feat, flow)
+            _fu(upf, prefix + "upsampled_flow" + utag, mk).record(prog, flow, ActView(cc, 2, foff))
+        _fd(dec, prefix + "deconv" + dtag, mk).record(prog, feat, ActView(cc, dch, doff))
+        prog.join()
+        feat = ActView(cc, ctot, 0)
+    concat2 = feat
 
     flow2 = torch.empty((B, 2, concat2.H, concat2.W), dtype=torch.float32, device=device)
     _fp(p.predict_flow2, prefix + "predict_flow2", mk).record(prog, concat2, flow2)

@@ -98,6 +98,7 @@ class Program:
         self.lib = _lib.load()
         self.stream = stream
         self.calls: List[Tuple[str, tuple]] = []
+        self.lanes: List[int] = []          # 0 = main stream, 1 = side stream (between fork / join)
         self.keepalive: list = []
         self.graph_exec = None
         self.flops = 0.0
@@ -106,6 +107,11 @@ class Program:
         # these two ctypes objects, whose values are filled in by _ensure_workspace() before the first launch
         self._ws_ptr, self._ws_size = ctypes.c_void_p(None), ctypes.c_size_t(0)
         self._ws_need, self._ws_tensor = 0, None
+        # parallel branch: calls recorded between fork() and join() with side=True run on a second stream (a parallel
+        # branch of the captured graph): two small independent launches share the GPU instead of queueing
+        self._side = False
+        self._side_stream: Optional[torch.cuda.Stream] = None
+        self._events: list = []
 
     @property
     def stream_handle(self) -> ctypes.c_void_p:
@@ -113,7 +119,37 @@ class Program:
 
     def add(self, name: str, *args, keep: Sequence = ()) -> None:
         self.calls.append((name, args))
+        self.lanes.append(1 if self._side else 0)
         self.keepalive.extend(keep)
+
+    def fork(self) -> None:
+        """Everything recorded until join() is split in two branches that may overlap: `with prog.side():` calls go to
+        the second stream, the others stay on the main one.  Both branches start after everything recorded so far."""
+        self.calls.append(("__fork__", ()))
+        self.lanes.append(0)
+
+    def join(self) -> None:
+        self.calls.append(("__join__", ()))
+        self.lanes.append(0)
+
+    def side(self):
+        prog = self
+
+        class _Side:
+            def __enter__(self_inner):
+                prog._side = True
+
+            def __exit__(self_inner, *exc):
+                prog._side = False
+                return False
+        return _Side()
+
+    def _event(self, i: int) -> ctypes.c_void_p:
+        while len(self._events) <= i:
+            e = ctypes.c_void_p()
+            check(self.lib.ft_event_create(ctypes.byref(e)), "ft_event_create")
+            self._events.append(e)
+        return self._events[i]
 
     def need_workspace(self, nbytes: int) -> None:
         self._ws_need = max(self._ws_need, int(nbytes))
@@ -126,12 +162,33 @@ class Program:
             self._ws_ptr.value = self._ws_tensor.data_ptr()
             self._ws_size.value = self._ws_need
 
-    def run_eager(self) -> None:
+    #: FT_NO_BRANCHES=1: ignore fork / join (everything in recording order on one stream) — dev A/B switch
+    use_branches = os.environ.get("FT_NO_BRANCHES") is None
+
+    def run_eager(self, branches: bool = True) -> None:
+        """Issue the launch list: on the program's stream, with the side-lane calls of each fork/join section on the
+        second stream (branches=False: everything in order on the main stream, as the timing passes need it)."""
         self._ensure_workspace()
         sh = self.stream_handle
         lib = self.lib
-        for name, args in self.calls:
-            check(getattr(lib, name)(*args, sh), name)
+        branches = branches and self.use_branches
+        if branches and any(self.lanes) and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.stream.device)
+        side = ctypes.c_void_p(self._side_stream.cuda_stream) if (branches and self._side_stream is not None) else None
+        nev = 0
+        for (name, args), lane in zip(self.calls, self.lanes):
+            if name == "__fork__":
+                if side is not None:
+                    ev = self._event(nev); nev += 1
+                    check(lib.ft_event_record(ev, sh))
+                    check(lib.ft_stream_wait_event(side, ev))
+            elif name == "__join__":
+                if side is not None:
+                    ev = self._event(nev); nev += 1
+                    check(lib.ft_event_record(ev, side))
+                    check(lib.ft_stream_wait_event(sh, ev))
+            else:
+                check(getattr(lib, name)(*args, side if (lane and side is not None) else sh), name)
 
     def capture(self) -> None:
         """Record the launch sequence into a HIP graph (hipStreamBeginCapture on our side stream)."""
@@ -171,7 +228,8 @@ class Program:
                 torch.cuda._sleep(4_000_000)   # device-side head start: the intervals below hold no host launch latency
             check(lib.ft_event_record(evs[0], sh))
             for i, (name, args) in enumerate(self.calls):
-                check(getattr(lib, name)(*args, sh), name)
+                if not name.startswith("__"):          # fork / join markers: the timing passes run everything in order
+                    check(getattr(lib, name)(*args, sh), name)
                 check(lib.ft_event_record(evs[i + 1], sh))
             check(lib.ft_event_synchronize(evs[-1]))
             for i in range(len(self.calls)):
@@ -203,7 +261,8 @@ class Program:
             for b in range(len(bounds) - 1):
                 check(lib.ft_event_record(evs[b], sh))
                 for name, args in self.calls[bounds[b]:bounds[b + 1]]:
-                    check(getattr(lib, name)(*args, sh), name)
+                    if not name.startswith("__"):
+                        check(getattr(lib, name)(*args, sh), name)
             check(lib.ft_event_record(evs[-1], sh))
             check(lib.ft_event_synchronize(evs[-1]))
             for b in range(len(bounds) - 1):
@@ -260,6 +319,8 @@ class Program:
                 with torch.cuda.stream(self.stream):
                     torch.cuda._sleep(4_000_000)          # ~2 ms head start for the host
                 for i, (name, args) in enumerate(self.calls):
+                    if name.startswith("__"):
+                        continue
                     k = conv_pos.get(i)
                     if k is not None:
                         check(lib.ft_event_record(ev[2 * k], sh))
@@ -501,6 +562,12 @@ class FusedConv:
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
+        if prog._side:     # side-branch launches may overlap main-branch ones: they must not share the plan's workspace
+            prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
+                     scale.data_ptr() if scale is not None else None,
+                     shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(),
+                     keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
+            return
         prog.need_workspace(self.lib.ft_conv_workspace_bytes(ctypes.byref(d)))
         prog.add("ft_conv2d_fwd_ws", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
                  scale.data_ptr() if scale is not None else None,

@@ -67,6 +67,9 @@ int ft_graph_destroy(void* graph_exec);
  * (torch.cuda.Event only sees torch's current stream). */
 int ft_event_create(void** event_out);
 int ft_event_record(void* event, ft_stream_t stream);
+/* later work on `stream` waits for `event` (fork / join of two streams; inside a stream capture this makes the second
+ * stream a parallel branch of the graph) */
+int ft_stream_wait_event(ft_stream_t stream, void* event);
 int ft_event_synchronize(void* event);
 int ft_event_elapsed_ms(void* start, void* stop, float* ms_out);
 int ft_event_destroy(void* event);
