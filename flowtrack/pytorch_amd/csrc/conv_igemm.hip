@@ -299,9 +299,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
       for (int idx = tid; idx < BP * NCH; idx += NT) {
         const int pl = idx / NCH, ch = idx % NCH;
         const long long o = s_opix[pl];
-        if (o >= 0 && co0 + ch * 8 < p.Cout)
-          *reinterpret_cast<uint4_t*>(ybase + o * p.y_cstride + ch * 8) =
-              *reinterpret_cast<const uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4));
+        if (o >= 0 && co0 + ch * 8 < p.Cout) {
+          const uint4_t v = *reinterpret_cast<const uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4));
+#if FT_EPI_NT
+          __builtin_nontemporal_store(v, reinterpret_cast<uint4_t*>(ybase + o * p.y_cstride + ch * 8));
+#else
+          *reinterpret_cast<uint4_t*>(ybase + o * p.y_cstride + ch * 8) = v;
+#endif
+        }
       }
       return;
     }
@@ -548,6 +553,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // pixel stride (x_cstride >= x_coff + cin_pad, padding channels zero), buffers < 2 GiB.
 // Occupancy target (waves per SIMD) the register allocator must respect: the K-loop is latency-bound per
 // workgroup (one barrier per K-step), so co-resident workgroups are what keeps the MFMA pipe fed.
+#ifndef FT_EPI_NT
+#define FT_EPI_NT 0     // non-temporal stores in the fp16 epilogue (dev A/B)
+#endif
 #ifndef FT_DMA_INTERLEAVE
 #define FT_DMA_INTERLEAVE 1
 #endif
@@ -2034,7 +2042,8 @@ static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
 template <typename T, int BP, int BC, int WGP, int WGC, int KS = 1, int BKB = kDmaBKB, int S = kDmaStages>
 static int launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
   // the residual-prefetch variant exists for the fp16 LDS-transposed epilogue only
-  if (sizeof(T) == 2 && p.res && p.epi_lds) return launch_dma_r<T, BP, BC, WGP, WGC, true, KS, BKB, S>(p, grid, s);
+  static const bool no_respre = getenv("FT_NO_RESPRE") != nullptr;   // dev A/B: load the residual in the epilogue instead
+  if (sizeof(T) == 2 && p.res && p.epi_lds && !no_respre) return launch_dma_r<T, BP, BC, WGP, WGC, true, KS, BKB, S>(p, grid, s);
   return launch_dma_r<T, BP, BC, WGP, WGC, false, KS, BKB, S>(p, grid, s);
 }
 
