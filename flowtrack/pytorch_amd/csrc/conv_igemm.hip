@@ -553,6 +553,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // pixel stride (x_cstride >= x_coff + cin_pad, padding channels zero), buffers < 2 GiB.
 // Occupancy target (waves per SIMD) the register allocator must respect: the K-loop is latency-bound per
 // workgroup (one barrier per K-step), so co-resident workgroups are what keeps the MFMA pipe fed.
+// Workgroup barrier of the K-loops.  The builtin is IntrNoMem for LLVM: ds_reads that follow it in program order may be
+// hoisted ABOVE it (measured: the stem kernel read patch rows other waves' LDS-DMA had not landed yet, ~0.1 % of the
+// tiles wrong once workgroups are recycled on a CU).  The inline-asm form with a memory clobber pins the order.
+#define FT_LDS_BARRIER() asm volatile("s_barrier" ::: "memory")
 #ifndef FT_EPI_NT
 #define FT_EPI_NT 0     // non-temporal stores in the fp16 epilogue (dev A/B)
 #endif
@@ -856,7 +860,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     // this wave's loads of K-step ks+1 have landed (STAGES-3 younger stages may still be in flight) ...
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 3)) : "memory");
     // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
-    __builtin_amdgcn_s_barrier();
+    FT_LDS_BARRIER();
     issue(nxt);
     load_frags(std::integral_constant<int, P ^ 1>{}, cur1);
 #pragma unroll
@@ -866,7 +870,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
   };
 
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 2)) : "memory");
-  __builtin_amdgcn_s_barrier();
+  FT_LDS_BARRIER();
   load_frags(std::integral_constant<int, 0>{}, 0);
   int ks = 0;
   for (; ks + 1 < nk_g; ks += 2) {
@@ -961,7 +965,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
       // this wave's loads of this K-step have landed (wait_c younger loads may stay in flight) ...
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(wait_c)::value) : "memory");
       // ... after the barrier everyone's have, and everyone is done reading the slot refilled below
-      __builtin_amdgcn_s_barrier();
+      FT_LDS_BARRIER();
       const char* st = smem + slot * STAGE;
       uint4_t fa[KK][MT_C], fb[KK][MT_P];
 #pragma unroll
@@ -1024,7 +1028,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 2)) : "memory");
     FT_T(0);
     // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
-    __builtin_amdgcn_s_barrier();
+    FT_LDS_BARRIER();
     FT_T(1);
 #if FT_DMA_INTERLEAVE && !defined(FT_CONV_TIMING)
     if constexpr (sizeof(T) == 2) {
@@ -1403,8 +1407,14 @@ __global__ __launch_bounds__(256, (CCH == 32 ? 3 : 2)) void conv_halo_kernel(con
       constexpr int st = decltype(st_c)::value;
       constexpr int tap = st / NSL, sl = st % NSL;
       constexpr int slot = st % S, nslot = (st + S - 1) % S;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS * (S - 2)) : "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (st == 0) {
+        // first K-step on a freshly prefetched patch buffer: wait for EVERY load of this wave (see conv_stem_kernel:
+        // the counted form was not reliable for a resident patch that older loads fill while younger ones stream)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS * (S - 2)) : "memory");
+      }
+      FT_LDS_BARRIER();
       // fragments: weights from the ring, pixels from the resident patch at this tap's offset
       const char* sa = ring + slot * A_STAGE;
       constexpr int ky = tap / KW, kx = tap % KW;
@@ -1581,8 +1591,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p) {
   static_for<KH>([&](auto ky_c) {
     constexpr int ky = decltype(ky_c)::value;
     constexpr int slot = ky % S, nslot = (ky + S - 1) % S;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA * (S - 2)) : "memory");
-    __builtin_amdgcn_s_barrier();
+    // every load of this wave has landed — not the counted vmcnt(NIA * (S - 2)) of the other kernels: with it ~0.1 % of
+    // the tiles came out wrong once workgroups were recycled on a CU (a patch row read before it landed; the counted
+    // form needs the patch loads to retire before the YOUNGER weight loads, which this mix of a cold HBM stream and
+    // L2-resident weights did not honour).  Only 7 K-steps per workgroup: the lost weight prefetch depth is noise.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    FT_LDS_BARRIER();
     load_a(std::integral_constant<int, nslot>{}, ky + S - 1 < KH, ky + S - 1);
     const char* sa = ring + slot * A_STAGE;
     const char* pb = patch + ky * RBp;
@@ -2253,7 +2267,9 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
           hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (wide << kHintWideShift) | (lg << kHintSkShift);
     }
   }
-  static const bool no_halo = getenv("FT_CONV_NO_HALO") != nullptr;   // dev: A/B the tile benchmark without the halo variants
+  // dev: A/B the tile benchmark without the halo variants ("1": none, "stem": no stem kernel, "conv": no conv_halo_kernel)
+  static const char* nh = getenv("FT_CONV_NO_HALO");
+  const bool no_halo = nh && (nh[0] == '1' || (nh[0] == 's' && g.rowpack) || (nh[0] == 'c' && !g.rowpack));
   for (int bc = 128; bc >= 64 && !no_halo; bc >>= 1)
     if (n < max && tile_valid(d, g, 128, bc, 1, 0, true)) hints[n++] = 128 | (bc << 12) | (1 << 24) | kHintHalo;
   return n;

@@ -46,8 +46,8 @@ def test_pose_r50_batch64_contains_the_pinned_batch4(hip_lib):
     assert np.array_equal(idx.cpu().numpy(), PG["r50_idx"]), "arg-max of rows 0..3 differs from the reference"
     alone = m(x[:4])
     assert (alone - hm[:4]).abs().max().item() <= 1e-4, "a crop's heatmaps depend on its batch"
-    again = m(x)
-    assert torch.equal(again, hm), "graph replay is not deterministic"
+    for _ in range(3):
+        assert torch.equal(m(x), hm), "graph replay is not deterministic"
 
 
 def test_pose_r101_384x288_batch16_fp16_vs_fp32(hip_lib):
