@@ -136,3 +136,45 @@ def test_full_size_batches_match_the_cpu_oracle(hip_lib, oracle_lib):
     mag = torch.norm(want_flow, dim=1).mean().item()
     assert err.max().item() <= 0.25 * max(mag, 1.0), "a fp16 flow pixel far off the oracle (corrupted tile?)"
     assert torch.norm(err, dim=1).mean().item() <= 0.02 * max(mag, 1.0) + 0.05
+
+
+@pytest.mark.parametrize("name", ["FlowNet2C", "FlowNet2CS", "FlowNet2SD", "FlowNet2"])
+def test_other_flow_stacks_at_512x384_match_the_cpu_oracle(hip_lib, oracle_lib, name):
+    """The stacked / correlation networks at the configs[3] frame size (batch 4: the oracle's C correlation is slow),
+    both modes, every pixel."""
+    from oracle import flow_ref
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    fwd = {"FlowNet2C": flow_ref.flownet2c_forward, "FlowNet2CS": flow_ref.flownet2cs_forward,
+           "FlowNet2SD": flow_ref.flownet2sd_forward, "FlowNet2": flow_ref.flownet2_forward}[name]
+    m = getattr(flow_models, name)(ARGS)
+    sd = synth.fill_flow_state_dict(m.state_dict(), SEED + 4)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    pairs = synth.frame_pairs(SEED + 13, 4)
+    want = fwd(sd, pairs)
+    mag = torch.norm(want, dim=1).mean().item()
+    m.compute_dtype = torch.float32
+    e32 = (m(pairs.cuda()).cpu() - want).abs().max().item()
+    assert e32 <= 1e-3 * max(1.0, want.abs().max().item() / 10), f"{name} fp32: {e32:.3e}"
+    m16 = getattr(flow_models, name)(ARGS)
+    m16.load_state_dict(sd)
+    m16 = m16.cuda().eval()
+    m16.compute_dtype = torch.float16
+    err = (m16(pairs.cuda()).cpu() - want).abs()
+    assert torch.norm(err, dim=1).mean().item() <= 0.03 * max(mag, 1.0) + 0.05, f"{name} fp16 EPE"
+    assert err.max().item() <= 0.5 * max(mag, 1.0) + 0.5, f"{name} fp16: a pixel far off the oracle (corrupted tile?)"
+
+
+def test_r101_384x288_batch16_matches_the_cpu_oracle(hip_lib):
+    """BASELINE configs[2] per-GPU shape in full against the oracle (fp32 <= 1e-3, identical arg-max; fp16 in bounds)."""
+    from oracle import pose_ref
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    x = synth.pose_crops(SEED + 14, 16, 384, 288)
+    m32 = _pose(101, torch.float32)
+    sd = synth.fill_pose_state_dict(m32.state_dict(), SEED)
+    want = pose_ref.pose_forward(sd, x, depth=101)
+    got = m32(x.cuda()).cpu()
+    assert (got - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item() / 4)
+    assert torch.equal(got.flatten(2).argmax(2), want.flatten(2).argmax(2))
+    got16 = _pose(101, torch.float16)(x.cuda()).cpu()
+    assert (got16 - want).abs().max().item() <= 0.05 * (want.max() - want.min()).item()
