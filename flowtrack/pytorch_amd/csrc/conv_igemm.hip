@@ -963,7 +963,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
       constexpr bool do_issue = decltype(issue_c)::value;
       constexpr int nslot = (slot + STAGES - 1) % STAGES;
       // this wave's loads of this K-step have landed (wait_c younger loads may stay in flight) ...
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(wait_c)::value) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(decltype(wait_c)::value) : "memory");
       // ... after the barrier everyone's have, and everyone is done reading the slot refilled below
       FT_LDS_BARRIER();
       const char* st = smem + slot * STAGE;
@@ -1025,7 +1025,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
     unsigned long long tprev = __builtin_readcyclecounter();
 #endif
     // this wave's loads of K-step ks have landed (STAGES-2 younger stages may still be in flight) ...
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (STAGES - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL * (STAGES - 2)) : "memory");
     FT_T(0);
     // ... after the barrier everyone's have, and everyone is done reading the slot issue() refills
     FT_LDS_BARRIER();
@@ -1412,7 +1412,7 @@ __global__ __launch_bounds__(256, (CCH == 32 ? 3 : 2)) void conv_halo_kernel(con
         // the counted form was not reliable for a resident patch that older loads fill while younger ones stream)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS * (S - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLS * (S - 2)) : "memory");
       }
       FT_LDS_BARRIER();
       // fragments: weights from the ring, pixels from the resident patch at this tap's offset
