@@ -10,6 +10,9 @@ export FT_TILE_CACHE=$R/gpurun_out/tile_cache_$tag.json
 rm -f $FT_TILE_CACHE
 for w in pose flow; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --steps 30 > gpurun_out/${tag}_${w}_bench.json 2> gpurun_out/${tag}_${w}_bench.err
+  # kernel-level passes run the launch list in order (FT_NO_BRANCHES=1): inside parallel graph branches two kernels share
+  # the GPU and each one's traced duration stretches, which is not what roofline.avg_launch_us (per-kernel, in order) means
+  export FT_NO_BRANCHES=1
   timeout 600 tools/dev/prof_trace.sh ${tag}_${w}_bench python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --fixed-warmup > /dev/null 2>&1
   timeout 900 tools/dev/prof_traffic.sh ${tag}_${w} python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --fixed-warmup
   # forwards in that run: the first call runs the launch list twice eagerly (plain + after the tile picks), then 1
@@ -18,5 +21,6 @@ for w in pose flow; do
   # 4. MFMA-busy fraction per kernel (its own --pmc pass)
   ( cd /tmp && export TMPDIR=/tmp && cd $R && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/mfma_${tag}_${w} -o pmc --output-format csv -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --fixed-warmup > gpurun_out/mfma_${tag}_${w}.log 2>&1 )
   python tools/dev/pmc_mfma.py gpurun_out/mfma_${tag}_${w} gpurun_out/${tag}_${w}_mfma_busy_pmc.json
+  unset FT_NO_BRANCHES
 done
 tail -c 600 gpurun_out/${tag}_pose_bench.json
