@@ -2258,12 +2258,13 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
     const int Hq = d->transposed ? d->Hi : d->Ho, Wq = d->transposed ? d->Wi : d->Wo;
     const long long M = (long long)d->N * Hq * Wq;
     static const int kSkTiles[3][2] = {{128, 128}, {64, 128}, {64, 64}};
+    static const int sk_max_blocks = getenv("FT_SK_MAX_BLOCKS") ? atoi(getenv("FT_SK_MAX_BLOCKS")) : 256;   // dev knob
     for (const auto& t : kSkTiles) {
       if (g.cout_pad % t[1] != 0) continue;
       const long long nblk = (long long)ceil_div((int)M, t[0]) * (g.cout_pad / t[1]) * g.nphases;
       const int wide = tile_valid(d, g, t[0], t[1], 1, 1) ? 1 : 0;
       for (int lg = 1; lg <= 3; ++lg)
-        if (n < max && nblk <= 256 && (nblk << lg) <= 1536 && tile_valid(d, g, t[0], t[1], 1, wide, false, 1 << lg))
+        if (n < max && nblk <= sk_max_blocks && (nblk << lg) <= 4 * sk_max_blocks + 512 && tile_valid(d, g, t[0], t[1], 1, wide, false, 1 << lg))
           hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (wide << kHintWideShift) | (lg << kHintSkShift);
     }
   }
