@@ -1591,10 +1591,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p) {
   static_for<KH>([&](auto ky_c) {
     constexpr int ky = decltype(ky_c)::value;
     constexpr int slot = ky % S, nslot = (ky + S - 1) % S;
-    // every load of this wave has landed — not the counted vmcnt(NIA * (S - 2)) of the other kernels: with it ~0.1 % of
-    // the tiles came out wrong once workgroups were recycled on a CU (a patch row read before it landed; the counted
-    // form needs the patch loads to retire before the YOUNGER weight loads, which this mix of a cold HBM stream and
-    // L2-resident weights did not honour).  Only 7 K-steps per workgroup: the lost weight prefetch depth is noise.
+    // FULL wait (every load of this wave has landed, every ds_read returned), not the counted vmcnt(NIA * (S - 2)) of
+    // the other kernels: with a counted wait ~0.1 % of the tiles came out wrong once workgroups were recycled on a CU.
+    // Probes (full wait at step 0 only / at the later steps only / no dummy tail loads) all still failed and the
+    // ordering micro-benchmarks under tools/dev/ubench pass, so the root cause is not pinned down; this form is the
+    // most conservative DMA -> LDS -> ds_read sync there is and is what tests/ + tools/dev/determinism_stress.py
+    // hold green.  Only 7 K-steps per workgroup: the lost weight prefetch depth is noise.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     FT_LDS_BARRIER();
     load_a(std::integral_constant<int, nslot>{}, ky + S - 1 < KH, ky + S - 1);
