@@ -297,13 +297,19 @@ class Program:
             return sum(1 for k in keys if _TILE_CACHE[k])
         cands = []
         hints = (ctypes.c_int * 32)()
-        for _, d in convs:
+        for (_, d), key in zip(convs, keys):
+            if key in _TILE_CACHE:        # picks are sticky within a process: two plans of one model (other batch-
+                cands.append([_TILE_CACHE[key]])   # independent keys aside) must run the same variants, bit for bit
+                continue
             n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
             if n < 0:
                 check(-n, "ft_conv_tile_candidates")
             cands.append([0] + [int(h) for h in hints[:n]] if n > 1 else [0])
         rounds = max(len(c) for c in cands)
         if rounds == 1:
+            for k, (_, d) in enumerate(convs):
+                d.tile_hint = cands[k][0]
+                _TILE_CACHE.setdefault(keys[k], cands[k][0])
             return 0
         conv_pos = {i: k for k, (i, _) in enumerate(convs)}
         ev = []
@@ -335,10 +341,19 @@ class Program:
                         times[k][r] = min(times[k][r], ms.value)
         for e in ev:
             lib.ft_event_destroy(e)
+        # one pick per distinct layer description (all instances of e.g. layer3.[1-5].conv1 share it, judged on their
+        # summed time): the variants differ in summation order, so a per-instance pick would make a freshly benchmarked
+        # plan and a later plan served from the cache disagree in the last bits
+        group_time = {}
+        for k, key in enumerate(keys):
+            tot = group_time.setdefault(key, [0.0] * len(cands[k]))
+            for r in range(len(cands[k])):
+                tot[r] += times[k][r]
         changed = 0
         for k, (_, d) in enumerate(convs):
-            best = min(range(len(cands[k])), key=lambda r: times[k][r])
-            if times[k][best] > 0.97 * times[k][0]:
+            tot = group_time[keys[k]]
+            best = min(range(len(cands[k])), key=lambda r: tot[r])
+            if tot[best] > 0.97 * tot[0]:
                 best = 0
             d.tile_hint = cands[k][best]
             _TILE_CACHE[keys[k]] = cands[k][best]
