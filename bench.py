@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from flowtrack.pytorch_amd import parallel, synth  # noqa: E402
+from flowtrack.pytorch_amd.hip_ops import is_conv_call  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -65,19 +66,19 @@ def conv_roofline(prog, dtype_name, iters=5):
     of consecutive conv launches (kernels back to back as in the graph); the per-launch pass (an event after every
     launch, ~1 us of overhead each) only feeds the --layers table and the cross-check field."""
     times = prog.time_calls(iters=iters)
-    per_launch_conv_ms = sum(ms for name, ms in times if name.startswith("ft_conv2d_fwd"))
+    per_launch_conv_ms = sum(ms for name, ms in times if is_conv_call(name))
     conv_ms, other_ms = prog.time_conv_runs(iters=iters)
     total_ms = conv_ms + other_ms
-    n_conv = sum(1 for name, _ in times if name.startswith("ft_conv2d_fwd"))
+    n_conv = sum(1 for name, _ in times if is_conv_call(name))
     flops = prog.flops
     achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[dtype_name]
     per_layer = []
-    for label, call_idx, fl, _ in prog.conv_records:
+    for label, call_idx, fl in sorted([r[:3] for r in prog.conv_records] + list(prog.fused_records), key=lambda r: r[1]):
         ms = times[call_idx][1]
         per_layer.append((label, fl, ms))
     return {
-        "bound": "mfma", "kernel": "every ft_conv2d_fwd launch of the step: conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow), generic and few-output variants", "achieved": round(achieved, 2), "peak": peak,
+        "bound": "mfma", "kernel": "every conv launch of the step (ft_conv2d_fwd / ft_bottleneck_fwd): conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow), fused-bottleneck, generic and few-output variants", "achieved": round(achieved, 2), "peak": peak,
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
         "launches_per_step": n_conv, "flop_per_launch_avg": flops / max(n_conv, 1),
         "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),

@@ -40,6 +40,13 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class BottleneckDesc(ctypes.Structure):
+    """Mirror of `ft_bottleneck_desc`."""
+
+    _fields_ = [("dtype", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("P", c_int),
+                ("x_cstride", c_int), ("x_coff", c_int), ("y_cstride", c_int), ("y_coff", c_int)]
+
+
 class ConvGeometry(ctypes.Structure):
     """Mirror of `ft_conv_geometry`."""
 
@@ -76,6 +83,9 @@ _PROTOTYPES = {
     "ft_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "ft_conv_flops": (c_double, [POINTER(ConvDesc)]),
+    "ft_bottleneck_supported": (c_int, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p] + [c_void_p] * 9 + [c_void_p, c_void_p]),
+    "ft_bottleneck_flops": (c_double, [POINTER(BottleneckDesc)]),
     "ft_pack_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ft_unpack_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),

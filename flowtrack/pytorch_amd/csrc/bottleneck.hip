@@ -1,0 +1,438 @@
+// Whole-bottleneck fusion for the HBM-bound first ResNet stage (fp16): conv1 1x1 + bn1 + relu -> conv2 3x3 + bn2 + relu
+// -> conv3 1x1 + bn3 + identity residual + relu in ONE launch (reference: Bottleneck.forward, lib/pose/models/blocks.py:
+// 105-120, the blocks without a projection shortcut, layer1.1 / layer1.2 of resnet.py:29-36).
+//
+// Why: at 64x48 x 256 channels the three launches move 6.1 MB per crop through HBM (read x, write/read t1, write/read
+// t2, read the residual, write y) for 27 MFLOP/KB — they run at the HBM roof (134 us per block at batch 64, of which
+// the matrix pipe needs ~45).  Fused, a block reads x once and writes y once (3.0 MB per crop): t1 and t2 only ever
+// exist in LDS.
+//
+// One 256-thread workgroup owns an 8x16 (or 16x8) patch of output pixels of one image:
+//   phase 1  t1 = relu(bn1(W1 . x)) on the 10x18 HALO patch (180 pixels padded to 192; out-of-image pixels forced to 0 =
+//            conv2's zero padding): GEMM [64 co] x [192 px] x K=256.  x streams HBM -> LDS in 32-channel chunks through a
+//            3-slot DMA ring together with the matching K-slice of W1; result -> fp16 T1 in LDS (24 KiB).
+//   phase 2  t2 = relu(bn2(W2 * t1)): GEMM [64 co] x [128 px] x K=9*64; the pixel operand of every tap is read from T1
+//            at the tap's offset (the conv_halo_kernel idea), only W2 streams (one tap = 8 KiB per K-step) -> fp16 T2 (16 KiB).
+//   phase 3  y = relu(bn3(W3 . t2) + x): four 64-channel quarters, GEMM [64 co] x [128 px] x K=64 each; the residual is
+//            re-read from L2 in the accumulator layout, the fp16 tile is transposed through LDS for 16-byte coalesced stores.
+// 73 KiB of LDS -> two workgroups per CU, so one workgroup's phase-1 HBM stream overlaps the other's phases 2-3.
+// The halo makes phase 1 do 1.4x the 1x1's MACs (0.9 GMAC of 13.7 per block at batch 64): cheap next to 3 MB of HBM.
+#include <type_traits>
+
+#include "ft_common.h"
+
+namespace ft {
+namespace {
+
+struct BnkParams {
+  const char* x;
+  char* y;
+  const char *w1, *w2, *w3;
+  const float *s1, *b1, *s2, *b2, *s3, *b3;
+  int N, H, W;
+  int x_cstride, x_coff, y_cstride, y_coff;
+  unsigned x_bytes;
+  int tx, ty;      // patches per image along x / y
+  int total;       // workgroups
+};
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void unroll_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    unroll_for<N, I + 1>(f);
+  }
+}
+
+// s_barrier with a memory clobber: the builtin is IntrNoMem, LDS reads may be hoisted above it (see conv_igemm.hip)
+#define BNK_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+constexpr int kC = 256, kP = 64;                 // block width / planes this kernel is written for
+[[maybe_unused]] constexpr int kOffT1 = 0;                        // [192 halo px][64 ch] fp16, 128-byte rows, chunk ^= row & 7
+[[maybe_unused]] constexpr int kOffStg = 24576;                   // phase 1: 3 x (x chunk 12 KiB + W1 slice 4 KiB); phase 2: W2 ring 3 x 8 KiB
+[[maybe_unused]] constexpr int kStage1 = 16384, kXChunk = 12288;
+[[maybe_unused]] constexpr int kStage2 = 8192;
+[[maybe_unused]] constexpr int kOffT2 = 49152;                    // [128 px][64 ch] fp16, same row format as T1
+[[maybe_unused]] constexpr int kOffW3q0 = 65536;                  // quarter 0 of W3 (8 KiB), prefetched during phase 2
+[[maybe_unused]] constexpr int kOffOut = 24576;                   // phase 3: fp16 output quarter [128 px][64 co] for the coalesced store
+constexpr int kLdsBytes = 73728;
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
+  static_assert(NPIX <= 192, "halo patch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // XCD-aware order: block b runs on XCD b % 8; give each XCD one contiguous range of patches (neighbouring patches
+  // share their halo rows through that XCD's L2)
+  int logical;
+  {
+    const int b = blockIdx.x;
+    const int q = p.total >> 3, r = p.total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tiles_per_img = p.tx * p.ty;
+  const int n = logical / tiles_per_img;
+  const int trem = logical - n * tiles_per_img;
+  const int tyi = trem / p.tx, txi = trem - tyi * p.tx;
+  const int qy0 = tyi * TH, qx0 = txi * TW;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, kP * kC * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, kP * 9 * kP * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, kC * kP * 2, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- loader lanes --------------------------------------------------------------------------------------------
+  // a 1-KiB wave load covers 16 rows of 64 bytes: lane -> (row = lane / 4, 16-byte position = lane % 4); the LDS image is
+  // lane-linear, so the XOR swizzle is applied to the SOURCE position
+  const int lrow = lane >> 2, lpos = lane & 3;
+  unsigned x_voff[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int pp = (t * 4 + wave) * 16 + lrow;          // halo pixel
+    const int pr = pp / PW, pc = pp - pr * PW;
+    const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
+    unsigned v = kOOB;
+    if (pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      v = (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cstride + p.x_coff) * 2 + ((lpos ^ ((pp >> 2) & 3)) << 4));
+    x_voff[t] = v;
+  }
+  const int wr = wave * 16 + lrow;                       // weight row (output channel within a 64-row block)
+  const unsigned w_lc = (unsigned)((lpos ^ ((wr >> 2) & 3)) << 4);
+  const unsigned w1_voff = (unsigned)(wr * kC * 2) + w_lc;          // W1 [64][256]
+  const unsigned w2_voff = (unsigned)(wr * 9 * kP * 2) + w_lc;      // W2 [64][576]
+  const unsigned w3_voff = (unsigned)(wr * kP * 2) + w_lc;          // W3 [256][64], + quarter * 64 rows
+
+  auto load_stage1 = [&](int slot, int c) {              // chunk c: channels 32c .. 32c+31 of the halo patch + W1's K-slice
+    char* st = smem + kOffStg + slot * kStage1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, x_voff[t],
+                                               x_voff[t] == kOOB ? 0 : c * 64, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (lds_ptr)(st + kXChunk + wave * 1024), 16, w1_voff, c * 64, 0, 0);
+  };
+  auto load_stage2 = [&](int slot, int tap) {            // W2's tap: [64 co][64 ci] as two 32-channel halves
+    char* st = smem + kOffStg + slot * kStage2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + wave * 1024), 16, w2_voff, tap * 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + 4096 + wave * 1024), 16, w2_voff, tap * 128 + 64, 0, 0);
+  };
+  auto load_w3q = [&](int off, int q) {
+    char* st = smem + off;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + wave * 1024), 16, w3_voff, q * 64 * kP * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + 4096 + wave * 1024), 16, w3_voff, q * 64 * kP * 2 + 64, 0, 0);
+  };
+
+  // ================= phase 1: t1 = relu(bn1(W1 . x)) on the halo patch ==========================================
+  // wave -> output-channel tile (wave & 1) x three 32-pixel tiles (wave >> 1)
+  const int wc1 = wave & 1, wp1 = wave >> 1;
+  const int a1_row = wc1 * 32 + l31;
+  const int a1_off = a1_row * 64 + ((lhi ^ ((a1_row >> 2) & 3)) << 4);
+  int b1_off[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = (wp1 * 3 + j) * 32 + l31;
+    b1_off[j] = r * 64 + ((lhi ^ ((r >> 2) & 3)) << 4);
+  }
+  float16_t acc1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+
+  load_stage1(0, 0);
+  load_stage1(1, 1);
+  unroll_for<8>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (c < 7) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // chunk c landed; c+1 may fly
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BNK_BARRIER();
+    if constexpr (c + 2 < 8) load_stage1((c + 2) % 3, c + 2);
+    const char* st = smem + kOffStg + (c % 3) * kStage1;
+    uint4_t fa[2], fb[2][3];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      fa[kk] = *reinterpret_cast<const uint4_t*>(st + kXChunk + (a1_off ^ (kk << 5)));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fb[kk][j] = *reinterpret_cast<const uint4_t*>(st + (b1_off[j] ^ (kk << 5)));
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk]),
+                                                         __builtin_bit_cast(half8_t, fb[kk][j]), acc1[j], 0, 0, 0);
+  });
+  // the last chunk had vmcnt(0): nothing of this wave is in flight.  Every wave is past its last stage read once it
+  // reaches this barrier, so the ring region may be refilled with W2 taps while the epilogue runs.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNK_BARRIER();
+  load_stage2(0, 0);
+  load_stage2(1, 1);
+  {
+    char* t1 = smem + kOffT1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = (wp1 * 3 + j) * 32 + l31;
+      const int pr = r / PW, pc = r - pr * PW;
+      const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
+      const bool inside = r < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = wc1 * 32 + g * 8 + lhi * 4;
+        const float4_t sc = *reinterpret_cast<const float4_t*>(p.s1 + co);
+        const float4_t sh = *reinterpret_cast<const float4_t*>(p.b1 + co);
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc1[j][g * 4 + e] * sc[e] + sh[e];
+          v = v > 0.f ? v : 0.f;
+          h[e] = (half_t)(inside ? v : 0.f);
+        }
+        *reinterpret_cast<half4_t*>(t1 + r * 128 + ((((co >> 3) ^ (r & 7))) << 4) + lhi * 8) = h;
+      }
+    }
+  }
+
+  // ================= phase 2: t2 = relu(bn2(W2 * t1)), pixel operand from T1 ======================================
+  // wave -> output-channel tile (wave >> 1) x two 32-pixel tiles (wave & 1)
+  const int wc2 = wave >> 1, wp2 = wave & 1;
+  const int a2_row = wc2 * 32 + l31;
+  const int a2_off = a2_row * 64 + ((lhi ^ ((a2_row >> 2) & 3)) << 4);
+  int r0[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = wp2 * 64 + j * 32 + l31;
+    r0[j] = (m / TW) * PW + (m % TW);
+  }
+  float16_t acc2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+
+  unroll_for<9>([&](auto tc) {
+    constexpr int tap = decltype(tc)::value;
+    constexpr int ky = tap / 3, kx = tap % 3;
+    // loads younger than tap `tap`'s stage: the stage (or the W3 quarter) issued one step ago = 2 per wave
+    if constexpr (tap == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // also: T1 written
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    BNK_BARRIER();
+    if constexpr (tap + 2 < 9) load_stage2((tap + 2) % 3, tap + 2);
+    else if constexpr (tap + 2 == 9) load_w3q(kOffW3q0, 0);
+    const char* st = smem + kOffStg + (tap % 3) * kStage2;
+    const char* t1 = smem + kOffT1;
+    uint4_t fa[2][2], fb[2][2][2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[sl][kk] = *reinterpret_cast<const uint4_t*>(st + sl * 4096 + (a2_off ^ (kk << 5)));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0[j] + ky * PW + kx;
+      const int lsw = lhi ^ (r & 7);
+      const char* rowp = t1 + r * 128;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          fb[sl][kk][j] = *reinterpret_cast<const uint4_t*>(rowp + ((lsw ^ (sl * 4 + kk * 2)) << 4));
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[sl][kk]),
+                                                           __builtin_bit_cast(half8_t, fb[sl][kk][j]), acc2[j], 0, 0, 0);
+  });
+  {
+    char* t2 = smem + kOffT2;            // the T2 region overlaps only phase-1 stages, dead since the barrier above
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = wp2 * 64 + j * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = wc2 * 32 + g * 8 + lhi * 4;
+        const float4_t sc = *reinterpret_cast<const float4_t*>(p.s2 + co);
+        const float4_t sh = *reinterpret_cast<const float4_t*>(p.b2 + co);
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc2[j][g * 4 + e] * sc[e] + sh[e];
+          h[e] = (half_t)(v > 0.f ? v : 0.f);
+        }
+        *reinterpret_cast<half4_t*>(t2 + m * 128 + (((co >> 3) ^ (m & 7)) << 4) + lhi * 8) = h;
+      }
+    }
+  }
+  // T1 and the W2 ring are dead once every wave is here: quarters 1..3 of W3 go into the T1 region
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNK_BARRIER();
+  load_w3q(kOffT1, 1);
+  load_w3q(kOffT1 + 8192, 2);
+  load_w3q(kOffT1 + 16384, 3);
+
+  // ================= phase 3: y = relu(bn3(W3 . t2) + x), four quarters of 64 output channels ====================
+  uint4_t fb3[2][2][2];
+  {
+    const char* t2 = smem + kOffT2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = wp2 * 64 + j * 32 + l31;
+      const int lsw = lhi ^ (m & 7);
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          fb3[sl][kk][j] = *reinterpret_cast<const uint4_t*>(t2 + m * 128 + ((lsw ^ (sl * 4 + kk * 2)) << 4));
+    }
+  }
+  // accumulator-layout pixels of this lane (residual reads) and store-pass pixels of this thread
+  long long apix[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = wp2 * 64 + j * 32 + l31;
+    const int oy = qy0 + m / TW, ox = qx0 + m % TW;
+    apix[j] = (oy < p.H && ox < p.W) ? ((long long)n * p.H + oy) * p.W + ox : -1;
+  }
+  long long spix[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = (tid + 256 * i) >> 3;
+    const int oy = qy0 + m / TW, ox = qx0 + m % TW;
+    spix[i] = (oy < p.H && ox < p.W) ? ((long long)n * p.H + oy) * p.W + ox : -1;
+  }
+
+  unroll_for<4>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    // residual x[pix][q*64 + wc2*32 + g*8 + lhi*4 .. +3] in the accumulator layout (L2 hits: phase 1 just read them)
+    half4_t res[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        res[j][g] = half4_t{0, 0, 0, 0};
+        if (apix[j] >= 0)
+          res[j][g] = *reinterpret_cast<const half4_t*>(p.x + (apix[j] * p.x_cstride + p.x_coff + q * 64 + wc2 * 32 + g * 8 + lhi * 4) * 2);
+      }
+    // every load of this wave (incl. all W3 quarters) has landed; all waves are past the previous store pass
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BNK_BARRIER();
+    const char* wq = smem + (q == 0 ? kOffW3q0 : kOffT1 + (q - 1) * 8192);
+    float16_t acc3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4_t fa = *reinterpret_cast<const uint4_t*>(wq + sl * 4096 + (a2_off ^ (kk << 5)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa),
+                                                           __builtin_bit_cast(half8_t, fb3[sl][kk][j]), acc3[j], 0, 0, 0);
+      }
+    char* so = smem + kOffOut;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = wp2 * 64 + j * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wc2 * 32 + g * 8 + lhi * 4;       // channel within the quarter
+        const float4_t sc = *reinterpret_cast<const float4_t*>(p.s3 + q * 64 + col);
+        const float4_t sh = *reinterpret_cast<const float4_t*>(p.b3 + q * 64 + col);
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc3[j][g * 4 + e] * sc[e] + sh[e] + (float)res[j][g][e];
+          h[e] = (half_t)(v > 0.f ? v : 0.f);
+        }
+        *reinterpret_cast<half4_t*>(so + m * 128 + (((col >> 3) ^ (m & 7)) << 4) + lhi * 8) = h;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BNK_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, m = idx >> 3, ch = idx & 7;
+      const uint4_t v = *reinterpret_cast<const uint4_t*>(so + m * 128 + ((ch ^ (m & 7)) << 4));
+      if (spix[i] >= 0)
+        *reinterpret_cast<uint4_t*>(p.y + (spix[i] * p.y_cstride + p.y_coff + q * 64 + ch * 8) * 2) = v;
+    }
+  });
+#endif
+}
+
+static int supported(const ft_bottleneck_desc* d) {
+  if (!d) return FT_ERR_INVALID_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
+  if (d->dtype != FT_F16 || d->C != kC || d->P != kP) return FT_ERR_UNSUPPORTED;
+  if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
+  if (d->x_cstride < d->x_coff + kC || d->y_cstride < d->y_coff + kC) return FT_ERR_INVALID_ARG;
+  if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
+  return FT_OK;
+}
+
+}  // namespace
+}  // namespace ft
+
+extern "C" int ft_bottleneck_supported(const ft_bottleneck_desc* d) { return ft::supported(d); }
+
+extern "C" double ft_bottleneck_flops(const ft_bottleneck_desc* d) {
+  if (!d) return 0.0;
+  return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (double)d->P * d->C);
+}
+
+extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, const void* w1, const float* scale1,
+                                 const float* shift1, const void* w2, const float* scale2, const float* shift2,
+                                 const void* w3, const float* scale3, const float* shift3, void* y, ft_stream_t stream) {
+  using namespace ft;
+  const int st = supported(d);
+  if (st != FT_OK) return st;
+  if (!x || !w1 || !w2 || !w3 || !scale1 || !shift1 || !scale2 || !shift2 || !scale3 || !shift3 || !y) return FT_ERR_INVALID_ARG;
+  BnkParams p{};
+  p.x = static_cast<const char*>(x);
+  p.y = static_cast<char*>(y);
+  p.w1 = static_cast<const char*>(w1);
+  p.w2 = static_cast<const char*>(w2);
+  p.w3 = static_cast<const char*>(w3);
+  p.s1 = scale1; p.b1 = shift1; p.s2 = scale2; p.b2 = shift2; p.s3 = scale3; p.b3 = shift3;
+  p.N = d->N; p.H = d->H; p.W = d->W;
+  p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
+  p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->x_cstride * 2);
+  // 8 rows x 16 columns unless the width only divides by 8 (R101 at 384x288: 96x72 maps -> 16 rows x 8 columns)
+  const bool tall = d->W % 16 != 0 && d->W % 8 == 0;
+  const int tw = tall ? 8 : 16, th = 128 / tw;
+  p.tx = ceil_div(d->W, tw);
+  p.ty = ceil_div(d->H, th);
+  p.total = d->N * p.tx * p.ty;
+  hipStream_t s = as_stream(stream);
+  if (tall) {
+    auto k = bottleneck_fused_kernel<8>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
+  } else {
+    auto k = bottleneck_fused_kernel<16>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
+  }
+  FT_LAUNCH_CHECK("bottleneck_fused_kernel");
+  return FT_OK;
+}

@@ -91,6 +91,11 @@ def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int
 # --------------------------------------------------------------------------------------------
 # launch recording: a Program is the static launch sequence of one network at one input shape.
 # --------------------------------------------------------------------------------------------
+def is_conv_call(name: str) -> bool:
+    """Launches whose work is convolution MACs (the roofline's kernels): ft_conv2d_fwd[_ws] and ft_bottleneck_fwd."""
+    return name.startswith("ft_conv2d_fwd") or name == "ft_bottleneck_fwd"
+
+
 class Program:
     """Ordered list of C-ABI calls with fully bound arguments, replayable eagerly or as a HIP graph."""
 
@@ -103,6 +108,7 @@ class Program:
         self.graph_exec = None
         self.flops = 0.0
         self.conv_records: list = []  # (label, call index, flops, ConvDesc) for per-layer timing / roofline / tuning
+        self.fused_records: list = []  # (label, call index, flops) of the multi-conv launches (ft_bottleneck_fwd)
         # one scratch buffer shared by every conv of the plan (split-K partial tiles, ft_conv2d_fwd_ws); the calls hold
         # these two ctypes objects, whose values are filled in by _ensure_workspace() before the first launch
         self._ws_ptr, self._ws_size = ctypes.c_void_p(None), ctypes.c_size_t(0)
@@ -247,7 +253,7 @@ class Program:
         Returns (conv_ms, other_ms) averaged over `iters` passes."""
         self._ensure_workspace()
         lib, sh = self.lib, self.stream_handle
-        is_conv = [name.startswith("ft_conv2d_fwd") for name, _ in self.calls]
+        is_conv = [is_conv_call(name) for name, _ in self.calls]
         bounds = [0] + [i for i in range(1, len(is_conv)) if is_conv[i] != is_conv[i - 1]] + [len(is_conv)]
         evs = []
         for _ in bounds:
@@ -649,6 +655,64 @@ class FusedShortcutConv:
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
         prog.add("ft_conv2d_fwd", ctypes.byref(d), t2.t.data_ptr(), w.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
                  y.t.data_ptr(), keep=(d, t2.t, x.t, y.t, w, shift))
+
+
+def bottleneck_fusable(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView) -> bool:
+    """True when ft_bottleneck_fwd covers this identity-shortcut block (fp16, 256 -> 64 -> 64 -> 256, stride 1)."""
+    if x.t.dtype != torch.float16 or x.rowpacked or (x.N, x.H, x.W, x.C) != (y.N, y.H, y.W, y.C):
+        return False
+    if (c1.k, c2.k, c3.k) != (1, 3, 1) or (c2.stride, c2.pad) != (1, 1) or c1.stride != 1 or c3.stride != 1:
+        return False
+    if (c1.cin, c1.cout, c2.cin, c2.cout, c3.cin, c3.cout) != (x.C, c2.cin, c2.cin, c2.cin, c2.cin, x.C):
+        return False
+    if any(c.transposed or c.tail_cout or c.act != ACT_CODES["relu"] or c._bn is None for c in (c1, c2, c3)):
+        return False
+    d = _bottleneck_desc(x, y, c2.cin)
+    return _lib.load().ft_bottleneck_supported(ctypes.byref(d)) == 0
+
+
+def _bottleneck_desc(x: ActView, y: ActView, planes: int) -> _lib.BottleneckDesc:
+    d = _lib.BottleneckDesc()
+    d.dtype = _lib.dtype_code(x.t.dtype)
+    d.N, d.H, d.W, d.C, d.P = x.N, x.H, x.W, x.C, planes
+    d.x_cstride, d.x_coff, d.y_cstride, d.y_coff = x.cstride, x.coff, y.cstride, y.coff
+    return d
+
+
+def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
+                      label: str) -> None:
+    """conv1 + bn1 + relu -> conv2 + bn2 + relu -> conv3 + bn3 + residual(x) + relu as ONE launch (ft_bottleneck_fwd);
+    the packed weights / folded BN are those the three FusedConv layers would use on channel-aligned views."""
+    lib = _lib.load()
+    if y.t.data_ptr() == x.t.data_ptr():
+        raise FlowtrackHipError(f"{label}: the fused bottleneck cannot run in place")
+    planes = c2.cin
+
+    def packed(conv: "FusedConv", want):
+        d = ConvDesc()
+        d.dtype = conv.code
+        d.N, d.Hi, d.Wi, d.Ho, d.Wo = x.N, x.H, x.W, x.H, x.W
+        d.Cin, d.x_cstride, d.x_coff = conv.cin, act_stride(conv.cin), 0
+        d.Cout, d.kh, d.kw, d.stride, d.pad = conv.cout, conv.k, conv.k, 1, conv.pad
+        d.y_cstride, d.y_coff, d.out_layout = act_stride(conv.cout), 0, FT_LAYOUT_NHWC
+        d.act = conv.act
+        g = conv_geometry(d)
+        if (g.cout_pad, g.kpad, g.nphases) != want:
+            raise FlowtrackHipError(f"{label}: unexpected packed layout {(g.cout_pad, g.kpad)} for the fused bottleneck")
+        w, _, scale, shift = conv._packed_for(d)
+        return w, scale, shift
+
+    w1, s1, b1 = packed(c1, (planes, x.C, 1))
+    w2, s2, b2 = packed(c2, (planes, 9 * planes, 1))
+    w3, s3, b3 = packed(c3, (x.C, planes, 1))
+    d = _bottleneck_desc(x, y, planes)
+    check(lib.ft_bottleneck_supported(ctypes.byref(d)), "ft_bottleneck_supported")
+    flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
+    prog.flops += flops
+    prog.fused_records.append((label, len(prog.calls), flops))
+    prog.add("ft_bottleneck_fwd", ctypes.byref(d), x.t.data_ptr(), w1.data_ptr(), s1.data_ptr(), b1.data_ptr(),
+             w2.data_ptr(), s2.data_ptr(), b2.data_ptr(), w3.data_ptr(), s3.data_ptr(), b3.data_ptr(), y.t.data_ptr(),
+             keep=(d, x.t, y.t, w1, s1, b1, w2, s2, b2, w3, s3, b3))
 
 
 # --------------------------------------------------------------------------------------------

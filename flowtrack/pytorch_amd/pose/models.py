@@ -24,7 +24,8 @@ import torch
 import torch.nn as nn
 
 from ..engine import HipModule
-from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, new_act, new_rowpacked_act,
+from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable, new_act,
+                       new_rowpacked_act, record_bottleneck,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -63,6 +64,8 @@ class _PosePlan:
 class DeconvResnet(HipModule):
     #: fold each block-0 projection shortcut into its conv3 launch (FusedShortcutConv); FT_FUSE_SHORTCUT=0 keeps them apart
     fuse_shortcut: bool = os.environ.get("FT_FUSE_SHORTCUT", "1") != "0"
+    #: identity-shortcut blocks of the 256-wide stage as one launch (ft_bottleneck_fwd); FT_FUSE_BOTTLENECK=0 keeps 3 convs
+    fuse_bottleneck: bool = os.environ.get("FT_FUSE_BOTTLENECK", "1") != "0"
     #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
     #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
     keypoints_in_plan = None
@@ -149,9 +152,14 @@ class DeconvResnet(HipModule):
                 c1 = self.fused(name + ".conv1", blk.conv1.weight, bn=blk.bn1.as_dict(), act="relu", **mk)
                 c2 = self.fused(name + ".conv2", blk.conv2.weight, stride=s, pad=1, bn=blk.bn2.as_dict(), act="relu", **mk)
                 c3 = self.fused(name + ".conv3", blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", **mk)
+                out = new_act(B, Ho, Wo, planes * 4, dtype, device)
+                if self.fuse_bottleneck and not len(blk.downsample) and s == 1 and bottleneck_fusable(c1, c2, c3, cur, out):
+                    # the whole block in one launch: t1 / t2 never leave LDS (HBM-bound 256-wide stage)
+                    record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
+                    cur = out
+                    continue
                 t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
                 t2 = new_act(B, Ho, Wo, planes, dtype, device)
-                out = new_act(B, Ho, Wo, planes * 4, dtype, device)
                 c1.record(prog, cur, t1)
                 c2.record(prog, t1, t2)
                 if len(blk.downsample) and self.fuse_shortcut:

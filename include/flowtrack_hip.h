@@ -182,6 +182,30 @@ int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int max);
 /* algorithmic FLOPs (2*MACs, unpadded) of one ft_conv2d_fwd call */
 double ft_conv_flops(const ft_conv_desc* d);
 
+/* ---- whole-bottleneck fusion (fp16) --------------------------------------------------------------
+ * One launch for an identity-shortcut Bottleneck (reference: Bottleneck.forward, lib/pose/models/blocks.py:105-120,
+ * the blocks whose `downsample` is empty, resnet.py:29-36):
+ *   y = relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(relu(bn1(conv1_1x1(x)))))))) + x)
+ * t1 / t2 live in LDS only; x is read once (+ halo / residual re-reads from L2), y written once.
+ * Supported: dtype FT_F16, C = 256, P = 64, stride 1 (ResNet layer1.1+); y must not alias x.
+ * w1 / w2 / w3 are the ft_conv_pack_geometry layouts of the three convs on channel-aligned views
+ * ([64][256], [64][9*64] with k = (ky*3+kx)*64 + ci, [256][64]); scale / shift = folded BN, float[Cout]. */
+typedef struct ft_bottleneck_desc {
+  int dtype;
+  int N, H, W;            /* block input = output size */
+  int C, P;               /* block width (in = out channels) and planes */
+  int x_cstride, x_coff;  /* NHWC views, element units, multiples of 8 */
+  int y_cstride, y_coff;
+} ft_bottleneck_desc;
+int ft_bottleneck_supported(const ft_bottleneck_desc* d);   /* FT_OK or FT_ERR_UNSUPPORTED / FT_ERR_INVALID_ARG */
+int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,
+                      const void* w1, const float* scale1, const float* shift1,
+                      const void* w2, const float* scale2, const float* shift2,
+                      const void* w3, const float* scale3, const float* shift3,
+                      void* y, ft_stream_t stream);
+/* algorithmic FLOPs of the three convs (2*MACs, no halo recompute) */
+double ft_bottleneck_flops(const ft_bottleneck_desc* d);
+
 /* ---- layout / pooling helpers -------------------------------------------- */
 /* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,wpitch,cpad]: pixel x lands in column lpad + x, channels
  * >= C and all other columns are zeroed (wpitch = W, lpad = 0: plain NHWC; cpad multiple of 4).

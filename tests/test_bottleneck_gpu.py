@@ -1,0 +1,98 @@
+"""ft_bottleneck_fwd (whole identity-shortcut Bottleneck in one launch, t1 / t2 in LDS only) vs the CPU oracle for
+the stock layers (torch CPU fp32 functional = the reference's own arithmetic for blocks.py:105-120) and vs the three
+separate ft_conv2d_fwd launches it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from flowtrack.pytorch_amd import synth
+from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv, act_stride, bottleneck_fusable, record_bottleneck
+from util import make_program, nchw_to_view, run_program, view_to_nchw
+
+pytestmark = pytest.mark.gpu
+
+# (name, N, H, W, x channel stride, x channel offset)
+CASES = [
+    ("r50_map_64x48", 2, 64, 48, 256, 0),            # 8 x 16 patches, exact
+    ("r101_map_96x72", 1, 96, 72, 256, 0),           # width divides by 8 only: 16 x 8 patches
+    ("ragged_y_40x24", 2, 40, 24, 256, 0),           # 16 x 8 patches, ragged in y
+    ("ragged_xy_13x20", 3, 13, 20, 256, 0),          # 8 x 16 patches, ragged both ways
+    ("tiny_5x3", 1, 5, 3, 256, 0),                   # one patch, mostly padding
+    ("view_offset", 1, 16, 16, 320, 32),             # input is a channel slice of a wider buffer
+    ("many_patches_recycle", 24, 64, 48, 256, 0),    # 2304 workgroups: > 4 rounds on 512 slots (LDS reuse across workgroups)
+]
+
+
+def _bn(seed, name, c):
+    return {"weight": synth.uniform(seed, name + "g", (c,), 0.5, 1.5), "bias": synth.normal(seed, name + "b", (c,), 0.1),
+            "running_mean": synth.normal(seed, name + "m", (c,), 0.1), "running_var": synth.uniform(seed, name + "v", (c,), 0.5, 1.5),
+            "eps": 1e-5}
+
+
+def _bnf(y, bn):
+    return F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], training=False, eps=1e-5)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_fused_bottleneck_matches_oracle_and_the_three_launches(hip_lib, case):
+    name, N, H, W, xcs, xoff = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 21
+    C, P = 256, 64
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+    t2 = F.relu(_bnf(F.conv2d(t1, w2, padding=1), bn2))
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + x)
+
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    c3 = FusedConv(w3, bn=bn3, label="conv3", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    if xoff:
+        xv.t[..., :xoff] = 7.0          # neighbours of the slice must not leak in
+    y_fused = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)   # output into a slice, too
+    assert bottleneck_fusable(c1, c2, c3, xv, y_fused)
+    prog = make_program()
+    record_bottleneck(prog, c1, c2, c3, xv, y_fused, name)
+    run_program(prog)
+    got = view_to_nchw(y_fused)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: fused bottleneck vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    assert torch.all(y_fused.t[..., :32] == 3.0), "channels outside the output slice were written"
+
+    # the three launches it replaces: same fp16 roundings of t1 / t2, only the fp32 summation order may differ
+    t1v = ActView(torch.zeros((N, H, W, act_stride(P)), dtype=dtype, device=dev), P, 0)
+    t2v = ActView(torch.zeros((N, H, W, act_stride(P)), dtype=dtype, device=dev), P, 0)
+    y3 = ActView(torch.zeros((N, H, W, C), dtype=dtype, device=dev), C, 0)
+    prog3 = make_program()
+    c1.record(prog3, xv, t1v)
+    c2.record(prog3, t1v, t2v)
+    c3.record(prog3, t2v, y3, residual=xv)
+    run_program(prog3)
+    sep = view_to_nchw(y3)
+    diff = (got - sep).abs()
+    assert diff.max().item() <= 1e-2 * scale, f"{name}: fused vs separate launches max abs diff {diff.max().item():.3e}"
+    assert (diff > 0).float().mean().item() < 0.05, "fused and separate launches should agree bit for bit almost everywhere"
+
+    # determinism: same bits on a second run (poisoned output first)
+    y_fused.t.fill_(5.0)
+    run_program(prog)
+    assert torch.equal(view_to_nchw(y_fused), got)
+
+
+def test_fused_bottleneck_rejects_other_blocks(hip_lib):
+    from flowtrack.pytorch_amd import _lib
+    import ctypes
+    d = _lib.BottleneckDesc()
+    d.dtype, d.N, d.H, d.W, d.C, d.P = _lib.FT_F16, 1, 8, 8, 512, 128
+    d.x_cstride = d.y_cstride = 512
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(d)) == 2
+    d.C, d.P, d.x_cstride, d.y_cstride, d.dtype = 256, 64, 256, 256, _lib.FT_F32
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(d)) == 2
+    d.dtype = _lib.FT_F16
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(d)) == 0
