@@ -17,6 +17,8 @@
 //            re-read from L2 in the accumulator layout, the fp16 tile is transposed through LDS for 16-byte coalesced stores.
 // 73 KiB of LDS -> two workgroups per CU, so one workgroup's phase-1 HBM stream overlaps the other's phases 2-3.
 // The halo makes phase 1 do 1.4x the 1x1's MACs (0.9 GMAC of 13.7 per block at batch 64): cheap next to 3 MB of HBM.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "ft_common.h"
@@ -28,12 +30,13 @@ struct BnkParams {
   const char* x;
   char* y;
   const char *w1, *w2, *w3;
-  const float *s1, *b1, *s2, *b2, *s3, *b3;
+  const char* tab;   // float [s1 64 | b1 64 | s2 64 | b2 64 | s3 256 | b3 256]
   int N, H, W;
   int x_cstride, x_coff, y_cstride, y_coff;
   unsigned x_bytes;
   int tx, ty;      // patches per image along x / y
   int total;       // workgroups
+  int dbg;         // FT_BNK_DBG (dev): 1 no x loads, 2 no residual loads, 4 no stores
 };
 
 template <int N, int I = 0, typename F>
@@ -48,14 +51,13 @@ __device__ __forceinline__ void unroll_for(F&& f) {
 #define BNK_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 constexpr int kC = 256, kP = 64;                 // block width / planes this kernel is written for
-[[maybe_unused]] constexpr int kOffT1 = 0;                        // [192 halo px][64 ch] fp16, 128-byte rows, chunk ^= row & 7
-[[maybe_unused]] constexpr int kOffStg = 24576;                   // phase 1: 3 x (x chunk 12 KiB + W1 slice 4 KiB); phase 2: W2 ring 3 x 8 KiB
+// LDS map (bytes).  Phase 1: four 16-KiB stages (x chunk 12 KiB + W1 K-slice 4 KiB) at 0 .. 64 Ki.
+// Phase 2: T1 at 0 (24 KiB), W2 ring slots 1..3 at 24 / 32 / 40 Ki and slot 0 at 64 Ki, T2 at 48 Ki (16 KiB).
+// Phase 3: W3 quarters in the ring slots, output staging A at 0 and B at 48 Ki (16 KiB each).  Folded-BN table at 72 Ki.
 [[maybe_unused]] constexpr int kStage1 = 16384, kXChunk = 12288;
-[[maybe_unused]] constexpr int kStage2 = 8192;
-[[maybe_unused]] constexpr int kOffT2 = 49152;                    // [128 px][64 ch] fp16, same row format as T1
-[[maybe_unused]] constexpr int kOffW3q0 = 65536;                  // quarter 0 of W3 (8 KiB), prefetched during phase 2
-[[maybe_unused]] constexpr int kOffOut = 24576;                   // phase 3: fp16 output quarter [128 px][64 co] for the coalesced store
-constexpr int kLdsBytes = 73728;
+[[maybe_unused]] constexpr int kOffT1 = 0, kOffT2 = 49152, kOffOutA = 0, kOffOutB = 49152, kOffTab = 73728;
+constexpr int kLdsBytes = 76800;
+__device__ __forceinline__ constexpr int ring_slot(int i) { return i == 0 ? 65536 : 24576 + (i - 1) * 8192; }
 
 template <int TW>
 __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParams p) {
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, kP * kC * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, kP * 9 * kP * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, kC * kP * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 3072, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
   // ---- loader lanes --------------------------------------------------------------------------------------------
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     const int pr = pp / PW, pc = pp - pr * PW;
     const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
     unsigned v = kOOB;
-    if (pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+    if (pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 1))
       v = (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cstride + p.x_coff) * 2 + ((lpos ^ ((pp >> 2) & 3)) << 4));
     x_voff[t] = v;
   }
@@ -110,23 +113,35 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   const unsigned w3_voff = (unsigned)(wr * kP * 2) + w_lc;          // W3 [256][64], + quarter * 64 rows
 
   auto load_stage1 = [&](int slot, int c) {              // chunk c: channels 32c .. 32c+31 of the halo patch + W1's K-slice
-    char* st = smem + kOffStg + slot * kStage1;
+    char* st = smem + slot * kStage1;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, x_voff[t],
                                                x_voff[t] == kOOB ? 0 : c * 64, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (lds_ptr)(st + kXChunk + wave * 1024), 16, w1_voff, c * 64, 0, 0);
   };
-  auto load_stage2 = [&](int slot, int tap) {            // W2's tap: [64 co][64 ci] as two 32-channel halves
-    char* st = smem + kOffStg + slot * kStage2;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + wave * 1024), 16, w2_voff, tap * 128, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + 4096 + wave * 1024), 16, w2_voff, tap * 128 + 64, 0, 0);
+  // ring items 0..8 = the nine taps of W2 ([64 co][64 ci] as two 32-channel halves), items 9..11 = quarters 0..2 of W3
+  auto load_item = [&](int item) {
+    char* st = smem + ring_slot(item & 3);
+    if (item < 9) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + wave * 1024), 16, w2_voff, item * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + 4096 + wave * 1024), 16, w2_voff, item * 128 + 64, 0, 0);
+    } else {
+      const int q = item - 9;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + wave * 1024), 16, w3_voff, q * 64 * kP * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + 4096 + wave * 1024), 16, w3_voff, q * 64 * kP * 2 + 64, 0, 0);
+    }
   };
-  auto load_w3q = [&](int off, int q) {
-    char* st = smem + off;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + wave * 1024), 16, w3_voff, q * 64 * kP * 2, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + 4096 + wave * 1024), 16, w3_voff, q * 64 * kP * 2 + 64, 0, 0);
-  };
+
+  // oldest loads of every wave: the folded-BN table (3 KiB, waves 0..2) and W2's first tap (its ring slot lies outside the
+  // phase-1 stages) — both land long before they are needed and sit in front of every counted wait below
+  if (wave < 3)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_tab, (lds_ptr)(smem + kOffTab + wave * 1024), 16, (unsigned)(lane * 16), wave * 1024, 0, 0);
+  load_item(0);
+  const float* tab = reinterpret_cast<const float*>(smem + kOffTab);
+  unsigned long long ts[8];
+#define BNK_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  BNK_TS(0);
 
   // ================= phase 1: t1 = relu(bn1(W1 . x)) on the halo patch ==========================================
   // wave -> output-channel tile (wave & 1) x three 32-pixel tiles (wave >> 1)
@@ -145,15 +160,31 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
 
+  // residual = the block input at the patch's own 128 pixels, picked up in the ACCUMULATOR layout of phase 3 (lane ->
+  // pixel wp2*64 + j*32 + l31, channels q*64 + wc2*32 + g*8 + lhi*4 .. +3) from the phase-1 stages as they pass through
+  // LDS: chunk c = channels 32c .. 32c+31 = quarter c / 2, half (wc2) c % 2.  No second trip to L2 for them.
+  const int wc2 = wave >> 1, wp2 = wave & 1;
+  int rc_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = wp2 * 64 + j * 32 + l31;
+    const int rc = (m / TW + 1) * PW + (m % TW + 1);
+    rc_off[j] = rc * 64 + lhi * 8 + (((rc >> 2) & 3) << 4);    // chunk g of the row sits at (g ^ swizzle) << 4
+  }
+  half4_t res[4][2][4];
+
   load_stage1(0, 0);
   load_stage1(1, 1);
+  load_stage1(2, 2);
   unroll_for<8>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    if constexpr (c < 7) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // chunk c landed; c+1 may fly
+    // chunk c has landed; the (up to two) younger stages = 4 loads per wave each stay in flight
+    if constexpr (c <= 5) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (c == 6) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BNK_BARRIER();
-    if constexpr (c + 2 < 8) load_stage1((c + 2) % 3, c + 2);
-    const char* st = smem + kOffStg + (c % 3) * kStage1;
+    if constexpr (c + 3 < 8) load_stage1((c + 3) & 3, c + 3);
+    const char* st = smem + (c & 3) * kStage1;
     uint4_t fa[2], fb[2][3];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -167,41 +198,51 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       for (int j = 0; j < 3; ++j)
         acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk]),
                                                          __builtin_bit_cast(half8_t, fb[kk][j]), acc1[j], 0, 0, 0);
+    if (wc2 == (c & 1)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) res[c >> 1][j][g] = *reinterpret_cast<const half4_t*>(st + (rc_off[j] ^ (g << 4)));
+    }
   });
   // the last chunk had vmcnt(0): nothing of this wave is in flight.  Every wave is past its last stage read once it
-  // reaches this barrier, so the ring region may be refilled with W2 taps while the epilogue runs.
+  // reaches this barrier: the stage region becomes T1 + the W2 ring.
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNK_BARRIER();
-  load_stage2(0, 0);
-  load_stage2(1, 1);
+  BNK_TS(1);
+  load_item(1);
+  load_item(2);
   {
     char* t1 = smem + kOffT1;
+    float4_t sc[4], sh[4];               // read once: the compiler cannot hoist LDS reads over the T1 writes itself
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      sc[g] = *reinterpret_cast<const float4_t*>(tab + wc1 * 32 + g * 8 + lhi * 4);
+      sh[g] = *reinterpret_cast<const float4_t*>(tab + 64 + wc1 * 32 + g * 8 + lhi * 4);
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int r = (wp1 * 3 + j) * 32 + l31;
       const int pr = r / PW, pc = r - pr * PW;
       const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
       const bool inside = r < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      char* rowp = t1 + r * 128 + lhi * 8;
+      const int rsw = (r & 7) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = wc1 * 32 + g * 8 + lhi * 4;
-        const float4_t sc = *reinterpret_cast<const float4_t*>(p.s1 + co);
-        const float4_t sh = *reinterpret_cast<const float4_t*>(p.b1 + co);
         half4_t h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc1[j][g * 4 + e] * sc[e] + sh[e];
-          v = v > 0.f ? v : 0.f;
-          h[e] = (half_t)(inside ? v : 0.f);
-        }
-        *reinterpret_cast<half4_t*>(t1 + r * 128 + ((((co >> 3) ^ (r & 7))) << 4) + lhi * 8) = h;
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)__builtin_fmaxf(acc1[j][g * 4 + e] * sc[g][e] + sh[g][e], 0.f);
+        uint2 hb = __builtin_bit_cast(uint2, h);
+        hb.x = inside ? hb.x : 0u;       // out-of-image halo pixels are conv2's zero padding, not relu(bn1(0))
+        hb.y = inside ? hb.y : 0u;
+        *reinterpret_cast<uint2*>(rowp + ((((wc1 * 4 + g) << 4)) ^ rsw)) = hb;
       }
     }
   }
-
+  BNK_TS(2);
   // ================= phase 2: t2 = relu(bn2(W2 * t1)), pixel operand from T1 ======================================
-  // wave -> output-channel tile (wave >> 1) x two 32-pixel tiles (wave & 1)
-  const int wc2 = wave >> 1, wp2 = wave & 1;
+  // wave -> output-channel tile wc2 = wave >> 1 x two 32-pixel tiles (wp2 = wave & 1)
   const int a2_row = wc2 * 32 + l31;
   const int a2_off = a2_row * 64 + ((lhi ^ ((a2_row >> 2) & 3)) << 4);
   int r0[2];
@@ -219,13 +260,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   unroll_for<9>([&](auto tc) {
     constexpr int tap = decltype(tc)::value;
     constexpr int ky = tap / 3, kx = tap % 3;
-    // loads younger than tap `tap`'s stage: the stage (or the W3 quarter) issued one step ago = 2 per wave
-    if constexpr (tap == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // also: T1 written
-    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    // item `tap` has landed; the two younger items (2 loads per wave each) stay in flight.  (tap 0: also T1 written)
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     BNK_BARRIER();
-    if constexpr (tap + 2 < 9) load_stage2((tap + 2) % 3, tap + 2);
-    else if constexpr (tap + 2 == 9) load_w3q(kOffW3q0, 0);
-    const char* st = smem + kOffStg + (tap % 3) * kStage2;
+    load_item(tap + 3);                                  // taps 3..8, then quarters 0..2 of W3
+    const char* st = smem + ring_slot(tap & 3);
     const char* t1 = smem + kOffT1;
     uint4_t fa[2][2], fb[2][2][2];
 #pragma unroll
@@ -252,32 +291,39 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
           acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[sl][kk]),
                                                            __builtin_bit_cast(half8_t, fb[sl][kk][j]), acc2[j], 0, 0, 0);
   });
+
+  BNK_TS(3);
   {
-    char* t2 = smem + kOffT2;            // the T2 region overlaps only phase-1 stages, dead since the barrier above
+    char* t2 = smem + kOffT2;            // the T2 region held only a phase-1 stage, dead since the barrier after phase 1
+    float4_t sc[4], sh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      sc[g] = *reinterpret_cast<const float4_t*>(tab + 128 + wc2 * 32 + g * 8 + lhi * 4);
+      sh[g] = *reinterpret_cast<const float4_t*>(tab + 192 + wc2 * 32 + g * 8 + lhi * 4);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = wp2 * 64 + j * 32 + l31;
+      char* rowp = t2 + m * 128 + lhi * 8;
+      const int msw = (m & 7) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = wc2 * 32 + g * 8 + lhi * 4;
-        const float4_t sc = *reinterpret_cast<const float4_t*>(p.s2 + co);
-        const float4_t sh = *reinterpret_cast<const float4_t*>(p.b2 + co);
         half4_t h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = acc2[j][g * 4 + e] * sc[e] + sh[e];
-          h[e] = (half_t)(v > 0.f ? v : 0.f);
-        }
-        *reinterpret_cast<half4_t*>(t2 + m * 128 + (((co >> 3) ^ (m & 7)) << 4) + lhi * 8) = h;
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)__builtin_fmaxf(acc2[j][g * 4 + e] * sc[g][e] + sh[g][e], 0.f);
+        *reinterpret_cast<half4_t*>(rowp + (((wc2 * 4 + g) << 4) ^ msw)) = h;
       }
     }
   }
-  // T1 and the W2 ring are dead once every wave is here: quarters 1..3 of W3 go into the T1 region
+  // T2 complete, T1 and the last tap's slot dead once every wave is here: the last quarter of W3 goes into that slot
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNK_BARRIER();
-  load_w3q(kOffT1, 1);
-  load_w3q(kOffT1 + 8192, 2);
-  load_w3q(kOffT1 + 16384, 3);
+  BNK_TS(4);
+  {
+    char* st = smem + ring_slot(0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + wave * 1024), 16, w3_voff, 3 * 64 * kP * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + 4096 + wave * 1024), 16, w3_voff, 3 * 64 * kP * 2 + 64, 0, 0);
+  }
 
   // ================= phase 3: y = relu(bn3(W3 . t2) + x), four quarters of 64 output channels ====================
   uint4_t fb3[2][2][2];
@@ -294,14 +340,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
           fb3[sl][kk][j] = *reinterpret_cast<const uint4_t*>(t2 + m * 128 + ((lsw ^ (sl * 4 + kk * 2)) << 4));
     }
   }
-  // accumulator-layout pixels of this lane (residual reads) and store-pass pixels of this thread
-  long long apix[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = wp2 * 64 + j * 32 + l31;
-    const int oy = qy0 + m / TW, ox = qx0 + m % TW;
-    apix[j] = (oy < p.H && ox < p.W) ? ((long long)n * p.H + oy) * p.W + ox : -1;
-  }
   long long spix[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -309,23 +347,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     const int oy = qy0 + m / TW, ox = qx0 + m % TW;
     spix[i] = (oy < p.H && ox < p.W) ? ((long long)n * p.H + oy) * p.W + ox : -1;
   }
+  // every W3 quarter and the residuals have landed; every wave holds its T2 fragments (staging B reuses the T2 region)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  BNK_BARRIER();
+  BNK_TS(5);
 
   unroll_for<4>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    // residual x[pix][q*64 + wc2*32 + g*8 + lhi*4 .. +3] in the accumulator layout (L2 hits: phase 1 just read them)
-    half4_t res[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        res[j][g] = half4_t{0, 0, 0, 0};
-        if (apix[j] >= 0)
-          res[j][g] = *reinterpret_cast<const half4_t*>(p.x + (apix[j] * p.x_cstride + p.x_coff + q * 64 + wc2 * 32 + g * 8 + lhi * 4) * 2);
-      }
-    // every load of this wave (incl. all W3 quarters) has landed; all waves are past the previous store pass
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    BNK_BARRIER();
-    const char* wq = smem + (q == 0 ? kOffW3q0 : kOffT1 + (q - 1) * 8192);
+    const char* wq = smem + ring_slot((q + 1) & 3);
     float16_t acc3[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -341,34 +370,48 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
           acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa),
                                                            __builtin_bit_cast(half8_t, fb3[sl][kk][j]), acc3[j], 0, 0, 0);
       }
-    char* so = smem + kOffOut;
+    char* so = smem + ((q & 1) ? kOffOutB : kOffOutA);
+    float4_t sc[4], sh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      sc[g] = *reinterpret_cast<const float4_t*>(tab + 256 + q * 64 + wc2 * 32 + g * 8 + lhi * 4);
+      sh[g] = *reinterpret_cast<const float4_t*>(tab + 512 + q * 64 + wc2 * 32 + g * 8 + lhi * 4);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = wp2 * 64 + j * 32 + l31;
+      char* rowp = so + m * 128 + lhi * 8;
+      const int msw = (m & 7) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int col = wc2 * 32 + g * 8 + lhi * 4;       // channel within the quarter
-        const float4_t sc = *reinterpret_cast<const float4_t*>(p.s3 + q * 64 + col);
-        const float4_t sh = *reinterpret_cast<const float4_t*>(p.b3 + q * 64 + col);
         half4_t h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = acc3[j][g * 4 + e] * sc[e] + sh[e] + (float)res[j][g][e];
-          h[e] = (half_t)(v > 0.f ? v : 0.f);
-        }
-        *reinterpret_cast<half4_t*>(so + m * 128 + (((col >> 3) ^ (m & 7)) << 4) + lhi * 8) = h;
+        for (int e = 0; e < 4; ++e)
+          h[e] = (half_t)__builtin_fmaxf(acc3[j][g * 4 + e] * sc[g][e] + sh[g][e] + (float)res[q][j][g][e], 0.f);
+        *reinterpret_cast<half4_t*>(rowp + (((wc2 * 4 + g) << 4) ^ msw)) = h;
       }
     }
+    // one barrier per quarter: the two staging buffers alternate, a buffer's previous readers are two barriers behind
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BNK_BARRIER();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i, m = idx >> 3, ch = idx & 7;
       const uint4_t v = *reinterpret_cast<const uint4_t*>(so + m * 128 + ((ch ^ (m & 7)) << 4));
-      if (spix[i] >= 0)
+      if (spix[i] >= 0 && !(p.dbg & 4))
         *reinterpret_cast<uint4_t*>(p.y + (spix[i] * p.y_cstride + p.y_coff + q * 64 + ch * 8) * 2) = v;
     }
   });
+  if (p.dbg & 32) {       // dev: phase timestamps of wave 0 over the tile's first output pixel (output is garbage then)
+    ts[6] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[7] = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y + ((((long long)n * p.H + qy0) * p.W + qx0) * p.y_cstride + p.y_coff) * 2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    }
+  }
 #endif
 }
 
@@ -392,20 +435,19 @@ extern "C" double ft_bottleneck_flops(const ft_bottleneck_desc* d) {
   return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (double)d->P * d->C);
 }
 
-extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, const void* w1, const float* scale1,
-                                 const float* shift1, const void* w2, const float* scale2, const float* shift2,
-                                 const void* w3, const float* scale3, const float* shift3, void* y, ft_stream_t stream) {
+extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, const void* w1, const void* w2, const void* w3,
+                                 const float* scale_shift, void* y, ft_stream_t stream) {
   using namespace ft;
   const int st = supported(d);
   if (st != FT_OK) return st;
-  if (!x || !w1 || !w2 || !w3 || !scale1 || !shift1 || !scale2 || !shift2 || !scale3 || !shift3 || !y) return FT_ERR_INVALID_ARG;
+  if (!x || !w1 || !w2 || !w3 || !scale_shift || !y) return FT_ERR_INVALID_ARG;
   BnkParams p{};
   p.x = static_cast<const char*>(x);
   p.y = static_cast<char*>(y);
   p.w1 = static_cast<const char*>(w1);
   p.w2 = static_cast<const char*>(w2);
   p.w3 = static_cast<const char*>(w3);
-  p.s1 = scale1; p.b1 = shift1; p.s2 = scale2; p.b2 = shift2; p.s3 = scale3; p.b3 = shift3;
+  p.tab = reinterpret_cast<const char*>(scale_shift);
   p.N = d->N; p.H = d->H; p.W = d->W;
   p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
   p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->x_cstride * 2);
@@ -415,6 +457,8 @@ extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, con
   p.tx = ceil_div(d->W, tw);
   p.ty = ceil_div(d->H, th);
   p.total = d->N * p.tx * p.ty;
+  static const int dbg = getenv("FT_BNK_DBG") ? atoi(getenv("FT_BNK_DBG")) : 0;
+  p.dbg = dbg;
   hipStream_t s = as_stream(stream);
   if (tall) {
     auto k = bottleneck_fused_kernel<8>;

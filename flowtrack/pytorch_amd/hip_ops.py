@@ -710,9 +710,9 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
     flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
     prog.flops += flops
     prog.fused_records.append((label, len(prog.calls), flops))
-    prog.add("ft_bottleneck_fwd", ctypes.byref(d), x.t.data_ptr(), w1.data_ptr(), s1.data_ptr(), b1.data_ptr(),
-             w2.data_ptr(), s2.data_ptr(), b2.data_ptr(), w3.data_ptr(), s3.data_ptr(), b3.data_ptr(), y.t.data_ptr(),
-             keep=(d, x.t, y.t, w1, s1, b1, w2, s2, b2, w3, s3, b3))
+    table = torch.cat([t.flatten()[:n] for t, n in ((s1, planes), (b1, planes), (s2, planes), (b2, planes), (s3, x.C), (b3, x.C))]).contiguous()
+    prog.add("ft_bottleneck_fwd", ctypes.byref(d), x.t.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), table.data_ptr(),
+             y.t.data_ptr(), keep=(d, x.t, y.t, w1, w2, w3, table))
 
 
 # --------------------------------------------------------------------------------------------

@@ -189,7 +189,8 @@ double ft_conv_flops(const ft_conv_desc* d);
  * t1 / t2 live in LDS only; x is read once (+ halo / residual re-reads from L2), y written once.
  * Supported: dtype FT_F16, C = 256, P = 64, stride 1 (ResNet layer1.1+); y must not alias x.
  * w1 / w2 / w3 are the ft_conv_pack_geometry layouts of the three convs on channel-aligned views
- * ([64][256], [64][9*64] with k = (ky*3+kx)*64 + ci, [256][64]); scale / shift = folded BN, float[Cout]. */
+ * ([64][256], [64][9*64] with k = (ky*3+kx)*64 + ci, [256][64]); scale_shift = the three folded BatchNorms as one
+ * float[2P + 2P + 2C] table: scale1[P] shift1[P] scale2[P] shift2[P] scale3[C] shift3[C]. */
 typedef struct ft_bottleneck_desc {
   int dtype;
   int N, H, W;            /* block input = output size */
@@ -199,10 +200,8 @@ typedef struct ft_bottleneck_desc {
 } ft_bottleneck_desc;
 int ft_bottleneck_supported(const ft_bottleneck_desc* d);   /* FT_OK or FT_ERR_UNSUPPORTED / FT_ERR_INVALID_ARG */
 int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,
-                      const void* w1, const float* scale1, const float* shift1,
-                      const void* w2, const float* scale2, const float* shift2,
-                      const void* w3, const float* scale3, const float* shift3,
-                      void* y, ft_stream_t stream);
+                      const void* w1, const void* w2, const void* w3,
+                      const float* scale_shift, void* y, ft_stream_t stream);
 /* algorithmic FLOPs of the three convs (2*MACs, no halo recompute) */
 double ft_bottleneck_flops(const ft_bottleneck_desc* d);
 
