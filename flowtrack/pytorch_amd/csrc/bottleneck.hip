@@ -9,14 +9,22 @@
 //
 // One 256-thread workgroup owns an 8x16 (or 16x8) patch of output pixels of one image:
 //   phase 1  t1 = relu(bn1(W1 . x)) on the 10x18 HALO patch (180 pixels padded to 192; out-of-image pixels forced to 0 =
-//            conv2's zero padding): GEMM [64 co] x [192 px] x K=256.  x streams HBM -> LDS in 32-channel chunks through a
-//            3-slot DMA ring together with the matching K-slice of W1; result -> fp16 T1 in LDS (24 KiB).
+//            conv2's zero padding): GEMM [64 co] x [192 px] x K=256.  x streams HBM -> LDS in four 64-channel chunks
+//            (whole 128-byte lines per pixel) through two DMA stages together with the matching K-slice of W1; the
+//            residual (the patch's own 128 pixels) is picked out of the same stages in phase 3's register layout;
+//            result -> fp16 T1 in LDS (24 KiB).
 //   phase 2  t2 = relu(bn2(W2 * t1)): GEMM [64 co] x [128 px] x K=9*64; the pixel operand of every tap is read from T1
-//            at the tap's offset (the conv_halo_kernel idea), only W2 streams (one tap = 8 KiB per K-step) -> fp16 T2 (16 KiB).
-//   phase 3  y = relu(bn3(W3 . t2) + x): four 64-channel quarters, GEMM [64 co] x [128 px] x K=64 each; the residual is
-//            re-read from L2 in the accumulator layout, the fp16 tile is transposed through LDS for 16-byte coalesced stores.
-// 73 KiB of LDS -> two workgroups per CU, so one workgroup's phase-1 HBM stream overlaps the other's phases 2-3.
-// The halo makes phase 1 do 1.4x the 1x1's MACs (0.9 GMAC of 13.7 per block at batch 64): cheap next to 3 MB of HBM.
+//            at the tap's offset (the conv_halo_kernel idea), only W2 streams (one tap = 8 KiB per K-step, 4-slot ring,
+//            W3's quarters follow the taps through the same ring) -> fp16 T2 (16 KiB).
+//   phase 3  y = relu(bn3(W3 . t2) + x): four 64-channel quarters, GEMM [64 co] x [128 px] x K=64 each, nothing is loaded
+//            from memory any more; the fp16 tile is transposed through two alternating LDS buffers for 16-byte
+//            coalesced stores (one barrier per quarter, no wait on the stores).
+// 75 KiB of LDS -> two workgroups per CU.  The halo makes phase 1 do 1.4x the 1x1's MACs (0.9 GMAC of 13.7 per block at
+// batch 64): cheap next to 3 MB of HBM.
+// Measured (batch 64, 64x48): 134 us for the three launches -> 64 us.  Per patch 232 KB go L2 -> LDS (96 x, 136 weights)
+// and that delivery (~16 B/clk/CU, the same ceiling the conv kernels see) is what bounds it now, not HBM: tools/dev/
+// bnk_phases.py (phase timestamps) and the FT_BNK_DBG ablations in bnk_bench.py are how that was established; deeper
+// rings, 64- vs 128-byte rows, an L2 warm-up of the later chunks and staggering the co-resident workgroups changed nothing.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -36,7 +44,7 @@ struct BnkParams {
   unsigned x_bytes;
   int tx, ty;      // patches per image along x / y
   int total;       // workgroups
-  int dbg;         // FT_BNK_DBG (dev): 1 no x loads, 2 no residual loads, 4 no stores
+  int dbg;         // FT_BNK_DBG (dev): 1 no x loads, 4 no stores, 16 x loads from images 0..7 only (L2-resident), 32 phase timestamps
 };
 
 template <int N, int I = 0, typename F>
@@ -51,10 +59,10 @@ __device__ __forceinline__ void unroll_for(F&& f) {
 #define BNK_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 constexpr int kC = 256, kP = 64;                 // block width / planes this kernel is written for
-// LDS map (bytes).  Phase 1: four 16-KiB stages (x chunk 12 KiB + W1 K-slice 4 KiB) at 0 .. 64 Ki.
+// LDS map (bytes).  Phase 1: two 32-KiB stages (64-channel x chunk 24 KiB + W1 K-slice 8 KiB) at 0 .. 64 Ki.
 // Phase 2: T1 at 0 (24 KiB), W2 ring slots 1..3 at 24 / 32 / 40 Ki and slot 0 at 64 Ki, T2 at 48 Ki (16 KiB).
 // Phase 3: W3 quarters in the ring slots, output staging A at 0 and B at 48 Ki (16 KiB each).  Folded-BN table at 72 Ki.
-[[maybe_unused]] constexpr int kStage1 = 16384, kXChunk = 12288;
+[[maybe_unused]] constexpr int kStage1 = 32768, kXChunk = 24576;
 [[maybe_unused]] constexpr int kOffT1 = 0, kOffT2 = 49152, kOffOutA = 0, kOffOutB = 49152, kOffTab = 73728;
 constexpr int kLdsBytes = 76800;
 __device__ __forceinline__ constexpr int ring_slot(int i) { return i == 0 ? 65536 : 24576 + (i - 1) * 8192; }
@@ -92,44 +100,51 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   constexpr unsigned kOOB = 0x80000000u;
 
   // ---- loader lanes --------------------------------------------------------------------------------------------
-  // a 1-KiB wave load covers 16 rows of 64 bytes: lane -> (row = lane / 4, 16-byte position = lane % 4); the LDS image is
-  // lane-linear, so the XOR swizzle is applied to the SOURCE position
-  const int lrow = lane >> 2, lpos = lane & 3;
-  unsigned x_voff[3];
+  // every LDS tile here has 128-byte rows (64 fp16): a 1-KiB wave load covers 8 rows, lane -> (row = lane / 8, 16-byte
+  // position = lane % 8) — whole 128-byte lines per row for the texture path (64-byte rows cost twice the requests per
+  // byte: the phase-1 stream was request-bound with them).  The LDS image is lane-linear, so the XOR swizzle
+  // (position ^= row & 7) is applied to the SOURCE position.
+  const int lrow = lane >> 3, lpos = lane & 7;
+  unsigned x_voff[6];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int pp = (t * 4 + wave) * 16 + lrow;          // halo pixel
+  for (int t = 0; t < 6; ++t) {
+    const int pp = (t * 4 + wave) * 8 + lrow;           // halo pixel
     const int pr = pp / PW, pc = pp - pr * PW;
     const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
     unsigned v = kOOB;
     if (pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 1))
-      v = (unsigned)((((n * p.H + iy) * p.W + ix) * p.x_cstride + p.x_coff) * 2 + ((lpos ^ ((pp >> 2) & 3)) << 4));
+      v = (unsigned)(((((p.dbg & 16 ? (n & 7) : n) * p.H + iy) * p.W + ix) * p.x_cstride + p.x_coff) * 2 + ((lpos ^ (pp & 7)) << 4));
     x_voff[t] = v;
   }
-  const int wr = wave * 16 + lrow;                       // weight row (output channel within a 64-row block)
-  const unsigned w_lc = (unsigned)((lpos ^ ((wr >> 2) & 3)) << 4);
-  const unsigned w1_voff = (unsigned)(wr * kC * 2) + w_lc;          // W1 [64][256]
-  const unsigned w2_voff = (unsigned)(wr * 9 * kP * 2) + w_lc;      // W2 [64][576]
-  const unsigned w3_voff = (unsigned)(wr * kP * 2) + w_lc;          // W3 [256][64], + quarter * 64 rows
+  unsigned w1_voff[2], w2_voff[2], w3_voff[2];           // rows (t * 4 + wave) * 8 + lrow of a 64-row weight block
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int wr = (t * 4 + wave) * 8 + lrow;
+    const unsigned lc = (unsigned)((lpos ^ (wr & 7)) << 4);
+    w1_voff[t] = (unsigned)(wr * kC * 2) + lc;           // W1 [64][256]
+    w2_voff[t] = (unsigned)(wr * 9 * kP * 2) + lc;       // W2 [64][576]
+    w3_voff[t] = (unsigned)(wr * kP * 2) + lc;           // W3 [256][64], + quarter * 64 rows
+  }
 
-  auto load_stage1 = [&](int slot, int c) {              // chunk c: channels 32c .. 32c+31 of the halo patch + W1's K-slice
+  auto load_stage1 = [&](int slot, int c) {              // chunk c: channels 64c .. 64c+63 of the halo patch + W1's K-slice
     char* st = smem + slot * kStage1;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 6; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, x_voff[t],
-                                               x_voff[t] == kOOB ? 0 : c * 64, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (lds_ptr)(st + kXChunk + wave * 1024), 16, w1_voff, c * 64, 0, 0);
+                                               x_voff[t] == kOOB ? 0 : c * 128, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (lds_ptr)(st + kXChunk + (t * 4 + wave) * 1024), 16, w1_voff[t], c * 128, 0, 0);
   };
-  // ring items 0..8 = the nine taps of W2 ([64 co][64 ci] as two 32-channel halves), items 9..11 = quarters 0..2 of W3
+  // ring items 0..8 = the nine taps of W2 ([64 co][64 ci] = 128-byte rows), items 9..12 = the quarters of W3
   auto load_item = [&](int item) {
     char* st = smem + ring_slot(item & 3);
-    if (item < 9) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + wave * 1024), 16, w2_voff, item * 128, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + 4096 + wave * 1024), 16, w2_voff, item * 128 + 64, 0, 0);
-    } else {
-      const int q = item - 9;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + wave * 1024), 16, w3_voff, q * 64 * kP * 2, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + 4096 + wave * 1024), 16, w3_voff, q * 64 * kP * 2 + 64, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (item < 9)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w2_voff[t], item * 128, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w3_voff[t], (item - 9) * 64 * kP * 2, 0, 0);
     }
   };
 
@@ -147,12 +162,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   // wave -> output-channel tile (wave & 1) x three 32-pixel tiles (wave >> 1)
   const int wc1 = wave & 1, wp1 = wave >> 1;
   const int a1_row = wc1 * 32 + l31;
-  const int a1_off = a1_row * 64 + ((lhi ^ ((a1_row >> 2) & 3)) << 4);
+  const int a1_off = a1_row * 128 + ((lhi ^ (a1_row & 7)) << 4);       // + (k16 * 2) << 4 by XOR: 16-channel slice k16
   int b1_off[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int r = (wp1 * 3 + j) * 32 + l31;
-    b1_off[j] = r * 64 + ((lhi ^ ((r >> 2) & 3)) << 4);
+    b1_off[j] = r * 128 + ((lhi ^ (r & 7)) << 4);
   }
   float16_t acc1[3];
 #pragma unroll
@@ -162,47 +177,48 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 
   // residual = the block input at the patch's own 128 pixels, picked up in the ACCUMULATOR layout of phase 3 (lane ->
   // pixel wp2*64 + j*32 + l31, channels q*64 + wc2*32 + g*8 + lhi*4 .. +3) from the phase-1 stages as they pass through
-  // LDS: chunk c = channels 32c .. 32c+31 = quarter c / 2, half (wc2) c % 2.  No second trip to L2 for them.
+  // LDS: chunk c = quarter c.  No second trip to L2 for them.
   const int wc2 = wave >> 1, wp2 = wave & 1;
   int rc_off[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = wp2 * 64 + j * 32 + l31;
     const int rc = (m / TW + 1) * PW + (m % TW + 1);
-    rc_off[j] = rc * 64 + lhi * 8 + (((rc >> 2) & 3) << 4);    // chunk g of the row sits at (g ^ swizzle) << 4
+    rc_off[j] = rc * 128 + lhi * 8 + (((wc2 * 4) ^ (rc & 7)) << 4);    // 16-byte chunk wc2*4 + g sits at (.. ^ g) << 4
   }
   half4_t res[4][2][4];
 
+  // two 32-KiB stages: chunk c+1 streams while chunk c is multiplied; a stage is refilled (chunk c+2) once every wave is
+  // past its reads — a second barrier per chunk, four chunks
   load_stage1(0, 0);
   load_stage1(1, 1);
-  load_stage1(2, 2);
-  unroll_for<8>([&](auto cc) {
+  unroll_for<4>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    // chunk c has landed; the (up to two) younger stages = 4 loads per wave each stay in flight
-    if constexpr (c <= 5) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if constexpr (c == 6) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if constexpr (c < 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // chunk c landed; c+1 (8 loads) may fly
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BNK_BARRIER();
-    if constexpr (c + 3 < 8) load_stage1((c + 3) & 3, c + 3);
-    const char* st = smem + (c & 3) * kStage1;
-    uint4_t fa[2], fb[2][3];
+    const char* st = smem + (c & 1) * kStage1;
+    uint4_t fa[4], fb[4][3];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      fa[kk] = *reinterpret_cast<const uint4_t*>(st + kXChunk + (a1_off ^ (kk << 5)));
+    for (int k16 = 0; k16 < 4; ++k16) {
+      fa[k16] = *reinterpret_cast<const uint4_t*>(st + kXChunk + (a1_off ^ (k16 << 5)));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) fb[kk][j] = *reinterpret_cast<const uint4_t*>(st + (b1_off[j] ^ (kk << 5)));
+      for (int j = 0; j < 3; ++j) fb[k16][j] = *reinterpret_cast<const uint4_t*>(st + (b1_off[j] ^ (k16 << 5)));
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) res[c][j][g] = *reinterpret_cast<const half4_t*>(st + (rc_off[j] ^ (g << 4)));
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[kk]),
-                                                         __builtin_bit_cast(half8_t, fb[kk][j]), acc1[j], 0, 0, 0);
-    if (wc2 == (c & 1)) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) res[c >> 1][j][g] = *reinterpret_cast<const half4_t*>(st + (rc_off[j] ^ (g << 4)));
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[k16]),
+                                                         __builtin_bit_cast(half8_t, fb[k16][j]), acc1[j], 0, 0, 0);
+    if constexpr (c + 2 < 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      BNK_BARRIER();
+      load_stage1(c & 1, c + 2);
     }
   });
   // the last chunk had vmcnt(0): nothing of this wave is in flight.  Every wave is past its last stage read once it
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   // ================= phase 2: t2 = relu(bn2(W2 * t1)), pixel operand from T1 ======================================
   // wave -> output-channel tile wc2 = wave >> 1 x two 32-pixel tiles (wp2 = wave & 1)
   const int a2_row = wc2 * 32 + l31;
-  const int a2_off = a2_row * 64 + ((lhi ^ ((a2_row >> 2) & 3)) << 4);
+  const int a2_off = a2_row * 128 + ((lhi ^ (a2_row & 7)) << 4);
   int r0[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[sl][kk] = *reinterpret_cast<const uint4_t*>(st + sl * 4096 + (a2_off ^ (kk << 5)));
+      for (int kk = 0; kk < 2; ++kk) fa[sl][kk] = *reinterpret_cast<const uint4_t*>(st + (a2_off ^ ((sl * 2 + kk) << 5)));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = r0[j] + ky * PW + kx;
@@ -319,11 +335,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNK_BARRIER();
   BNK_TS(4);
-  {
-    char* st = smem + ring_slot(0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + wave * 1024), 16, w3_voff, 3 * 64 * kP * 2, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + 4096 + wave * 1024), 16, w3_voff, 3 * 64 * kP * 2 + 64, 0, 0);
-  }
+  load_item(12);
 
   // ================= phase 3: y = relu(bn3(W3 . t2) + x), four quarters of 64 output channels ====================
   uint4_t fb3[2][2][2];
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const uint4_t fa = *reinterpret_cast<const uint4_t*>(wq + sl * 4096 + (a2_off ^ (kk << 5)));
+        const uint4_t fa = *reinterpret_cast<const uint4_t*>(wq + (a2_off ^ ((sl * 2 + kk) << 5)));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa),
