@@ -67,7 +67,10 @@ constexpr int kC = 256, kP = 64;                 // block width / planes this ke
 constexpr int kLdsBytes = 76800;
 __device__ __forceinline__ constexpr int ring_slot(int i) { return i == 0 ? 65536 : 24576 + (i - 1) * 8192; }
 
-template <int TW>
+// NCH = 64-channel chunks of the block input (4: the 256-wide identity blocks, 1: the stage's entry block, 64 in).
+// FULL = false stops after phase 2 and writes t2 (the entry block's conv3 is K-concatenated with its projection shortcut
+// in ft_conv2d_fwd's x2_* path; here only its conv1 + conv2 pair is fused).
+template <int TW, int NCH, bool FULL>
 __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
@@ -93,10 +96,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   const int qy0 = tyi * TH, qx0 = txi * TW;
 
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, kP * kC * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, kP * NCH * 128, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, kP * 9 * kP * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, kC * kP * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 3072, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, FULL ? kC * kP * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, FULL ? 3072 : 1024, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
   // ---- loader lanes --------------------------------------------------------------------------------------------
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   for (int t = 0; t < 2; ++t) {
     const int wr = (t * 4 + wave) * 8 + lrow;
     const unsigned lc = (unsigned)((lpos ^ (wr & 7)) << 4);
-    w1_voff[t] = (unsigned)(wr * kC * 2) + lc;           // W1 [64][256]
+    w1_voff[t] = (unsigned)(wr * NCH * 128) + lc;        // W1 [64][64 * NCH]
     w2_voff[t] = (unsigned)(wr * 9 * kP * 2) + lc;       // W2 [64][576]
     w3_voff[t] = (unsigned)(wr * kP * 2) + lc;           // W3 [256][64], + quarter * 64 rows
   }
@@ -143,14 +146,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     for (int t = 0; t < 2; ++t) {
       if (item < 9)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w2_voff[t], item * 128, 0, 0);
-      else
+      else    // !FULL: rsrc_w3 is empty, every lane is out of range -> zero fill, no traffic, same load count for the waits
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w3_voff[t], (item - 9) * 64 * kP * 2, 0, 0);
     }
   };
 
   // oldest loads of every wave: the folded-BN table (3 KiB, waves 0..2) and W2's first tap (its ring slot lies outside the
   // phase-1 stages) — both land long before they are needed and sit in front of every counted wait below
-  if (wave < 3)
+  if (wave < (FULL ? 3 : 1))
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_tab, (lds_ptr)(smem + kOffTab + wave * 1024), 16, (unsigned)(lane * 16), wave * 1024, 0, 0);
   load_item(0);
   const float* tab = reinterpret_cast<const float*>(smem + kOffTab);
@@ -186,15 +189,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     const int rc = (m / TW + 1) * PW + (m % TW + 1);
     rc_off[j] = rc * 128 + lhi * 8 + (((wc2 * 4) ^ (rc & 7)) << 4);    // 16-byte chunk wc2*4 + g sits at (.. ^ g) << 4
   }
-  half4_t res[4][2][4];
+  half4_t res[FULL ? 4 : 1][2][4];
 
   // two 32-KiB stages: chunk c+1 streams while chunk c is multiplied; a stage is refilled (chunk c+2) once every wave is
   // past its reads — a second barrier per chunk, four chunks
   load_stage1(0, 0);
-  load_stage1(1, 1);
-  unroll_for<4>([&](auto cc) {
+  if constexpr (NCH > 1) load_stage1(1, 1);
+  unroll_for<NCH>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    if constexpr (c < 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // chunk c landed; c+1 (8 loads) may fly
+    if constexpr (c < NCH - 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // chunk c landed; c+1 (8 loads) may fly
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BNK_BARRIER();
     const char* st = smem + (c & 1) * kStage1;
@@ -205,17 +208,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
       for (int j = 0; j < 3; ++j) fb[k16][j] = *reinterpret_cast<const uint4_t*>(st + (b1_off[j] ^ (k16 << 5)));
     }
+    if constexpr (FULL) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) res[c][j][g] = *reinterpret_cast<const half4_t*>(st + (rc_off[j] ^ (g << 4)));
+        for (int g = 0; g < 4; ++g) res[c][j][g] = *reinterpret_cast<const half4_t*>(st + (rc_off[j] ^ (g << 4)));
+    }
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[k16]),
                                                          __builtin_bit_cast(half8_t, fb[k16][j]), acc1[j], 0, 0, 0);
-    if constexpr (c + 2 < 4) {
+    if constexpr (c + 2 < NCH) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       BNK_BARRIER();
       load_stage1(c & 1, c + 2);
@@ -335,6 +340,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNK_BARRIER();
   BNK_TS(4);
+  if constexpr (!FULL) {     // entry block: t2 is the result — 128 pixels x 128 bytes, 16 bytes per lane
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing (empty) loads must not outlive the workgroup's LDS
+    const char* t2 = smem + kOffT2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, m = idx >> 3, ch = idx & 7;
+      const int oy = qy0 + m / TW, ox = qx0 + m % TW;
+      const uint4_t v = *reinterpret_cast<const uint4_t*>(t2 + m * 128 + ((ch ^ (m & 7)) << 4));
+      if (oy < p.H && ox < p.W && !(p.dbg & 4))
+        *reinterpret_cast<uint4_t*>(p.y + ((((long long)n * p.H + oy) * p.W + ox) * p.y_cstride + p.y_coff + ch * 8) * 2) = v;
+    }
+    return;
+  }
   load_item(12);
 
   // ================= phase 3: y = relu(bn3(W3 . t2) + x), four quarters of 64 output channels ====================
@@ -430,10 +448,26 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 static int supported(const ft_bottleneck_desc* d) {
   if (!d) return FT_ERR_INVALID_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
-  if (d->dtype != FT_F16 || d->C != kC || d->P != kP) return FT_ERR_UNSUPPORTED;
+  if (d->dtype != FT_F16 || d->P != kP) return FT_ERR_UNSUPPORTED;
+  if (d->head_only ? (d->C != 64 && d->C != kC) : d->C != kC) return FT_ERR_UNSUPPORTED;
+  if (d->head_only && d->C != 64) return FT_ERR_UNSUPPORTED;     // (256-wide head-only: no caller, not instantiated)
+  const int yc = d->head_only ? d->P : d->C;
   if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
-  if (d->x_cstride < d->x_coff + kC || d->y_cstride < d->y_coff + kC) return FT_ERR_INVALID_ARG;
+  if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + yc) return FT_ERR_INVALID_ARG;
   if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
+  return FT_OK;
+}
+
+template <int TW, int NCH, bool FULL>
+static int launch(const BnkParams& p, hipStream_t s) {
+  auto k = bottleneck_fused_kernel<TW, NCH, FULL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
+  FT_LAUNCH_CHECK("bottleneck_fused_kernel");
   return FT_OK;
 }
 
@@ -444,7 +478,7 @@ extern "C" int ft_bottleneck_supported(const ft_bottleneck_desc* d) { return ft:
 
 extern "C" double ft_bottleneck_flops(const ft_bottleneck_desc* d) {
   if (!d) return 0.0;
-  return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (double)d->P * d->C);
+  return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (d->head_only ? 0.0 : (double)d->P * d->C));
 }
 
 extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, const void* w1, const void* w2, const void* w3,
@@ -452,7 +486,7 @@ extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, con
   using namespace ft;
   const int st = supported(d);
   if (st != FT_OK) return st;
-  if (!x || !w1 || !w2 || !w3 || !scale_shift || !y) return FT_ERR_INVALID_ARG;
+  if (!x || !w1 || !w2 || (!w3 && !d->head_only) || !scale_shift || !y) return FT_ERR_INVALID_ARG;
   BnkParams p{};
   p.x = static_cast<const char*>(x);
   p.y = static_cast<char*>(y);
@@ -472,23 +506,7 @@ extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, con
   static const int dbg = getenv("FT_BNK_DBG") ? atoi(getenv("FT_BNK_DBG")) : 0;
   p.dbg = dbg;
   hipStream_t s = as_stream(stream);
-  if (tall) {
-    auto k = bottleneck_fused_kernel<8>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
-  } else {
-    auto k = bottleneck_fused_kernel<16>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
-  }
-  FT_LAUNCH_CHECK("bottleneck_fused_kernel");
-  return FT_OK;
+  if (d->head_only) return tall ? launch<8, 1, false>(p, s) : launch<16, 1, false>(p, s);
+  return tall ? launch<8, 4, true>(p, s) : launch<16, 4, true>(p, s);
 }
+

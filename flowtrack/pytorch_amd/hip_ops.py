@@ -671,12 +671,58 @@ def bottleneck_fusable(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: Act
     return _lib.load().ft_bottleneck_supported(ctypes.byref(d)) == 0
 
 
-def _bottleneck_desc(x: ActView, y: ActView, planes: int) -> _lib.BottleneckDesc:
+def _bottleneck_desc(x: ActView, y: ActView, planes: int, head_only: bool = False) -> _lib.BottleneckDesc:
     d = _lib.BottleneckDesc()
     d.dtype = _lib.dtype_code(x.t.dtype)
     d.N, d.H, d.W, d.C, d.P = x.N, x.H, x.W, x.C, planes
     d.x_cstride, d.x_coff, d.y_cstride, d.y_coff = x.cstride, x.coff, y.cstride, y.coff
+    d.head_only = int(head_only)
     return d
+
+
+def bottleneck_head_fusable(c1: "FusedConv", c2: "FusedConv", x: ActView, t2: ActView) -> bool:
+    """True when ft_bottleneck_fwd(head_only) covers conv1 + conv2 of a stage's entry block (fp16, 64 -> 64 -> 64, stride 1)."""
+    if x.t.dtype != torch.float16 or x.rowpacked or (x.N, x.H, x.W) != (t2.N, t2.H, t2.W):
+        return False
+    if (c1.k, c2.k) != (1, 3) or (c1.stride, c2.stride, c2.pad) != (1, 1, 1):
+        return False
+    if (c1.cin, c1.cout, c2.cin, c2.cout, t2.C) != (x.C, c2.cin, c2.cin, c2.cin, c2.cin):
+        return False
+    if any(c.transposed or c.tail_cout or c.act != ACT_CODES["relu"] or c._bn is None for c in (c1, c2)):
+        return False
+    d = _bottleneck_desc(x, t2, c2.cin, head_only=True)
+    return _lib.load().ft_bottleneck_supported(ctypes.byref(d)) == 0
+
+
+def _bottleneck_packed(conv: "FusedConv", x: ActView, want, label: str):
+    d = ConvDesc()
+    d.dtype = conv.code
+    d.N, d.Hi, d.Wi, d.Ho, d.Wo = x.N, x.H, x.W, x.H, x.W
+    d.Cin, d.x_cstride, d.x_coff = conv.cin, act_stride(conv.cin), 0
+    d.Cout, d.kh, d.kw, d.stride, d.pad = conv.cout, conv.k, conv.k, 1, conv.pad
+    d.y_cstride, d.y_coff, d.out_layout = act_stride(conv.cout), 0, FT_LAYOUT_NHWC
+    d.act = conv.act
+    g = conv_geometry(d)
+    if (g.cout_pad, g.kpad, g.nphases) != want:
+        raise FlowtrackHipError(f"{label}: unexpected packed layout {(g.cout_pad, g.kpad)} for the fused bottleneck")
+    w, _, scale, shift = conv._packed_for(d)
+    return w, scale, shift
+
+
+def record_bottleneck_head(prog: Program, c1: "FusedConv", c2: "FusedConv", x: ActView, t2: ActView, label: str) -> None:
+    """conv1 + bn1 + relu -> conv2 + bn2 + relu of a stage's entry block as one launch (ft_bottleneck_fwd, head_only)."""
+    lib = _lib.load()
+    planes = c2.cin
+    w1, s1, b1 = _bottleneck_packed(c1, x, (planes, x.C, 1), label)
+    w2, s2, b2 = _bottleneck_packed(c2, x, (planes, 9 * planes, 1), label)
+    d = _bottleneck_desc(x, t2, planes, head_only=True)
+    check(lib.ft_bottleneck_supported(ctypes.byref(d)), "ft_bottleneck_supported")
+    flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
+    prog.flops += flops
+    prog.fused_records.append((label, len(prog.calls), flops))
+    table = torch.cat([t.flatten()[:planes] for t in (s1, b1, s2, b2)]).contiguous()
+    prog.add("ft_bottleneck_fwd", ctypes.byref(d), x.t.data_ptr(), w1.data_ptr(), w2.data_ptr(), None, table.data_ptr(),
+             t2.t.data_ptr(), keep=(d, x.t, t2.t, w1, w2, table))
 
 
 def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
@@ -688,23 +734,9 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
         raise FlowtrackHipError(f"{label}: the fused bottleneck cannot run in place")
     planes = c2.cin
 
-    def packed(conv: "FusedConv", want):
-        d = ConvDesc()
-        d.dtype = conv.code
-        d.N, d.Hi, d.Wi, d.Ho, d.Wo = x.N, x.H, x.W, x.H, x.W
-        d.Cin, d.x_cstride, d.x_coff = conv.cin, act_stride(conv.cin), 0
-        d.Cout, d.kh, d.kw, d.stride, d.pad = conv.cout, conv.k, conv.k, 1, conv.pad
-        d.y_cstride, d.y_coff, d.out_layout = act_stride(conv.cout), 0, FT_LAYOUT_NHWC
-        d.act = conv.act
-        g = conv_geometry(d)
-        if (g.cout_pad, g.kpad, g.nphases) != want:
-            raise FlowtrackHipError(f"{label}: unexpected packed layout {(g.cout_pad, g.kpad)} for the fused bottleneck")
-        w, _, scale, shift = conv._packed_for(d)
-        return w, scale, shift
-
-    w1, s1, b1 = packed(c1, (planes, x.C, 1))
-    w2, s2, b2 = packed(c2, (planes, 9 * planes, 1))
-    w3, s3, b3 = packed(c3, (x.C, planes, 1))
+    w1, s1, b1 = _bottleneck_packed(c1, x, (planes, x.C, 1), label)
+    w2, s2, b2 = _bottleneck_packed(c2, x, (planes, 9 * planes, 1), label)
+    w3, s3, b3 = _bottleneck_packed(c3, x, (x.C, planes, 1), label)
     d = _bottleneck_desc(x, y, planes)
     check(lib.ft_bottleneck_supported(ctypes.byref(d)), "ft_bottleneck_supported")
     flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))

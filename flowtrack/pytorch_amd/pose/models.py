@@ -24,8 +24,8 @@ import torch
 import torch.nn as nn
 
 from ..engine import HipModule
-from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable, new_act,
-                       new_rowpacked_act, record_bottleneck,
+from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable,
+                       bottleneck_head_fusable, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_head,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -158,10 +158,13 @@ class DeconvResnet(HipModule):
                     record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
                     cur = out
                     continue
-                t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
                 t2 = new_act(B, Ho, Wo, planes, dtype, device)
-                c1.record(prog, cur, t1)
-                c2.record(prog, t1, t2)
+                if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
+                    record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
+                else:
+                    t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
+                    c1.record(prog, cur, t1)
+                    c2.record(prog, t1, t2)
                 if len(blk.downsample) and self.fuse_shortcut:
                     # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
                     # the shortcut tensor never exists in HBM

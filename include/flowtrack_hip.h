@@ -197,6 +197,9 @@ typedef struct ft_bottleneck_desc {
   int C, P;               /* block width (in = out channels) and planes */
   int x_cstride, x_coff;  /* NHWC views, element units, multiples of 8 */
   int y_cstride, y_coff;
+  int head_only;          /* 1: conv1 + conv2 only, y = t2 [N,H,W,P] (C = 64: the stage's entry block, whose conv3 is
+                             K-concatenated with its projection shortcut by ft_conv2d_fwd); w3 = NULL,
+                             scale_shift = float[4P] */
 } ft_bottleneck_desc;
 int ft_bottleneck_supported(const ft_bottleneck_desc* d);   /* FT_OK or FT_ERR_UNSUPPORTED / FT_ERR_INVALID_ARG */
 int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,

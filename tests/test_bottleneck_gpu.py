@@ -85,6 +85,47 @@ def test_fused_bottleneck_matches_oracle_and_the_three_launches(hip_lib, case):
     assert torch.equal(view_to_nchw(y_fused), got)
 
 
+HEAD_CASES = [("r50_64x48", 2, 64, 48), ("r101_96x72", 1, 96, 72), ("ragged_13x20", 3, 13, 20), ("recycle", 24, 64, 48)]
+
+
+@pytest.mark.parametrize("case", HEAD_CASES, ids=[c[0] for c in HEAD_CASES])
+def test_fused_bottleneck_head_matches_oracle_and_the_two_launches(hip_lib, case):
+    """conv1 + conv2 of the stage's entry block (64 -> 64 -> 64) as one launch (head_only)."""
+    from flowtrack.pytorch_amd.hip_ops import bottleneck_head_fusable, record_bottleneck_head
+    name, N, H, W = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 23
+    C = P = 64
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    bn1, bn2 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    want = F.relu(_bnf(F.conv2d(F.relu(_bnf(F.conv2d(x, w1), bn1)), w2, padding=1), bn2))
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    xv = nchw_to_view(x, dtype, dev)
+    t2f = ActView(torch.full((N, H, W, P), 3.0, dtype=dtype, device=dev), P, 0)
+    assert bottleneck_head_fusable(c1, c2, xv, t2f)
+    prog = make_program()
+    record_bottleneck_head(prog, c1, c2, xv, t2f, name)
+    run_program(prog)
+    got = view_to_nchw(t2f)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: fused head vs oracle max abs err {err:.3e}"
+    t1v = ActView(torch.zeros((N, H, W, P), dtype=dtype, device=dev), P, 0)
+    t2v = ActView(torch.zeros((N, H, W, P), dtype=dtype, device=dev), P, 0)
+    prog2 = make_program()
+    c1.record(prog2, xv, t1v)
+    c2.record(prog2, t1v, t2v)
+    run_program(prog2)
+    diff = (got - view_to_nchw(t2v)).abs()
+    assert diff.max().item() <= 1e-2 * scale and (diff > 0).float().mean().item() < 0.05
+    t2f.t.fill_(5.0)
+    run_program(prog)
+    assert torch.equal(view_to_nchw(t2f), got)
+
+
 def test_fused_bottleneck_rejects_other_blocks(hip_lib):
     from flowtrack.pytorch_amd import _lib
     import ctypes
