@@ -217,3 +217,37 @@ def test_tile_candidates_and_fusion_descriptors(hip_lib):
     assert _geom(hip_lib, tl)[0] == 1
     tl.tail_cout = 17; tl.dtype = _lib.FT_F32
     assert _geom(hip_lib, tl)[0] == 2                    # the fused tail is an fp16-mode feature
+
+
+def test_bottleneck_desc_matches_header_and_argument_checks(hip_lib):
+    """ft_bottleneck_desc mirror == header; supported / flops / argument errors need no GPU."""
+    from flowtrack.pytorch_amd._lib import BottleneckDesc
+    header = open(os.path.join(ROOT, "include", "flowtrack_hip.h")).read()
+    body = header[header.index("typedef struct ft_bottleneck_desc {"):header.index("} ft_bottleneck_desc;")]
+    fields = []
+    for line in body.splitlines()[1:]:
+        m = re.match(r"int\s+([^;]*);", line.split("/*")[0].strip())
+        if m:
+            fields += [n.strip() for n in m.group(1).split(",")]
+    assert fields == [f[0] for f in BottleneckDesc._fields_]
+
+    def desc(**kw):
+        d = BottleneckDesc()
+        base = dict(dtype=0, N=2, H=64, W=48, C=256, P=64, x_cstride=256, x_coff=0, y_cstride=256, y_coff=0, head_only=0)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        return d
+    ok, unsupported, invalid = 0, 2, 1
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc())) == ok
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(C=64, x_cstride=64, y_cstride=64, head_only=1))) == ok
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(C=64, x_cstride=64))) == unsupported          # full block needs C = 256
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(P=128))) == unsupported
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(dtype=1))) == unsupported                     # fp32: separate launches
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(x_coff=4))) == unsupported                    # 16-byte alignment
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(y_cstride=128))) == invalid
+    assert hip_lib.ft_bottleneck_supported(ctypes.byref(desc(N=0))) == invalid
+    macs = 2 * 64 * 48 * (256 * 64 + 9 * 64 * 64 + 64 * 256)
+    assert hip_lib.ft_bottleneck_flops(ctypes.byref(desc())) == 2.0 * macs
+    # NULL operands are an argument error, not a crash (no launch happens)
+    assert hip_lib.ft_bottleneck_fwd(ctypes.byref(desc()), None, None, None, None, None, None, None) == invalid
