@@ -1637,6 +1637,185 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p) {
 #endif
 }
 
+// ---- stem + max-pool (fp16): 7x7/s2 row-packed stem conv + bn + relu with the 3x3/s2/p1 max-pool behind it -----
+// (resnet.py:19-23 = conv1 -> bn1 -> relu -> maxpool).  The workgroup owns an 8x8 patch of POOLED pixels: it computes the
+// 17x17 stem outputs those windows cover (1.13x recompute of a cheap layer) with the stem kernel's K-loop, parks them as
+// fp16 in LDS, and writes only the pooled maxima: the [N, H/2, W/2, 64] stem map — the largest activation of the trunk,
+// 100 MB at batch 64 — is never written or re-read.  Pooling happens on the same fp16 values the separate launches
+// would pool, so the result is bit-identical to conv_stem_kernel + maxpool3x3s2.
+template <int RUNB>
+__global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams p, int Hp, int Wp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int KH = 7, STRIDE = 2, BC = 64, NW = 4, WGP = 2;
+  constexpr int PT = 8, TS = 2 * PT + 1, NPX = TS * TS;      // pooled tile edge, stem patch edge (17), stem pixels (289)
+  constexpr int MT_P = 5, WT_P = MT_P * 32;                  // 2 x 160 >= 289 pixels
+  constexpr int S = 3, A_STAGE = BC * RUNB;
+  constexpr int CH = RUNB / 16, SWZ_DIV = 256 / RUNB >= 1 ? 256 / RUNB : 1, RPI = 64 / CH;
+  constexpr int NIA = BC / RPI / NW;
+  constexpr int G = RUNB / 32;
+  constexpr int PH = (TS - 1) * STRIDE + KH;                 // 39 input rows
+  constexpr int NPLW_MAX = 12;
+  static_assert(RUNB == 64 || RUNB == 128, "bytes of one packed kernel row");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave % WGP, wc = wave / WGP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int ptile;
+  {
+    const int total = p.npt;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    ptile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tiles_per_img = p.h_ty * p.h_tx;
+  const int n = ptile / tiles_per_img;
+  const int trem = ptile - n * tiles_per_img;
+  const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+  const int py0 = tyi * PT, px0 = txi * PT;              // pooled origin
+  const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;        // stem-output origin (row / column -1 = the pool's padding)
+  const int cpb = p.x_cstride * 2;
+  const int CPR = p.h_pw;
+  const int RBp = CPR * 16;
+  const int iy_org = oy0 * STRIDE - p.pad;
+  const int col0 = ox0 * STRIDE - p.pad_x;               // >= 0: the host requires x_lpad >= pad + 2
+
+  char* const ring = smem;
+  char* const patch = smem + S * A_STAGE;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, BC * p.Kpad * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  const int nchunks = PH * CPR;
+#pragma unroll
+  for (int t = 0; t < NPLW_MAX; ++t) {
+    if (t < p.h_npww) {
+      const int gci = (t * NW + wave) * 64 + lane;
+      const int row = gci / CPR, ch = gci - row * CPR;
+      const int iy = iy_org + row;
+      unsigned v = kOOB;
+      if (gci < nchunks && (unsigned)iy < (unsigned)p.Hi)
+        v = (unsigned)(((n * p.Hi + iy) * p.Wi + col0) * cpb + ch * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(patch + (t * NW + wave) * 1024), 16, v, 0, 0, 0);
+    }
+  }
+  unsigned a_voff[NIA];
+  {
+    const int lrow = lane / CH, pos = lane % CH;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t) {
+      const int r = (wave + NW * t) * RPI + lrow;
+      const int lc = pos ^ ((r / SWZ_DIV) % CH);
+      a_voff[t] = (unsigned)(r * p.Kpad * 2 + lc * 16);
+    }
+  }
+  auto load_a = [&](auto slot_c, bool live, int ky) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(ring + slot * A_STAGE + (wave + NW * t) * 1024), 16,
+                                               live ? a_voff[t] : kOOB, live ? ky * RUNB : 0, 0, 0);
+  };
+  static_for<S - 1>([&](auto sc) { load_a(sc, decltype(sc)::value < KH, decltype(sc)::value); });
+
+  const int r_a = wc * 32 + l31;
+  const int a_off = r_a * RUNB + ((lhi ^ ((r_a / SWZ_DIV) % CH)) << 4);
+  int b_off[MT_P];
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j) {
+    int m = wp * WT_P + j * 32 + l31;
+    m = m < NPX ? m : NPX - 1;                           // the 31 surplus pixels recompute the last one (never stored)
+    b_off[j] = (m / TS) * STRIDE * RBp + (m % TS) * STRIDE * cpb + lhi * 16;
+  }
+
+  float16_t acc[MT_P];
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  static_for<KH>([&](auto ky_c) {
+    constexpr int ky = decltype(ky_c)::value;
+    constexpr int slot = ky % S, nslot = (ky + S - 1) % S;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // full wait: see conv_stem_kernel
+    FT_LDS_BARRIER();
+    load_a(std::integral_constant<int, nslot>{}, ky + S - 1 < KH, ky + S - 1);
+    const char* sa = ring + slot * A_STAGE;
+    const char* pb = patch + ky * RBp;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint4_t fa = *reinterpret_cast<const uint4_t*>(sa + (a_off ^ (g << 5)));
+      uint4_t fb[MT_P];
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j) fb[j] = *reinterpret_cast<const uint4_t*>(pb + b_off[j] + g * 32);
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa), __builtin_bit_cast(half8_t, fb[j]), acc[j], 0, 0, 0);
+    }
+  });
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  FT_LDS_BARRIER();                                      // ring + patch are dead: the stem tile takes their place
+  // ---- bn + relu -> fp16 stem tile [320 px][64 co] in LDS (128-byte rows, 16-byte chunk ^= row & 7) -----------
+  char* const stage = smem;
+  {
+#pragma clang fp contract(off)   // scale, then shift, each rounded — as conv_epilogue does: the result must match it bit for bit
+    float4_t sc[4], sh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = wc * 32 + g * 8 + lhi * 4;
+      sc[g] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + co) : float4_t{1.f, 1.f, 1.f, 1.f};
+      sh[g] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + co) : float4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < MT_P; ++j) {
+      const int m = wp * WT_P + j * 32 + l31;
+      const int oy = oy0 + m / TS, ox = ox0 + m % TS;
+      // relu output >= 0, every window holds a real pixel: 0 is the identity for the pool's padding / ragged edge
+      const bool inside = m < NPX && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+      char* rowp = stage + m * 128 + lhi * 8;
+      const int msw = (m & 7) << 4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)__builtin_fmaxf(acc[j][g * 4 + e] * sc[g][e] + sh[g][e], 0.f);
+        uint2 hb = __builtin_bit_cast(uint2, h);
+        hb.x = inside ? hb.x : 0u;
+        hb.y = inside ? hb.y : 0u;
+        *reinterpret_cast<uint2*>(rowp + (((wc * 4 + g) << 4) ^ msw)) = hb;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FT_LDS_BARRIER();
+  // ---- 3x3/s2 max over the tile: thread = (pooled pixel, 8-channel chunk), 16 bytes out ------------------------
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, pp = idx >> 3, ch = idx & 7;
+    const int ppy = pp >> 3, ppx = pp & 7;
+    const int py = py0 + ppy, px = px0 + ppx;
+    half8_t best = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int m = (2 * ppy + dy) * TS + 2 * ppx + dx;
+        const uint4_t v = *reinterpret_cast<const uint4_t*>(stage + m * 128 + ((ch ^ (m & 7)) << 4));
+        best = __builtin_elementwise_max(best, __builtin_bit_cast(half8_t, v));
+      }
+    if (py < Hp && px < Wp)
+      *reinterpret_cast<uint4_t*>(p.y + ((((long long)n * Hp + py) * Wp + px) * p.y_cstride + p.y_coff + ch * 8) * 2) =
+          __builtin_bit_cast(uint4_t, best);
+  }
+#endif
+}
+
 // ---- few-output-channel conv (FlowNet predict_flow: Cout = 2, K up to 9 * 1026) -----------------------
 // A GEMM tile would leave 30/32 MFMA columns idle and serialise a 9k-long K loop in a handful of
 // workgroups.  Instead: one wave per group of PIX consecutive output pixels, the 64 lanes split the
@@ -1943,6 +2122,7 @@ static int validate(const ft_conv_desc* d) {
     if (d->dtype != FT_F16 || d->has_residual || d->x2_cin != 0 || !(d->Cout == 64 || d->Cout == 128 || d->Cout == 256))
       return FT_ERR_UNSUPPORTED;
   }
+  if (d->pool != 0 && d->pool != 1) return FT_ERR_INVALID_ARG;
   if (d->x2_cin < 0) return FT_ERR_INVALID_ARG;
   if (d->x2_cin > 0) {   // second input (K-concat): 1x1 / stride 1 main conv, no residual, plain NHWC views
     if (d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->has_residual || d->x_wpitch > 0)
@@ -2140,6 +2320,31 @@ static int launch_stem(ConvParams p, const ft_conv_desc* d, const Geometry& g, h
   return FT_OK;
 }
 
+static bool stem_ok(const ft_conv_desc* d, const Geometry& g);
+
+// ft_conv_desc.pool: the pose stem with its max-pool fused (conv_stem_pool_kernel)
+static int launch_stem_pool(ConvParams p, const ft_conv_desc* d, const Geometry& g, hipStream_t s) {
+  const int runb = g.cin_pad * 2, cpb = d->x_cstride * 2;
+  if (!stem_ok(d, g) || d->kh != 7 || runb != 64 || d->act != FT_ACT_RELU || d->Ho % 2 || d->Wo % 2 || d->x_lpad < d->pad + 2 ||
+      ((d->x_lpad - d->pad - 2) * cpb) % 16 != 0)
+    return FT_ERR_UNSUPPORTED;
+  const int Hp = d->Ho / 2, Wp = d->Wo / 2;
+  const int rb = 16 * d->stride * cpb + runb;            // bytes of one patch row (17 stem columns)
+  p.h_pw = ceil_div(rb, 16);
+  p.h_npww = ceil_div(ceil_div(39 * p.h_pw, 64), 4);
+  if (p.h_npww > 12) return FT_ERR_UNSUPPORTED;
+  p.h_pb = p.h_npww * 4 * 1024;
+  p.h_ty = ceil_div(Hp, 8);
+  p.h_tx = ceil_div(Wp, 8);
+  p.npt = d->N * p.h_ty * p.h_tx;
+  p.nct = 1;
+  size_t lds = (size_t)3 * 64 * runb + p.h_pb;
+  if (lds < 320 * 128) lds = 320 * 128;
+  hipLaunchKernelGGL(conv_stem_pool_kernel<64>, dim3(p.npt), dim3(256), lds, s, p, Hp, Wp);
+  FT_LAUNCH_CHECK("conv_stem_pool_kernel");
+  return FT_OK;
+}
+
 static int launch_halo(ConvParams p, const ft_conv_desc* d, const Geometry& g, int bc, hipStream_t s) {
   if (g.rowpack) return launch_stem(p, d, g, s);
   const int Hq = p.HqWq / p.Wq, Wq = p.Wq;
@@ -2244,6 +2449,7 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
   if (st != FT_OK) return -st;
   if (!hints || max <= 0) return -FT_ERR_INVALID_ARG;
   if (d->tail_cout > 0) return 0;   // one variant: pixel tile x ALL channels
+  if (d->pool) return 0;            // one kernel
   static const int kTiles[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
   int n = 0;
   for (const auto& t : kTiles)
@@ -2432,6 +2638,11 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   const unsigned long long x_bytes =
       (unsigned long long)d->N * d->Hi * (d->x_wpitch > 0 ? d->x_wpitch : d->Wi) * d->x_cstride * esz;
 
+  if (d->pool) {            // stem + max-pool: y is the pooled [N, Ho/2, Wo/2, Cout] map
+    if (!g.rowpack || x_bytes >= (1ull << 31) || d->tail_cout > 0 || d->x2_cin > 0 || d->has_residual) return FT_ERR_UNSUPPORTED;
+    p.x_bytes = (unsigned)x_bytes;
+    return launch_stem_pool(p, d, g, s);
+  }
   if (d->tail_cout > 0) {   // conv + fused tail 1x1 conv: 128 pixels x all Cout channels per workgroup
     if (!g.dma || g.rowpack || x_bytes >= (1ull << 31) || g.cout_pad != d->Cout) return FT_ERR_UNSUPPORTED;
     if (!residual) return FT_ERR_INVALID_ARG;

@@ -540,8 +540,9 @@ class FusedConv:
             return 2 * H, 2 * W
         return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
 
-    def record(self, prog: Program, x: ActView, y, residual: Optional[ActView] = None) -> None:
-        """Append this layer to `prog`. y is an ActView (NHWC) or a contiguous NCHW fp32 tensor."""
+    def record(self, prog: Program, x: ActView, y, residual: Optional[ActView] = None, pool: bool = False) -> None:
+        """Append this layer to `prog`. y is an ActView (NHWC) or a contiguous NCHW fp32 tensor.
+        pool=True (the ResNet stem): the 3x3/s2/p1 max-pool runs inside the launch, y is the pooled map."""
         if x.C != self.cin:
             raise FlowtrackHipError(f"{self.label}: input has {x.C} channels, layer expects {self.cin}")
         if x.t.dtype != self.dtype or not x.t.is_contiguous():
@@ -557,8 +558,13 @@ class FusedConv:
         d.stride, d.pad, d.transposed = self.stride, self.pad, int(self.transposed)
         d.Ho, d.Wo = Ho, Wo
         out_c = self.tail_cout or self.cout
+        if pool:
+            if Ho % 2 or Wo % 2 or not isinstance(y, ActView) or residual is not None or self.tail_cout:
+                raise FlowtrackHipError(f"{self.label}: the fused max-pool needs an even conv output and a plain NHWC result")
+            d.pool = 1
+        yH, yW = (Ho // 2, Wo // 2) if pool else (Ho, Wo)
         if isinstance(y, ActView):
-            if (y.N, y.H, y.W) != (x.N, Ho, Wo) or y.C != out_c or y.t.dtype != self.dtype:
+            if (y.N, y.H, y.W) != (x.N, yH, yW) or y.C != out_c or y.t.dtype != self.dtype:
                 raise FlowtrackHipError(f"{self.label}: output view mismatch {tuple(y.t.shape)} C={y.C}")
             d.y_cstride, d.y_coff, d.out_layout = y.cstride, y.coff, FT_LAYOUT_NHWC
             yt = y.t

@@ -66,6 +66,8 @@ class DeconvResnet(HipModule):
     fuse_shortcut: bool = os.environ.get("FT_FUSE_SHORTCUT", "1") != "0"
     #: identity-shortcut blocks of the 256-wide stage as one launch (ft_bottleneck_fwd); FT_FUSE_BOTTLENECK=0 keeps 3 convs
     fuse_bottleneck: bool = os.environ.get("FT_FUSE_BOTTLENECK", "1") != "0"
+    #: the stem's max-pool inside the stem conv launch (ft_conv_desc.pool); FT_FUSE_STEM_POOL=0 keeps the two launches
+    fuse_stem_pool: bool = os.environ.get("FT_FUSE_STEM_POOL", "1") != "0"
     #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
     #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
     keypoints_in_plan = None
@@ -134,14 +136,22 @@ class DeconvResnet(HipModule):
         prog = Program(self._side_stream(device))
         mk = dict(dtype=dtype, device=device)
         x_static = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
-        a_in = new_rowpacked_act(B, H, W, 3, 3, dtype, device)   # 7x7/s2/p3 stem: one kernel row = one K-run
+        # 7x7/s2/p3 stem: one kernel row = one K-run.  fp16: conv1 + bn1 + relu + maxpool (resnet.py:19-23) are ONE launch
+        # (ft_conv_desc.pool; its patch starts one stem column further left: 5 physical pad columns instead of 3) and the
+        # [B, H/2, W/2, 64] stem map never exists
+        pool_in_stem = self.fuse_stem_pool and dtype == torch.float16
+        a_in = new_rowpacked_act(B, H, W, 3, 5 if pool_in_stem else 3, dtype, device)
         record_pack_input(prog, x_static, a_in)
 
-        stem = self.fused("conv1", self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(), act="relu", **mk)
-        a1 = new_act(B, H // 2, W // 2, 64, dtype, device)
-        stem.record(prog, a_in, a1)
+        stem = self.fused("conv1" + ("+maxpool" if pool_in_stem else ""), self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(),
+                          act="relu", **mk)
         cur = new_act(B, H // 4, W // 4, 64, dtype, device)
-        record_maxpool(prog, a1, cur)
+        if pool_in_stem:
+            stem.record(prog, a_in, cur, pool=True)
+        else:
+            a1 = new_act(B, H // 2, W // 2, 64, dtype, device)
+            stem.record(prog, a_in, a1)
+            record_maxpool(prog, a1, cur)
 
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), start=1):
             for bi, blk in enumerate(layer):

@@ -140,6 +140,11 @@ typedef struct ft_conv_desc {
    * ft_conv2d_fwd's `residual` argument; `y` / out_layout / y_cstride / y_coff describe the TAIL output
    * (Ho x Wo x tail_cout).  tail_cout = 0: none. */
   int tail_cout;
+  /* 1: fuse the 3x3 / stride 2 / pad 1 max-pool of the ResNet stem behind the activation (resnet.py:19-23: conv1 -> bn1
+   * -> relu -> maxpool).  Ho / Wo stay the CONV's output size (even); `y` is the pooled NHWC map [N, Ho/2, Wo/2, y_cstride].
+   * Supported for the row-packed 7x7 / stride 2 fp16 stem with relu, 64 outputs and x_lpad >= pad + 2 (the pooled patch
+   * starts one stem column further left); FT_ERR_UNSUPPORTED otherwise.  Bit-identical to conv + ft_maxpool3x3s2_fwd. */
+  int pool;
 } ft_conv_desc;
 
 /* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,

@@ -388,3 +388,48 @@ def test_patch_kernels_are_deterministic_when_workgroups_are_recycled(hip_lib, c
             outs.append(yv.t.clone())
         assert all(torch.equal(outs[0], o) for o in outs[1:]), f"{name} hint {h:#x}: runs differ"
         assert (outs[0].float() - ref).abs().max().item() <= 2e-2 * scale, f"{name} hint {h:#x}: differs from the plain variant"
+
+
+# ---- ResNet stem with the max-pool fused (ft_conv_desc.pool): conv1 -> bn1 -> relu -> maxpool, resnet.py:19-23 ----------
+STEM_POOL_CASES = [("r50_crop", 2, 256, 192), ("small_ragged_x", 2, 64, 48), ("ragged_xy", 3, 40, 56), ("recycle", 40, 256, 192)]
+
+
+@pytest.mark.parametrize("case", STEM_POOL_CASES, ids=[c[0] for c in STEM_POOL_CASES])
+def test_stem_with_fused_maxpool_matches_oracle_and_separate_launches(hip_lib, case):
+    from flowtrack.pytorch_amd.hip_ops import new_act, new_rowpacked_act, record_maxpool, record_pack_input
+    name, N, H, W = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 31
+    w = synth.normal(seed, name + ".w", (64, 3, 7, 7), std=(2.0 / 147) ** 0.5)
+    bn = {"weight": synth.uniform(seed, name + "g", (64,), 0.5, 1.5), "bias": synth.normal(seed, name + "b", (64,), 0.3),
+          "running_mean": synth.normal(seed, name + "m", (64,), 0.1), "running_var": synth.uniform(seed, name + "v", (64,), 0.5, 1.5), "eps": 1e-5}
+    x = synth.normal(seed, name + ".x", (N, 3, H, W))
+    layer = FusedConv(w, stride=2, pad=3, bn=bn, act="relu", dtype=dtype, device=dev, label=name)
+    xs = x.to(dev)
+    Hp, Wp = H // 4, W // 4
+
+    fused_in = new_rowpacked_act(N, H, W, 3, 5, dtype, dev)
+    pooled = new_act(N, Hp, Wp, 64, dtype, dev)
+    pooled.t.fill_(9.0)
+    prog = make_program()
+    record_pack_input(prog, xs, fused_in)
+    layer.record(prog, fused_in, pooled, pool=True)
+    run_program(prog)
+    got = view_to_nchw(pooled)
+
+    sep_in = new_rowpacked_act(N, H, W, 3, 3, dtype, dev)
+    a1 = new_act(N, H // 2, W // 2, 64, dtype, dev)
+    ref_pooled = new_act(N, Hp, Wp, 64, dtype, dev)
+    prog2 = make_program()
+    record_pack_input(prog2, xs, sep_in)
+    layer.record(prog2, sep_in, a1)
+    record_maxpool(prog2, a1, ref_pooled)
+    run_program(prog2)
+    assert torch.equal(got, view_to_nchw(ref_pooled)), f"{name}: fused stem + pool differs from conv + maxpool launches"
+
+    xh = x.half().float()
+    want = F.max_pool2d(_reference(xh, w, None, bn, 2, 3, False, "relu", None), 3, 2, 1)
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() <= 2e-2 * scale
+    pooled.t.fill_(7.0)
+    run_program(prog)
+    assert torch.equal(view_to_nchw(pooled), got)
