@@ -66,6 +66,33 @@ __global__ __launch_bounds__(256) void pack_nchw_to_nhwc_kernel(const float* __r
   }
 }
 
+// fast path of the above for the 3-channel network inputs (fp16, 4 halves per pixel, W % 4 == 0): one thread = 4
+// consecutive pixels = three 16-byte planar reads and 32 contiguous output bytes, 4x fewer index divisions; the first /
+// last thread of a row also zero the pad columns
+__global__ __launch_bounds__(256) void pack_nchw_rows4_kernel(const float* __restrict__ x, half_t* __restrict__ y, int C, int H,
+                                                              int W, int lpad, int wpitch, size_t total) {
+  const size_t HW = (size_t)H * W;
+  const int W4 = W >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % W4);
+    const size_t row = i / W4;              // n * H + yy
+    const size_t n = row / H, yy = row - n * H;
+    const float* xp_ = x + n * C * HW + yy * W + 4 * g;
+    float4_t v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = c < C ? *reinterpret_cast<const float4_t*>(xp_ + (size_t)c * HW) : float4_t{0.f, 0.f, 0.f, 0.f};
+    half_t* yrow = y + row * wpitch * 4;
+    half4_t* yp = reinterpret_cast<half4_t*>(yrow + (size_t)(lpad + 4 * g) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yp[k] = half4_t{(half_t)v[0][k], (half_t)v[1][k], (half_t)v[2][k], (half_t)0.f};
+    const half4_t z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    if (g == 0)
+      for (int c = 0; c < lpad; ++c) reinterpret_cast<half4_t*>(yrow)[c] = z;
+    if (g == W4 - 1)
+      for (int c = lpad + W; c < wpitch; ++c) reinterpret_cast<half4_t*>(yrow)[c] = z;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y,
                                                                   int C, size_t HW, size_t total, int cstride, int coff) {
@@ -326,6 +353,13 @@ extern "C" int ft_pack_nchw_to_nhwc(const float* x, void* y, int N, int C, int H
   if (lpad < 0 || wpitch < lpad + W) return FT_ERR_INVALID_ARG;
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
   const size_t total = (size_t)N * H * wpitch;
+  if (dtype == FT_F16 && C <= 3 && cpad == 4 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const size_t groups = (size_t)N * H * (W / 4);
+    hipLaunchKernelGGL(pack_nchw_rows4_kernel, dim3(grid_for(groups)), dim3(256), 0, as_stream(stream), x, static_cast<half_t*>(y),
+                       C, H, W, lpad, wpitch, groups);
+    FT_LAUNCH_CHECK("pack_nchw_rows4_kernel");
+    return FT_OK;
+  }
   if (dtype == FT_F16)
     hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,
                        static_cast<half_t*>(y), C, H, W, cpad, lpad, wpitch, total);

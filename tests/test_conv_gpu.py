@@ -433,3 +433,21 @@ def test_stem_with_fused_maxpool_matches_oracle_and_separate_launches(hip_lib, c
     pooled.t.fill_(7.0)
     run_program(prog)
     assert torch.equal(view_to_nchw(pooled), got)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24, 5), (1, 3, 9, 18, 3), (3, 2, 8, 32, 3), (2, 3, 256, 192, 5)], ids=str)
+def test_pack_input_rowpacked_layout(hip_lib, shape):
+    """ft_pack_nchw_to_nhwc into the row-packed stem layout: data in columns [lpad, lpad + W), every pad column and the
+    padding channel zero even when the buffer held garbage (fast 4-pixel path when W % 4 == 0, generic path otherwise)."""
+    from flowtrack.pytorch_amd.hip_ops import new_rowpacked_act, record_pack_input
+    N, C, H, W, pad = shape
+    dev = torch.device("cuda:0")
+    x = synth.normal(5, "pack" + str(shape), (N, C, H, W)).to(dev)
+    v = new_rowpacked_act(N, H, W, C, pad, torch.float16, dev)
+    v.t.fill_(9.0)
+    prog = make_program()
+    record_pack_input(prog, x, v)
+    run_program(prog)
+    want = torch.zeros_like(v.t)
+    want[:, :, pad:pad + W, :C] = x.permute(0, 2, 3, 1).half()
+    assert torch.equal(v.t, want)
