@@ -136,3 +136,28 @@ def test_keypoints_inside_the_plan_match_the_separate_call(hip_lib, adjust):
     for _ in range(2):          # eager first call, then the graph replay
         hm, idx, score, coords = m.forward_keypoints(x)
         assert torch.equal(hm, hm_ref) and torch.equal(idx, idx_r) and torch.equal(score, score_r) and torch.equal(coords, coords_r)
+
+
+@pytest.mark.parametrize("shape", [(2, 224, 160), (1, 288, 224), (3, 256, 192)], ids=str)
+def test_cross_layer_fusions_do_not_change_the_network(hip_lib, shape):
+    """fp16 plan with every cross-layer fusion (pooled stem, whole-bottleneck / head launches, K-concat shortcut, heatmap
+    tail) vs the plan built from one launch per layer: the pooled stem and the t1 / t2 roundings are identical by
+    construction, what remains is fp32 summation order — heatmaps agree to fp16 noise and the arg-max indices agree except
+    near-ties; sizes include maps that are ragged for the 8x16 / 16x8 patches and the 8x8 pooled tiles."""
+    B, H, W = shape
+    fused, _ = _model(50, torch.float16)
+    plain, _ = _model(50, torch.float16)
+    plain.fuse_bottleneck = plain.fuse_stem_pool = plain.fuse_shortcut = plain.fuse_heatmap = False
+    x = synth.pose_crops(SEED + 3, B, H, W).cuda()
+    a, b = fused(x).float().cpu(), plain(x).float().cpu()
+    assert {name for name, _ in fused._last_plan.prog.calls} >= {"ft_bottleneck_fwd"}
+    assert "ft_bottleneck_fwd" not in {name for name, _ in plain._last_plan.prog.calls}
+    rng = (b.max() - b.min()).item()
+    assert (a - b).abs().max().item() <= 0.02 * rng
+    ia, ib = a.flatten(2).argmax(2), b.flatten(2).argmax(2)
+    flips = (ia != ib)
+    if flips.any():      # every flip must be a near-tie in the one-launch-per-layer plan
+        bf = b.flatten(2)
+        gap = (bf.gather(2, ib.unsqueeze(2)) - bf.gather(2, ia.unsqueeze(2))).squeeze(2)[flips]
+        assert gap.abs().max().item() <= 0.02 * rng
+    assert flips.float().mean().item() <= 0.1
