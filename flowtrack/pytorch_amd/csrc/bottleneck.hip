@@ -461,7 +461,7 @@ static int supported(const ft_bottleneck_desc* d) {
 template <int TW, int NCH, bool FULL>
 static int launch(const BnkParams& p, hipStream_t s) {
   auto k = bottleneck_fused_kernel<TW, NCH, FULL>;
-  static bool attr_done = false;
+  static thread_local bool attr_done = false;   // per thread = per device in the one-thread-per-GPU callers (as launch_dma_r)
   if (!attr_done) {
     FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     attr_done = true;
