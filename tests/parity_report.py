@@ -16,16 +16,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from flowtrack.pytorch_amd import synth                      # noqa: E402
 from flowtrack.pytorch_amd.pose import evaluation, models   # noqa: E402
-from oracle import keypoints_ref, pose_ref                   # noqa: E402
+from oracle import flow_ref, keypoints_ref, pose_ref         # noqa: E402
+
+
+def flow_report(pairs, seed):
+    """FlowNet2S / FlowNet2C / FlowNet2CS at 512x384 (BASELINE configs[3] shape): GPU fp32 and fp16 flow vs the CPU oracle."""
+    import types
+    from flowtrack.pytorch_amd.flownet import models as fmodels
+    x = synth.frame_pairs(seed + 1, pairs, 384, 512)
+    out = {"pairs": pairs, "res": "512x384", "seed": seed, "models": {}}
+    for name, ref in (("FlowNet2S", flow_ref.flownet2s_forward), ("FlowNet2C", flow_ref.flownet2c_forward),
+                      ("FlowNet2CS", flow_ref.flownet2cs_forward)):
+        m = getattr(fmodels, name)(types.SimpleNamespace(rgb_max=255.0, fp16=False))
+        sd = synth.fill_flow_state_dict(m.state_dict(), seed)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        want = torch.cat([ref(sd, x[i:i + 1]) for i in range(pairs)])
+        mag = want.norm(dim=1).mean().item()
+        row = {"mean_flow_magnitude_px": mag}
+        for mode, dtype in (("fp32", torch.float32), ("fp16", torch.float16)):
+            m.compute_dtype = dtype
+            got = m(x.cuda()).float().cpu()
+            row[mode] = {"max_abs_err_px": float((got - want).abs().max()), "EPE_px": float((got - want).norm(dim=1).mean())}
+        out["models"][name] = row
+    print(json.dumps(out, indent=1))
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["pose", "flow"], default="pose")
+    ap.add_argument("--pairs", type=int, default=4)
     ap.add_argument("--crops", type=int, default=64)
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--res", default="256x192")
     ap.add_argument("--seed", type=int, default=2024)
     a = ap.parse_args()
+    if a.workload == "flow":
+        return flow_report(a.pairs, a.seed)
     H, W = (int(v) for v in a.res.split("x"))
     depth = int(a.backbone[len("resnet"):])
     m = models.deconv(a.backbone, 17, False)
