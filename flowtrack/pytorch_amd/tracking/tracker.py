@@ -38,6 +38,18 @@ def pose_oks(a: np.ndarray, b: np.ndarray, area: float, delta=COCO_DELTA, kpt_th
     return float(np.exp(-d2 / 2 / (delta[counted] ** 2) / (area + np.spacing(1))).mean())
 
 
+def pose_oks_matrix(dets: np.ndarray, tracks: np.ndarray, areas: np.ndarray, delta=COCO_DELTA,
+                    kpt_thresh: float = 0.0) -> np.ndarray:
+    """pose_oks of every (detection, track) pair at once: dets [D,K,3], tracks [T,K,3], areas [D] -> [D,T]."""
+    if len(dets) == 0 or len(tracks) == 0:
+        return np.zeros((len(dets), len(tracks)))
+    counted = np.logical_and(dets[:, None, :, 2] > kpt_thresh, tracks[None, :, :, 2] > kpt_thresh)       # [D,T,K]
+    d2 = ((dets[:, None, :, :2] - tracks[None, :, :, :2]) ** 2).sum(-1)
+    e = np.exp(-d2 / 2 / (np.asarray(delta) ** 2)[None, None, :] / (areas[:, None, None] + np.spacing(1)))
+    n = counted.sum(-1)
+    return np.where(n > 0, (e * counted).sum(-1) / np.maximum(n, 1), 0.0)
+
+
 @dataclass
 class FlowTracker:
     oks_threshold: float = 0.5
@@ -59,15 +71,17 @@ class FlowTracker:
         scores = boxes[:, 4] if boxes.shape[1] > 4 else keypoints[..., 2].mean(1)
         order = np.argsort(-scores, kind="stable")
         taken, assigned = set(), [-1] * len(keypoints)
+        areas = np.maximum((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), 1.0) if len(boxes) else np.zeros(0)
+        sim = pose_oks_matrix(keypoints, moved, areas, kpt_thresh=self.kpt_threshold)     # [detections, tracks]
+        free = np.ones(len(ids), dtype=bool)
         for d in order:
-            area = max((boxes[d, 2] - boxes[d, 0]) * (boxes[d, 3] - boxes[d, 1]), 1.0)
-            best, best_s = None, self.oks_threshold
-            for ti, tid in enumerate(ids):
-                if tid in taken:
-                    continue
-                s = pose_oks(keypoints[d], moved[ti], area, kpt_thresh=self.kpt_threshold)
-                if s > best_s:
-                    best, best_s = tid, s
+            best = None
+            if free.any():
+                row = np.where(free, sim[d], -1.0)
+                ti = int(np.argmax(row))                  # first maximum = the loop's "first strictly better" track
+                if row[ti] > self.oks_threshold:
+                    best = ids[ti]
+                    free[ti] = False
             if best is None:
                 best = self.next_id
                 self.next_id += 1

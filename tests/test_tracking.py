@@ -63,6 +63,51 @@ def test_tracker_keeps_ids_under_flow_and_spawns_new_ones():
     assert np.isclose(tracker.pose_oks(kp[0], kp[0], 1000.0), 1.0)
 
 
+def test_oks_matrix_equals_the_pairwise_loop_and_matching_is_unchanged():
+    """pose_oks_matrix (one broadcast) == pose_oks per pair, incl. joints below the score threshold and empty sets; the
+    greedy matcher on top of it assigns what the per-pair loop assigned (random poses, several frames)."""
+    rng = np.random.default_rng(3)
+    dets = rng.normal(50, 20, (7, 17, 3)); trks = rng.normal(50, 20, (5, 17, 3))
+    dets[..., 2] = rng.uniform(-0.2, 1, (7, 17)); trks[..., 2] = rng.uniform(-0.2, 1, (5, 17))
+    trks[2, :, 2] = -1.0                                                  # a track with no countable joint
+    areas = rng.uniform(500, 5000, 7)
+    got = tracker.pose_oks_matrix(dets, trks, areas, kpt_thresh=0.1)
+    want = np.array([[tracker.pose_oks(d, t, a, kpt_thresh=0.1) for t in trks] for d, a in zip(dets, areas)])
+    assert np.allclose(got, want, rtol=0, atol=1e-15) and np.all(got[:, 2] == 0.0)
+    assert tracker.pose_oks_matrix(dets[:0], trks, areas[:0]).shape == (0, 5)
+
+    def loop_update(tr, keypoints, boxes):                               # the matcher as first written: per-pair loop
+        ids = list(tr.tracks)
+        moved = np.stack([tr.tracks[i]["kpts"] for i in ids]) if ids else np.zeros((0,) + keypoints.shape[1:])
+        order = np.argsort(-boxes[:, 4], kind="stable")
+        taken, assigned = set(), [-1] * len(keypoints)
+        nxt = tr.next_id
+        for d in order:
+            area = max((boxes[d, 2] - boxes[d, 0]) * (boxes[d, 3] - boxes[d, 1]), 1.0)
+            best, best_s = None, tr.oks_threshold
+            for ti, tid in enumerate(ids):
+                if tid in taken:
+                    continue
+                s_ = tracker.pose_oks(keypoints[d], moved[ti], area, kpt_thresh=tr.kpt_threshold)
+                if s_ > best_s:
+                    best, best_s = tid, s_
+            if best is None:
+                best, nxt = nxt, nxt + 1
+            taken.add(best)
+            assigned[d] = best
+        return assigned
+
+    tr = FlowTracker(oks_threshold=0.3)
+    base = rng.normal(60, 25, (6, 17, 3)); base[..., 2] = 0.8
+    for t in range(6):
+        kp = base + rng.normal(0, 1.5, base.shape) + t
+        kp[..., 2] = 0.8
+        kp = kp[rng.permutation(6)][: 6 - (t % 2)]
+        boxes = np.array([[k[:, 0].min(), k[:, 1].min(), k[:, 0].max(), k[:, 1].max(), s_] for k, s_ in zip(kp, rng.uniform(0.3, 1, len(kp)))])
+        want_ids = loop_update(tr, kp, boxes)
+        assert tr.update(kp, boxes) == want_ids
+
+
 def test_boxes_to_center_scale():
     c, s = net_utils.boxes_to_center_scale(np.array([[10, 20, 50, 180], [0, 0, 191, 100]], float), (256, 192))
     assert np.allclose(c, [[30, 100], [95.5, 50]]) and np.allclose(s, [160, 191 / 192 * 256])
