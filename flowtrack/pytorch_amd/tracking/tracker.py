@@ -62,7 +62,12 @@ class FlowTracker:
         """keypoints [N,K,3], boxes [N,>=4] (x1,y1,x2,y2[,score]) of the current frame, flow from the previous
         frame (None on the first frame). Returns the track id of every detection."""
         keypoints = np.asarray(keypoints, dtype=np.float64)
-        boxes = np.asarray(boxes, dtype=np.float64).reshape(len(keypoints), -1)
+        boxes = np.asarray(boxes, dtype=np.float64)
+        if len(keypoints) == 0:        # a frame without detections: nothing to match, tracks still move and age
+            keypoints = keypoints.reshape((0,) + (keypoints.shape[1:] if keypoints.ndim == 3 else (len(COCO_DELTA), 3)))
+            boxes = np.zeros((0, boxes.shape[-1] if boxes.ndim == 2 and boxes.shape[-1] >= 4 else 5))
+        else:
+            boxes = boxes.reshape(len(keypoints), -1)
         ids = list(self.tracks)
         if flow is not None and ids:
             moved = propagate_keypoints(np.stack([self.tracks[i]["kpts"] for i in ids]), flow)

@@ -169,7 +169,8 @@ def test_flownet2s_batchnorm_variant(hip_lib):
     m, sd = _build(models.FlowNet2S, SEED + 1, torch.float32, batchNorm=True)
     B, H, W = (int(v) for v in G["synth_shape"])
     flow = m(synth.frame_pairs(SEED, B, H, W).cuda()).cpu().numpy()
-    assert np.abs(flow - G["synth_flow_bn"]).max() <= 2e-3
+    err = np.abs(flow - G["synth_flow_bn"]).max()
+    assert err <= 1e-3, f"FlowNet2S batchNorm: max abs err {err:.3e} px vs the north_star bar 1e-3"
 
 
 @pytest.mark.parametrize("bn", [False, True], ids=["plain", "batchnorm"])
@@ -179,7 +180,7 @@ def test_flownet2sd_fp32_matches_reference_golden(hip_lib, bn):
     B, H, W = (int(v) for v in G["synth_shape"])
     flow = m(synth.frame_pairs(SEED, B, H, W).cuda()).cpu().numpy()
     err = np.abs(flow - G["synth_flow_sd_bn" if bn else "synth_flow_sd"]).max()
-    assert err <= (2e-3 if bn else 1e-3), f"FlowNet2SD bn={bn}: max abs err {err:.3e} px"
+    assert err <= 1e-3, f"FlowNet2SD bn={bn}: max abs err {err:.3e} px vs the north_star bar 1e-3"
 
 
 _ORACLE_FWD = {"FlowNet2S": flow_ref.flownet2s_forward, "FlowNet2C": flow_ref.flownet2c_forward,

@@ -155,7 +155,7 @@ def test_other_flow_stacks_at_512x384_match_the_cpu_oracle(hip_lib, oracle_lib, 
     mag = torch.norm(want, dim=1).mean().item()
     m.compute_dtype = torch.float32
     e32 = (m(pairs.cuda()).cpu() - want).abs().max().item()
-    assert e32 <= 1e-3 * max(1.0, want.abs().max().item() / 10), f"{name} fp32: {e32:.3e}"
+    assert e32 <= 1e-3, f"{name} fp32: max abs err {e32:.3e} px vs the north_star bar 1e-3 (measured round 1: <= 8.3e-5)"
     m16 = getattr(flow_models, name)(ARGS)
     m16.load_state_dict(sd)
     m16 = m16.cuda().eval()
@@ -174,7 +174,8 @@ def test_r101_384x288_batch16_matches_the_cpu_oracle(hip_lib):
     sd = synth.fill_pose_state_dict(m32.state_dict(), SEED)
     want = pose_ref.pose_forward(sd, x, depth=101)
     got = m32(x.cuda()).cpu()
-    assert (got - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item() / 4)
+    e32 = (got - want).abs().max().item()
+    assert e32 <= 1e-3, f"R101 384x288 fp32: max abs err {e32:.3e} vs the north_star bar 1e-3 (measured round 1: ~1e-5)"
     assert torch.equal(got.flatten(2).argmax(2), want.flatten(2).argmax(2))
     got16 = _pose(101, torch.float16)(x.cuda()).cpu()
     assert (got16 - want).abs().max().item() <= 0.05 * (want.max() - want.min()).item()

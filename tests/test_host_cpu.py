@@ -251,3 +251,22 @@ def test_bottleneck_desc_matches_header_and_argument_checks(hip_lib):
     assert hip_lib.ft_bottleneck_flops(ctypes.byref(desc())) == 2.0 * macs
     # NULL operands are an argument error, not a crash (no launch happens)
     assert hip_lib.ft_bottleneck_fwd(ctypes.byref(desc()), None, None, None, None, None, None, None) == invalid
+
+
+def test_flip_test_pairs_follow_the_dataset():
+    """tools/pose/main.py flip test: the left/right table is the dataset's (get_pairs, lib/pose/utils/transforms.py:60-95),
+    not COCO's for everything; a table that does not fit the head raises instead of being skipped."""
+    from tools.pose import main as pose_main
+    assert pose_main.get_flip_pairs("mpii") == [(0, 5), (1, 4), (2, 3), (10, 15), (11, 14), (12, 13)]
+    assert pose_main.get_flip_pairs("aic") == [(0, 3), (1, 4), (2, 5), (6, 9), (7, 10), (8, 11)]
+    assert sorted(map(sorted, pose_main.get_flip_pairs("coco"))) == [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+    with pytest.raises(ValueError):
+        pose_main.get_flip_pairs("lsp")
+    hm = torch.arange(2 * 16 * 3 * 4, dtype=torch.float32).reshape(2, 16, 3, 4)
+    back = pose_main._flip_back(hm, pose_main.get_flip_pairs("mpii"))
+    perm = list(range(16))
+    for a, b in [(0, 5), (1, 4), (2, 3), (10, 15), (11, 14), (12, 13)]:
+        perm[a], perm[b] = perm[b], perm[a]
+    assert torch.equal(back, torch.flip(hm, dims=[3])[:, perm])
+    with pytest.raises(ValueError):
+        pose_main._flip_back(hm[:, :14], pose_main.get_flip_pairs("mpii"))

@@ -63,6 +63,25 @@ def test_tracker_keeps_ids_under_flow_and_spawns_new_ones():
     assert np.isclose(tracker.pose_oks(kp[0], kp[0], 1000.0), 1.0)
 
 
+def test_tracker_survives_a_frame_without_detections():
+    """A frame where no box survives (pose_est returns (0,17,3)): no ids, tracks move with the flow and age; the people
+    coming back one frame later (max_age=1) keep their ids, after two empty frames they are new."""
+    kp = _kp(9, n=2)
+    kp[..., 2] = 0.9
+    boxes = np.array([[k[:, 0].min(), k[:, 1].min(), k[:, 0].max(), k[:, 1].max(), 0.9] for k in kp])
+    flow = np.zeros((2, 96, 128), np.float32); flow[0] = 2.0
+    tr = FlowTracker(oks_threshold=0.5, max_age=1)
+    assert tr.update(kp, boxes) == [0, 1]
+    assert tr.update(np.zeros((0, 17, 3)), np.zeros((0, 5)), flow) == []
+    assert sorted(tr.tracks) == [0, 1] and all(t["age"] == 1 for t in tr.tracks.values())
+    assert np.allclose(tr.tracks[0]["kpts"][:, 0], kp[0, :, 0] + 2.0)              # still propagated
+    moved = kp.copy(); moved[..., 0] += 4.0
+    assert tr.update(moved, boxes + [4, 0, 4, 0, 0], flow) == [0, 1]
+    assert tr.update(np.zeros((0, 17, 3)), np.zeros((0,)), None) == []             # degenerate box array shapes too
+    assert tr.update([], [], flow) == [] and tr.tracks == {}                        # aged out after two empty frames
+    assert tr.update(moved, boxes, flow) == [2, 3]
+
+
 def test_oks_matrix_equals_the_pairwise_loop_and_matching_is_unchanged():
     """pose_oks_matrix (one broadcast) == pose_oks per pair, incl. joints below the score threshold and empty sets; the
     greedy matcher on top of it assigns what the per-pair loop assigned (random poses, several frames)."""

@@ -30,8 +30,21 @@ from flowtrack.pytorch_amd.pose import evaluation, models    # noqa: E402
 from tools.pose.config import opt                            # noqa: E402
 
 num_joints = {'mpii': 16, 'aic': 14, 'coco': 17}
-# COCO left/right keypoint pairs (lib/pose/utils/transforms.py flip helpers)
-COCO_FLIP_PAIRS = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16)]
+# left/right joint pairs per dataset: the (joint_right, joint_left) tables of get_pairs, lib/pose/utils/transforms.py:60-95,
+# which swaplr_image applies with opt.dataset (tools/pose/main.py:294-296)
+FLIP_PAIRS = {
+    'coco': [(2, 1), (4, 3), (6, 5), (8, 7), (10, 9), (12, 11), (14, 13), (16, 15)],
+    'mpii': [(0, 5), (1, 4), (2, 3), (10, 15), (11, 14), (12, 13)],
+    'aic': [(0, 3), (1, 4), (2, 5), (6, 9), (7, 10), (8, 11)],
+}
+COCO_FLIP_PAIRS = FLIP_PAIRS['coco']
+
+
+def get_flip_pairs(dataset):
+    """Joint pairs swapped by the flip test for `dataset`; an unknown dataset raises (the reference only prints)."""
+    if dataset not in FLIP_PAIRS:
+        raise ValueError("flip test: no left/right joint table for dataset '{}'".format(dataset))
+    return FLIP_PAIRS[dataset]
 
 
 def _flip_back(hm, pairs):
@@ -39,8 +52,9 @@ def _flip_back(hm, pairs):
     hm = torch.flip(hm, dims=[3])
     idx = list(range(hm.shape[1]))
     for a, b in pairs:
-        if a < len(idx) and b < len(idx):
-            idx[a], idx[b] = idx[b], idx[a]
+        if a >= len(idx) or b >= len(idx):
+            raise ValueError('flip pair ({}, {}) does not fit {} heatmap channels: wrong dataset table?'.format(a, b, len(idx)))
+        idx[a], idx[b] = idx[b], idx[a]
     return hm[:, idx]
 
 
@@ -107,7 +121,8 @@ def main(**kwargs):
     if 'valid' not in opt.run_type and 'test' not in opt.run_type:
         raise ValueError("run_type '{}': training is out of scope of the HIP path (use 'valid')".format(opt.run_type))
     batches = kwargs.get('batches') or synthetic_batches(opt.num_samples, opt.test_batch_size, opt.input_res, opt.seed)
-    out = validate(model, batches, flip_test=opt.flip_test, adjust_coords=opt.adjust_coords)
+    out = validate(model, batches, flip_test=opt.flip_test, adjust_coords=opt.adjust_coords,
+                   flip_pairs=get_flip_pairs(opt.dataset) if opt.flip_test else ())
     out['model'] = model
     return out
 
