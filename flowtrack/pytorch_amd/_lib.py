@@ -86,6 +86,10 @@ _PROTOTYPES = {
     "ft_bottleneck_supported": (c_int, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_flops": (c_double, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_stream_supported": (c_int, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_stream_weight_bytes": (ctypes.c_longlong, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_stream_pack": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ft_bottleneck_stream_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_pack_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ft_unpack_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),

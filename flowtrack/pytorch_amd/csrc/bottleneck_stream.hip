@@ -1,0 +1,695 @@
+// Whole-bottleneck fusion for the 128- and 256-plane ResNet stages (fp16): conv1 1x1 + bn1 + relu -> conv2 3x3 + bn2 +
+// relu -> conv3 1x1 + bn3 + identity residual + relu in ONE launch, with every weight byte STREAMED through LDS
+// (reference: Bottleneck.forward, lib/pose/models/blocks.py:105-120, the blocks without a projection shortcut:
+// layer2.1-3 / layer3.1-5 of ResNet-50, layer3.1-22 of ResNet-101, resnet.py:29-36,51-55).
+//
+// Why a second fused kernel (bottleneck.hip covers the 64-plane stage): at 512 / 1024 channels the three launches of a
+// block are no longer HBM-bound, they are bound by operand delivery L2 -> LDS: with 12 k .. 49 k pixels per layer the
+// GEMM tiles that fill 256 CUs are small (64x64 .. 128x128), every operand byte is re-delivered M/BP or N/BC times
+// (200 + 226 + 200 MB per layer3 block at batch 64) and the three launches take 82 (layer3) / 94 us (layer2) for 27.4
+// GFLOP.  Here a workgroup owns a full-width strip of output rows of one image, keeps t1 and t2 in LDS and streams the
+// block's weights ONCE through a ring (2.2 MB per workgroup at 256 planes, 0.55 MB at 128): the pixel operand never
+// leaves the CU, the weight operand arrives as 1-KiB-contiguous DMA pieces (pre-packed in MFMA fragment order, so the
+// LDS image needs no swizzle and ds_read_b128 is lane-linear).  tools/dev/ubench/stream_ring.hip is the micro-model of
+// the inner loop: 1.24 PFLOP/s chip-wide at 256 workgroups (21 B/clk/CU of weights beside the matrix pipe).
+//
+// Geometry (P planes, C = 4P channels; 4 waves = WCOLS x WPG, wave = 2 output-channel tiles x MT pixel tiles of 32):
+//   P = 256: WCOLS 4, WPG 1: strip <= 96 output pixels (MT2 = 3) on <= 120 halo pixels (MT1 = 4)   [or 64 on 96]
+//   P = 128: WCOLS 2, WPG 2: strip <= 192 output pixels on <= 256 halo pixels
+//   phase 1  t1 = relu(bn1(W1 . x)) on the strip + one halo row above and below: x streams in 64-channel chunks (whole
+//            128-byte lines per pixel, XOR-swizzled on the source side), W1 in matching K-slices; the residual (the
+//            strip's own pixels) is picked out of the chunks in phase 3's accumulator layout as they pass through LDS.
+//   phase 2  t2 = relu(bn2(W2 * t1)): the pixel operand of tap (ky, kx) is T1 at row offset ky*W + kx - 1 (full-width
+//            strips make the 3x3 neighbourhood a linear shift; the two x-border taps are lane-masked); only W2 streams.
+//   phase 3  y = relu(bn3(W3 . t2) + x) in four quarters of P output channels; each lane owns 16 consecutive channels of
+//            a pixel (the A-fragment rows are permuted at pack time), so y leaves as 32-byte runs per lane.
+// LDS: T1 / T2 (aliased) <= 60 / 64 KiB, three x-chunk buffers (inside the T1 region during phase 1), three weight-step
+// buffers, two folded-BN table buffers = 160 KiB, one workgroup per CU.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "ft_common.h"
+
+namespace ft {
+namespace {
+
+struct BnsParams {
+  const char* x;
+  char* y;
+  const char* ws;    // packed weight stream (ft_bottleneck_stream_pack)
+  const char* tab;   // float [6][2P]: {s1 b1} {s2 b2} {s3 b3 of quarter 0} .. {quarter 3}
+  int H, W, TH;      // image size, output rows per strip
+  int ppi, total;    // strips per image, workgroups
+  int x_cstride, x_coff, y_cstride, y_coff;
+  unsigned x_bytes, y_bytes, ws_bytes;
+  int dbg;
+};
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void bns_unroll(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    bns_unroll<N, I + 1>(f);
+  }
+}
+
+#define BNS_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// MFMA row r of an A fragment holds output channel sigma(r) of its 32-channel tile, so that accumulator register k of
+// lane (pixel, half) is channel 16 * half + k: 16 consecutive channels per lane.
+__host__ __device__ constexpr int bns_sigma(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
+
+template <int P>
+struct BnsGeom {
+  static constexpr int C = 4 * P;
+  static constexpr int NCT = P / 32;          // output-channel tiles of a P-wide GEMM
+  static constexpr int WCOLS = P / 64;        // wave columns (2 channel tiles each)
+  static constexpr int WPG = 4 / WCOLS;       // pixel groups
+  static constexpr int NC1 = C / 64;          // x chunks = weight steps of phase 1
+  static constexpr int KC = P / 64;           // 64-wide K chunks of a P-deep GEMM
+  static constexpr int WSTEP = NCT * 4096;    // bytes of a weight step: 4 K16 slices x NCT fragments x 1 KiB
+  static constexpr int LW = NCT;              // 1-KiB weight loads per wave per step
+  static constexpr int G2 = NC1, G3 = NC1 + 9 * KC, GEND = G3 + 4 * KC;
+  static constexpr int ROWB = 2 * P;          // bytes of a T1 / T2 / staging row
+  static constexpr int TABB = 8 * P;          // bytes of one table {scale[P], shift[P]}
+  static constexpr int LT = P / 128;          // 256-byte table loads per wave
+  // LDS map: [0, ..) three x-chunk buffers in phase 1, then T1, then T2 (+ the output staging tile behind it at 128
+  // planes); one folded-BN table, one all-zero row (the x-border taps read it), three weight-step buffers
+  static constexpr int XSTRIDE = P == 256 ? 16384 : 32768;
+  static constexpr int T1_ROWS = P == 256 ? 120 : 256;
+  static constexpr int TAB = P == 256 ? 61440 : 98304;
+  static constexpr int ZROW = TAB + TABB;
+  static constexpr int WBASE = P == 256 ? 65536 : 114688;
+  static constexpr int STG = 49152;           // P = 128: staging tile [48 K, 96 K)
+  static constexpr int LDS_BYTES = 163840;
+  static_assert(ZROW % ROWB == 0 && ZROW + ROWB <= WBASE && WBASE + 3 * WSTEP == LDS_BYTES, "LDS map");
+};
+
+template <int P, int MT1, int MT2>
+__global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using G = BnsGeom<P>;
+  constexpr int NCT = G::NCT, WCOLS = G::WCOLS, WPG = G::WPG, NC1 = G::NC1, KC = G::KC, WSTEP = G::WSTEP, LW = G::LW;
+  constexpr int ROWB = G::ROWB;
+  constexpr int XROWS = WPG * MT1 * 32, LX = WPG * MT1;     // rows of an x chunk buffer; 1-KiB x loads per wave per chunk
+  constexpr int NOUT = WPG * MT2 * 32;                       // output pixels of the strip (padded)
+  // the output tile of a quarter goes through LDS for whole-line stores: behind T2 at 128 planes, in the weight buffer the
+  // quarter's last step has just released at 256 planes (32 KiB: the 64-pixel strips only)
+  constexpr bool STAGED = P == 128 || NOUT * ROWB <= WSTEP;
+  static_assert(XROWS * 128 <= G::XSTRIDE, "x chunk buffer");
+  static_assert(NOUT * ROWB <= 49152, "T2 fits below the staging tile / inside the T1 region");
+  static_assert(2 * (LX + LW) <= 63, "vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wcol = wave % WCOLS, pg = wave / WCOLS;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int logical;
+  {
+    const int b = blockIdx.x;
+    const int q = p.total >> 3, r = p.total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int n = logical / p.ppi;
+  const int y0 = (logical - n * p.ppi) * p.TH;
+  const int W = p.W;
+  const int rows_out = p.H - y0 < p.TH ? p.H - y0 : p.TH;
+  const int npix_out = rows_out * W;
+  const int npix_halo = (p.TH + 2) * W;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 6 * G::TABB, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- loaders -------------------------------------------------------------------------------------------------------
+  // x chunk: row = halo pixel, 128 bytes (64 channels); a 1-KiB wave load covers 8 rows, lane -> (row = lane / 8,
+  // 16-byte position lane % 8), the XOR swizzle (position ^= row & 7) is applied to the SOURCE position
+  unsigned x_voff[LX];
+#pragma unroll
+  for (int t = 0; t < LX; ++t) {
+    const int hp = (t * 4 + wave) * 8 + (lane >> 3);
+    const int hr = hp / W, hc = hp - hr * W;
+    const int iy = y0 - 1 + hr;
+    unsigned v = kOOB;
+    if (hp < npix_halo && (unsigned)iy < (unsigned)p.H)
+      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ (hp & 7)) << 4));
+    x_voff[t] = v;
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto issue_x = [&](int c, int buf) {
+    char* dst = smem + buf * G::XSTRIDE;
+#pragma unroll
+    for (int t = 0; t < LX; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x_voff[t], c * 128, 0, 0);
+  };
+  auto issue_w = [&](int g, int buf) {
+    char* dst = smem + G::WBASE + buf * WSTEP;
+#pragma unroll
+    for (int t = 0; t < LW; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, lane16,
+                                               g * WSTEP + (t * 4 + wave) * 1024, 0, 0);
+  };
+  auto issue_tab = [&](int e) {       // {scale[P], shift[P]} of epilogue e; one buffer: issued once epilogue e-1 is behind a barrier
+#pragma unroll
+    for (int t = 0; t < G::LT; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + G::TAB + (t * 4 + wave) * 256), 4, (unsigned)lane * 4u,
+                                               e * G::TABB + (t * 4 + wave) * 256, 0, 0);
+  };
+  // per-lane A-fragment base inside a weight step: fragment (kk, channel tile 2*wcol + i) at (kk * NCT + 2*wcol + i) KiB
+  const unsigned a_base = (unsigned)(G::WBASE + (2 * wcol) * 1024) + lane16;
+  uint4_t fa[2][2];                   // A fragments, two register sets: slice k+1 is read while slice k multiplies
+
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BNS_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  BNS_TS(0);
+  // prologue: table 0, chunks 0..2 (x + W1 slice each), the zero row
+  issue_tab(0);
+  issue_x(0, 0); issue_w(0, 0);
+  issue_x(1, 1); issue_w(1, 1);
+  issue_x(2, 2); issue_w(2, 2);
+  if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + G::ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
+
+  // residual = the block input at the strip's own pixels, in phase 3's accumulator layout: [quarter][tile i][pixel tile j][half]
+  uint4_t res[4][2][MT2][2];
+  int m_out[MT2];       // output pixel (strip-relative, row-major at width W) of this lane per pixel tile
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) m_out[j] = (pg * MT2 + j) * 32 + l31;
+
+  // ================= phase 1: t1 = relu(bn1(W1 . x)) on the halo strip =============================================
+  float16_t acc1[2][MT1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT1; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+  int b1_off[MT1];      // x-chunk fragment offsets (buffer-relative): row hp, 16-byte position (kk*2 + lhi) ^ (hp & 7)
+#pragma unroll
+  for (int j = 0; j < MT1; ++j) {
+    const int hp = (pg * MT1 + j) * 32 + l31;
+    b1_off[j] = hp * 128 + ((lhi ^ (hp & 7)) << 4);
+  }
+  {
+    uint4_t fx[2][MT1];
+    auto ld1 = [&](auto setc, int buf, int kk) {
+      constexpr int S = decltype(setc)::value;
+      const unsigned ab = a_base + buf * WSTEP;
+      const char* xb = smem + buf * G::XSTRIDE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[S][i] = *reinterpret_cast<const uint4_t*>(smem + ab + (kk * NCT + i) * 1024);
+#pragma unroll
+      for (int j = 0; j < MT1; ++j) fx[S][j] = *reinterpret_cast<const uint4_t*>(xb + (b1_off[j] ^ (kk << 5)));
+    };
+    auto mma1 = [&](auto setc) {
+      constexpr int S = decltype(setc)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MT1; ++j)
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[S][i]), __builtin_bit_cast(half8_t, fx[S][j]),
+                                                              acc1[i][j], 0, 0, 0);
+    };
+    // chunk 0 has landed (this wave's share) while chunks 1 and 2 fly; after the barrier everyone's share has
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (LX + LW)) : "memory");
+    BNS_BARRIER();
+    ld1(c0{}, 0, 0);
+    bns_unroll<NC1>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int buf = c % 3;
+      __builtin_amdgcn_sched_barrier(0);
+      ld1(c1{}, buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(c0{});
+      __builtin_amdgcn_sched_barrier(0);
+      ld1(c0{}, buf, 2);
+      if (c % WCOLS == wcol) {       // this chunk holds the channels of this wave column for quarter c / WCOLS
+        constexpr int q = c / WCOLS;
+        const char* xb = smem + buf * G::XSTRIDE;
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) {
+          const int hp = m_out[j] + W;
+          const char* rowp = xb + hp * 128;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ (hp & 7)) << 4));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(c1{});
+      __builtin_amdgcn_sched_barrier(0);
+      ld1(c1{}, buf, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(c0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (c + 1 < NC1) {
+        // chunk c+1 has landed (chunk c+2 may fly), every read of chunk c's buffers is complete: refill them with chunk c+3
+        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + LW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LW) : "memory");
+        BNS_BARRIER();
+        if constexpr (c + 3 < NC1) issue_x(c + 3, buf);
+        issue_w(c + 3, buf);
+        ld1(c0{}, (c + 1) % 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mma1(c1{});
+    });
+  }
+  // every wave is past its last x-chunk read once it reaches this barrier: the x buffers become T1
+  BNS_TS(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNS_BARRIER();
+  {
+    const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < MT1; ++j) {
+        const int hp = (pg * MT1 + j) * 32 + l31;
+        const int hr = hp / W;
+        const int iy = y0 - 1 + hr;
+        const bool inside = (unsigned)iy < (unsigned)p.H;     // out-of-image halo rows are conv2's zero padding
+        half8_t h8[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = __builtin_fmaxf(acc1[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
+          h8[r >> 3][r & 7] = inside ? (half_t)v : (half_t)0.f;
+        }
+        if (hp < npix_halo) {
+          char* rowp = smem + hp * ROWB;
+          const int cb = (2 * wcol + i) * 4 + 2 * lhi;           // 16-byte chunk of channel `ch`
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<half8_t*>(rowp + (((cb + h) ^ (hp & 15)) << 4)) = h8[h];
+        }
+      }
+    }
+  }
+  BNS_TS(2);
+
+  // ================= phases 2 + 3: weight steps G2 .. GEND-1, pixel operand from T1 / T2 ===========================
+  float16_t acc[2][MT2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  uint4_t fb[2][MT2];
+  auto ld2 = [&](auto setc, int buf, int kk, const int (&rb)[MT2]) {
+    constexpr int S = decltype(setc)::value;
+    const unsigned ab = a_base + buf * WSTEP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[S][i] = *reinterpret_cast<const uint4_t*>(smem + ab + (kk * NCT + i) * 1024);
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (kk << 5)));
+  };
+  auto mma2 = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[S][i]), __builtin_bit_cast(half8_t, fb[S][j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+  // x-border flags of this lane's output pixels: bit 0 = first column (tap kx = 0 is padding), bit 1 = last column
+  int edge[MT2];
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) {
+    const int ox = m_out[j] % W;
+    edge[j] = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+  }
+  // byte base of pixel row `m + off` of the T region for K chunk kc (slice kk is one more XOR); lanes whose tap is
+  // x-padding read the zero row instead
+  auto row_bases = [&](int off, int kc, int bad, int (&rb)[MT2]) {
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const int row = m_out[j] + off;
+      const int v = row * ROWB + (((row & 15) ^ lhi) << 4);
+      rb[j] = ((edge[j] & bad) ? G::ZROW + (lhi << 4) : v) ^ (kc << 7);
+    }
+  };
+  // one weight step (slices 1..3 of it, slice 0 already sits in register set 0) with the hand-over to the next one in front
+  // of its last slice: the next step's weights have landed (this wave's share, then everyone's), every read of THIS step's
+  // buffer is complete, so the buffer is refilled with step g+3 (unless `defer`: phase 3 stages its output tile there first)
+  auto pstep = [&](int g, int buf, const int (&rb)[MT2], bool has_next, const int (&rb_next)[MT2], int tab_e, bool defer) {
+    __builtin_amdgcn_sched_barrier(0);
+    ld2(c1{}, buf, 1, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(c0{});
+    __builtin_amdgcn_sched_barrier(0);
+    ld2(c0{}, buf, 2, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(c1{});
+    __builtin_amdgcn_sched_barrier(0);
+    ld2(c1{}, buf, 3, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(c0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) {
+      if (g + 2 < G::GEND) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      BNS_BARRIER();
+      if (tab_e >= 0) issue_tab(tab_e);
+      if (g + 3 < G::GEND && !defer) issue_w(g + 3, buf);
+      ld2(c0{}, buf == 2 ? 0 : buf + 1, 0, rb_next);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma2(c1{});
+  };
+  // start of a phase: the T region has just been written, weight step g has landed: slice 0 into register set 0
+  auto pstart = [&](int g, int buf, const int (&rb)[MT2], int tab_e) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LW) : "memory");
+    BNS_BARRIER();
+    issue_tab(tab_e);
+    issue_w(g + 2, buf == 0 ? 2 : buf - 1);          // (g + 2) % 3: the buffer of step g-1
+    ld2(c0{}, buf, 0, rb);
+  };
+
+  // ---- phase 2: nine taps x KC chunks ---------------------------------------------------------------------------------
+  {
+    int rb[MT2], rbn[MT2];
+    row_bases(-1, 0, 1, rb);                         // tap (0, 0), chunk 0
+    pstart(G::G2, G::G2 % 3, rb, 1);
+    int g = G::G2, buf = G::G2 % 3;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const bool has_next = !(tap == 8 && kc == KC - 1);
+        int nky = ky, nkx = kx, nkc = kc + 1;
+        if (nkc == KC) { nkc = 0; if (++nkx == 3) { nkx = 0; ++nky; } }
+        row_bases(nky * W + nkx - 1, nkc, nkx == 0 ? 1 : (nkx == 2 ? 2 : 0), rbn);
+        pstep(g, buf, rb, has_next, rbn, -1, false);
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
+        ++g;
+        buf = buf == 2 ? 0 : buf + 1;
+      }
+    }
+  }
+  // every wave is past its last T1 read once it reaches this barrier: T2 overwrites T1
+  BNS_TS(3);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNS_BARRIER();
+  {
+    const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < MT2; ++j) {
+        const int m = m_out[j];
+        half8_t h8[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          h8[r >> 3][r & 7] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
+        char* rowp = smem + m * ROWB;
+        const int cb = (2 * wcol + i) * 4 + 2 * lhi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<half8_t*>(rowp + (((cb + h) ^ (m & 15)) << 4)) = h8[h];
+      }
+    }
+  }
+  zero_acc();
+  BNS_TS(4);
+
+  // ---- phase 3: four quarters of P output channels, K = P -------------------------------------------------------------
+  {
+    // direct form: lane -> 32-byte runs of its own pixel; staged form: thread -> 16-byte chunks of whole pixel rows
+    unsigned y_voff[MT2];
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const int m = m_out[j];
+      y_voff[j] = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + (2 * wcol) * 32 + 16 * lhi) * 2) : kOOB;
+    }
+    constexpr int CPR = ROWB / 16;                   // 16-byte chunks per staging row
+    constexpr int NSTG = NOUT * CPR / 256;           // chunks per thread
+    unsigned s_voff[STAGED ? NSTG : 1];
+    int s_off[STAGED ? NSTG : 1];
+    if constexpr (STAGED) {
+#pragma unroll
+      for (int k = 0; k < NSTG; ++k) {
+        const int idx = tid + 256 * k, m = idx / CPR, ch = idx % CPR;
+        s_voff[k] = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
+        s_off[k] = m * ROWB + ((ch ^ (m & 15)) << 4);
+      }
+    }
+    int rb[MT2];
+    row_bases(0, 0, 0, rb);
+    pstart(G::G3, G::G3 % 3, rb, 2);
+    bns_unroll<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      bns_unroll<KC>([&](auto kcc) {
+        constexpr int kc = decltype(kcc)::value;
+        constexpr int g = G::G3 + q * KC + kc;
+        constexpr bool last_of_q = kc == KC - 1;
+        int rbn[MT2];
+        row_bases(0, last_of_q ? 0 : kc + 1, 0, rbn);
+        // the table of the NEXT quarter's epilogue follows the barrier of the quarter's first step
+        pstep(g, g % 3, rb, g + 1 < G::GEND, rbn, (kc == 0 && q > 0) ? 2 + q : -1, STAGED && P == 256 && last_of_q);
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
+      });
+      if constexpr (q == 3) {
+        // the last table: no later hand-over waits for it, and every wave loaded only its share of it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BNS_BARRIER();
+      }
+      constexpr int glast = G::G3 + q * KC + KC - 1;
+      char* stg = smem + (P == 128 ? G::STG : G::WBASE + (glast % 3) * WSTEP);
+      const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+        float4_t sc[4], sh[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int r = h * 8 + e;
+              o[e] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
+            }
+            if constexpr (STAGED) {
+              const int m = m_out[j];
+              *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
+            } else if (!(p.dbg & 4)) {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, y_voff[j], (q * P + i * 32 + h * 8) * 2, 0);
+            }
+          }
+        }
+      }
+      zero_acc();
+      if constexpr (STAGED) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BNS_BARRIER();
+#pragma unroll
+        for (int k = 0; k < NSTG; ++k) {
+          const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
+          if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, 0);
+        }
+        if constexpr (P == 256 && q < 3) {
+          // the staging tile sat in a weight buffer: hand it back (its refill with step glast + 3 was deferred)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          BNS_BARRIER();
+          if constexpr (glast + 3 < G::GEND) issue_w(glast + 3, glast % 3);
+        }
+      }
+    });
+  }
+  if (p.dbg & 32) {       // dev: phase timestamps of wave 0 over the strip's first output pixel (the output is garbage then)
+    ts[5] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y + ((size_t)((n * p.H + y0) * W) * p.y_cstride + p.y_coff) * 2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    }
+  }
+#endif
+}
+
+// ---- weight stream packing -------------------------------------------------------------------------------------------
+// w1 [P][C], w2 [P][9P] (k = tap * P + ci), w3 [C][P]: the K-major layouts of ft_conv_pack_geometry.  One thread per
+// 16-byte piece of the stream: step g, slice kk, channel tile i, lane -> 8 consecutive k of one output channel.
+template <int P>
+__global__ __launch_bounds__(256) void bns_pack_kernel(const half_t* __restrict__ w1, const half_t* __restrict__ w2,
+                                                       const half_t* __restrict__ w3, uint4_t* __restrict__ out) {
+  using G = BnsGeom<P>;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= G::GEND * G::WSTEP / 16) return;
+  const int lane = idx & 63, frag = idx >> 6;
+  const int per_step = 4 * G::NCT;
+  const int g = frag / per_step, f = frag - g * per_step;
+  const int kk = f / G::NCT, i = f - kk * G::NCT;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int co_t = 32 * i + bns_sigma(l31);
+  const int k_t = 16 * kk + 8 * lhi;
+  const half_t* src;
+  if (g < G::G2) {
+    src = w1 + (size_t)co_t * G::C + 64 * g + k_t;
+  } else if (g < G::G3) {
+    const int s = g - G::G2, tap = s / G::KC, kc = s - tap * G::KC;
+    src = w2 + (size_t)co_t * (9 * P) + tap * P + 64 * kc + k_t;
+  } else {
+    const int s = g - G::G3, q = s / G::KC, kc = s - q * G::KC;
+    src = w3 + (size_t)(q * P + co_t) * P + 64 * kc + k_t;
+  }
+  out[idx] = *reinterpret_cast<const uint4_t*>(src);
+}
+
+struct BnsPlan {
+  int variant;   // 0: <128,4,3>  1: <256,4,3>  2: <256,3,2>
+  int TH, ppi;
+};
+
+static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
+  if (!d) return FT_ERR_INVALID_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
+  if (d->dtype != FT_F16 || d->head_only || (d->P != 128 && d->P != 256) || d->C != 4 * d->P) return FT_ERR_UNSUPPORTED;
+  if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
+  if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + d->C) return FT_ERR_INVALID_ARG;
+  if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->H * d->W * d->y_cstride * 2 >= (1LL << 31))
+    return FT_ERR_UNSUPPORTED;
+  auto rows = [&](int outcap, int halocap) {
+    int th = outcap / d->W;
+    const int th2 = halocap / d->W - 2;
+    th = th < th2 ? th : th2;
+    if (th < 1) return 0;
+    th = th < d->H ? th : d->H;
+    return ceil_div(d->H, ceil_div(d->H, th));     // same strip count, balanced rows
+  };
+  static const int force = getenv("FT_BNS_VARIANT") ? atoi(getenv("FT_BNS_VARIANT")) : -1;
+  if (d->P == 128) {
+    const int th = rows(192, 256);
+    if (th < 1) return FT_ERR_UNSUPPORTED;
+    *out = BnsPlan{0, th, ceil_div(d->H, th)};
+    return FT_OK;
+  }
+  const int th_big = rows(96, 120), th_small = rows(64, 96);
+  if (th_big < 1 && th_small < 1) return FT_ERR_UNSUPPORTED;
+  int pick;
+  if (force == 1 || force == 2) pick = force;
+  else {
+    // the big strip halves the weight stream per pixel; the small one doubles the workgroups when the big one leaves CUs idle
+    const long long wg_big = th_big >= 1 ? (long long)d->N * ceil_div(d->H, th_big) : 0;
+    pick = (th_big >= 1 && (wg_big >= 224 || th_small < 1)) ? 1 : 2;
+  }
+  if (pick == 1 && th_big < 1) pick = 2;
+  if (pick == 2 && th_small < 1) pick = 1;
+  const int th = pick == 1 ? th_big : th_small;
+  *out = BnsPlan{pick, th, ceil_div(d->H, th)};
+  return FT_OK;
+}
+
+template <int P, int MT1, int MT2>
+static int bns_launch(const BnsParams& p, hipStream_t s) {
+  auto k = bottleneck_stream_kernel<P, MT1, MT2>;
+  static bool attr_done[64] = {};          // the LDS opt-in is per device
+  int dev = 0;
+  FT_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, BnsGeom<P>::LDS_BYTES));
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(k, dim3(p.total), dim3(256), BnsGeom<P>::LDS_BYTES, s, p);
+  FT_LAUNCH_CHECK("bottleneck_stream_kernel");
+  return FT_OK;
+}
+
+}  // namespace
+}  // namespace ft
+
+extern "C" int ft_bottleneck_stream_supported(const ft_bottleneck_desc* d) {
+  ft::BnsPlan pl;
+  return ft::bns_plan(d, &pl);
+}
+
+extern "C" long long ft_bottleneck_stream_weight_bytes(const ft_bottleneck_desc* d) {
+  ft::BnsPlan pl;
+  if (ft::bns_plan(d, &pl) != FT_OK) return 0;
+  return d->P == 128 ? (long long)ft::BnsGeom<128>::GEND * ft::BnsGeom<128>::WSTEP : (long long)ft::BnsGeom<256>::GEND * ft::BnsGeom<256>::WSTEP;
+}
+
+extern "C" int ft_bottleneck_stream_pack(const ft_bottleneck_desc* d, const void* w1, const void* w2, const void* w3, void* wstream,
+                                         ft_stream_t stream) {
+  using namespace ft;
+  BnsPlan pl;
+  const int st = bns_plan(d, &pl);
+  if (st != FT_OK) return st;
+  if (!w1 || !w2 || !w3 || !wstream) return FT_ERR_INVALID_ARG;
+  hipStream_t s = as_stream(stream);
+  const half_t *a = static_cast<const half_t*>(w1), *b = static_cast<const half_t*>(w2), *c = static_cast<const half_t*>(w3);
+  if (d->P == 128) {
+    const int n16 = BnsGeom<128>::GEND * BnsGeom<128>::WSTEP / 16;
+    hipLaunchKernelGGL(bns_pack_kernel<128>, dim3(ceil_div(n16, 256)), dim3(256), 0, s, a, b, c, static_cast<uint4_t*>(wstream));
+  } else {
+    const int n16 = BnsGeom<256>::GEND * BnsGeom<256>::WSTEP / 16;
+    hipLaunchKernelGGL(bns_pack_kernel<256>, dim3(ceil_div(n16, 256)), dim3(256), 0, s, a, b, c, static_cast<uint4_t*>(wstream));
+  }
+  FT_LAUNCH_CHECK("bns_pack_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
+                                        ft_stream_t stream) {
+  using namespace ft;
+  BnsPlan pl;
+  const int st = bns_plan(d, &pl);
+  if (st != FT_OK) return st;
+  if (!x || !wstream || !tables || !y || x == y) return FT_ERR_INVALID_ARG;
+  BnsParams p{};
+  p.x = static_cast<const char*>(x);
+  p.y = static_cast<char*>(y);
+  p.ws = static_cast<const char*>(wstream);
+  p.tab = reinterpret_cast<const char*>(tables);
+  p.H = d->H; p.W = d->W; p.TH = pl.TH; p.ppi = pl.ppi;
+  p.total = d->N * pl.ppi;
+  p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
+  p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->x_cstride * 2);
+  p.y_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->y_cstride * 2);
+  p.ws_bytes = (unsigned)ft_bottleneck_stream_weight_bytes(d);
+  static const int dbg = getenv("FT_BNS_DBG") ? atoi(getenv("FT_BNS_DBG")) : 0;
+  p.dbg = dbg;
+  hipStream_t s = as_stream(stream);
+  switch (pl.variant) {
+    case 0: return bns_launch<128, 4, 3>(p, s);
+    case 1: return bns_launch<256, 4, 3>(p, s);
+    default: return bns_launch<256, 3, 2>(p, s);
+  }
+}

@@ -93,7 +93,7 @@ def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int
 # --------------------------------------------------------------------------------------------
 def is_conv_call(name: str) -> bool:
     """Launches whose work is convolution MACs (the roofline's kernels): ft_conv2d_fwd[_ws] and ft_bottleneck_fwd."""
-    return name.startswith("ft_conv2d_fwd") or name == "ft_bottleneck_fwd"
+    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd")
 
 
 class Program:
@@ -674,7 +674,14 @@ def bottleneck_fusable(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: Act
     if any(c.transposed or c.tail_cout or c.act != ACT_CODES["relu"] or c._bn is None for c in (c1, c2, c3)):
         return False
     d = _bottleneck_desc(x, y, c2.cin)
-    return _lib.load().ft_bottleneck_supported(ctypes.byref(d)) == 0
+    lib = _lib.load()
+    return lib.ft_bottleneck_supported(ctypes.byref(d)) == 0 or (
+        FUSE_BOTTLENECK_STREAM and lib.ft_bottleneck_stream_supported(ctypes.byref(d)) == 0)
+
+
+#: the streamed-weights fused bottleneck (ft_bottleneck_stream_fwd) for the 128- / 256-plane stages; FT_FUSE_BOTTLENECK_STREAM=0
+#: keeps their three conv launches
+FUSE_BOTTLENECK_STREAM = os.environ.get("FT_FUSE_BOTTLENECK_STREAM", "1") != "0"
 
 
 def _bottleneck_desc(x: ActView, y: ActView, planes: int, head_only: bool = False) -> _lib.BottleneckDesc:
@@ -744,7 +751,30 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
     w2, s2, b2 = _bottleneck_packed(c2, x, (planes, 9 * planes, 1), label)
     w3, s3, b3 = _bottleneck_packed(c3, x, (x.C, planes, 1), label)
     d = _bottleneck_desc(x, y, planes)
-    check(lib.ft_bottleneck_supported(ctypes.byref(d)), "ft_bottleneck_supported")
+    if lib.ft_bottleneck_supported(ctypes.byref(d)) != 0:
+        # 128 / 256 planes: the streamed-weights kernel; its weight stream is built once per weight set by the library
+        check(lib.ft_bottleneck_stream_supported(ctypes.byref(d)), "ft_bottleneck_stream_supported")
+        flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
+        key = ("bns_stream", x.N, x.H, x.W)
+        cached = c1._packed.get(key) if hasattr(c1, "_packed") else None
+        if cached is None:
+            nbytes = int(lib.ft_bottleneck_stream_weight_bytes(ctypes.byref(d)))
+            wstream = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
+            check(lib.ft_bottleneck_stream_pack(ctypes.byref(d), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), wstream.data_ptr(),
+                                                current_stream_handle(x.t.device)), "ft_bottleneck_stream_pack")
+            torch.cuda.current_stream(x.t.device).synchronize()     # plan-build time: the plan may replay on another stream
+            P = planes
+            tables = torch.cat([s1.flatten()[:P], b1.flatten()[:P], s2.flatten()[:P], b2.flatten()[:P]] +
+                               [t.flatten()[q * P:(q + 1) * P] for q in range(4) for t in (s3, b3)]).float().contiguous()
+            cached = (wstream, tables)
+            if hasattr(c1, "_packed"):
+                c1._packed[key] = cached
+        wstream, tables = cached
+        prog.flops += flops
+        prog.fused_records.append((label, len(prog.calls), flops))
+        prog.add("ft_bottleneck_stream_fwd", ctypes.byref(d), x.t.data_ptr(), wstream.data_ptr(), tables.data_ptr(), y.t.data_ptr(),
+                 keep=(d, x.t, y.t, wstream, tables))
+        return
     flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
     prog.flops += flops
     prog.fused_records.append((label, len(prog.calls), flops))
@@ -774,8 +804,9 @@ def record_upsample4x(prog: Program, x: torch.Tensor, y: torch.Tensor, mul: floa
     prog.add("ft_upsample_bilinear4x", x.data_ptr(), y.data_ptr(), N, C, h, w, ctypes.c_float(mul), keep=(x, y))
 
 
-def current_stream_handle() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def current_stream_handle(device=None) -> ctypes.c_void_p:
+    """Handle of torch's current stream on `device` (default: the current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def heatmap_max_preds(heatmaps: torch.Tensor, adjust_coords: bool):

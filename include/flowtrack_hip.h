@@ -213,6 +213,21 @@ int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,
 /* algorithmic FLOPs of the three convs (2*MACs, no halo recompute) */
 double ft_bottleneck_flops(const ft_bottleneck_desc* d);
 
+/* Streamed-weights form of the same fusion for the 128- and 256-plane stages (fp16, C = 4P, P = 128 or 256, stride 1,
+ * head_only = 0; ResNet layer2.1+ / layer3.1+): a workgroup owns a full-width strip of output rows of one image, keeps
+ * t1 / t2 in LDS and streams the block's weights once through an LDS ring (csrc/bottleneck_stream.hip).
+ *   ft_bottleneck_stream_weight_bytes  size of the packed weight stream (0 when unsupported)
+ *   ft_bottleneck_stream_pack          builds it from the three convs' ft_conv_pack_geometry layouts
+ *                                      (w1 [P][C], w2 [P][9P] with k = (ky*3+kx)*P + ci, w3 [C][P]); once per weight set
+ *   ft_bottleneck_stream_fwd           tables = float[6][2P]: {scale1, shift1} {scale2, shift2} then {scale3, shift3} of
+ *                                      output channels [qP, qP+P) for q = 0..3; y must not alias x. */
+int ft_bottleneck_stream_supported(const ft_bottleneck_desc* d);
+long long ft_bottleneck_stream_weight_bytes(const ft_bottleneck_desc* d);
+int ft_bottleneck_stream_pack(const ft_bottleneck_desc* d, const void* w1, const void* w2, const void* w3, void* wstream,
+                              ft_stream_t stream);
+int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
+                             ft_stream_t stream);
+
 /* ---- layout / pooling helpers -------------------------------------------- */
 /* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,wpitch,cpad]: pixel x lands in column lpad + x, channels
  * >= C and all other columns are zeroed (wpitch = W, lpad = 0: plain NHWC; cpad multiple of 4).

@@ -21,6 +21,23 @@ CASES = [
     ("view_offset", 1, 16, 16, 320, 32),             # input is a channel slice of a wider buffer
     ("many_patches_recycle", 24, 64, 48, 256, 0),    # 2304 workgroups: > 4 rounds on 512 slots (LDS reuse across workgroups)
 ]
+# ft_bottleneck_stream_fwd (128 / 256 planes, full-width strips): (name, N, H, W, x channel stride, x channel offset, planes)
+STREAM_CASES = [
+    ("s128_r50_32x24", 3, 32, 24, 512, 0, 128),      # layer2 of R50 at 256x192: 4 strips of 8 rows, exact
+    ("s128_r101_48x36", 1, 48, 36, 512, 0, 128),     # layer2 of R101 at 384x288: strips of 5 rows, last one ragged
+    ("s128_ragged_13x20", 2, 13, 20, 512, 0, 128),   # 9-row strips on 13 rows
+    ("s128_tiny_5x3", 1, 5, 3, 512, 0, 128),         # one strip, mostly padding lanes
+    ("s128_view_offset", 1, 16, 16, 576, 32, 128),   # input is a channel slice of a wider buffer
+    ("s128_wide_60", 1, 6, 60, 512, 0, 128),         # width 60: two output rows per strip
+    ("s256_r50_16x12", 5, 16, 12, 1024, 0, 256),     # layer3 of R50: few workgroups -> the 4-row strips (64 px on 96)
+    ("s256_r101_24x18", 2, 24, 18, 1024, 0, 256),    # layer3 of R101
+    ("s256_tiny_5x3", 1, 5, 3, 1024, 0, 256),
+    ("s256_view_offset", 1, 9, 7, 1056, 32, 256),
+    ("s256_many_recycle", 300, 16, 12, 1024, 0, 256),  # 600 workgroups of 8 rows: > 2 rounds on 256 CUs (LDS reuse across workgroups)
+    ("s128_many_recycle", 160, 32, 24, 512, 0, 128),   # 640 workgroups
+    ("s256_r101_big_strips", 40, 24, 18, 1024, 0, 256),  # 240 workgroups of 4 rows x 18 (72 px on 108)
+    ("s256_small_recycle", 100, 16, 12, 1024, 0, 256),   # 400 workgroups of the 4-row strips: > 1 round on 256 CUs
+]
 
 
 def _bn(seed, name, c):
@@ -33,11 +50,12 @@ def _bnf(y, bn):
     return F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], training=False, eps=1e-5)
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("case", CASES + STREAM_CASES, ids=[c[0] for c in CASES + STREAM_CASES])
 def test_fused_bottleneck_matches_oracle_and_the_three_launches(hip_lib, case):
-    name, N, H, W, xcs, xoff = case
+    name, N, H, W, xcs, xoff = case[:6]
     dev, dtype, seed = torch.device("cuda:0"), torch.float16, 21
-    C, P = 256, 64
+    P = case[6] if len(case) > 6 else 64
+    C = 4 * P
     w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
     w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
     w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
@@ -78,6 +96,8 @@ def test_fused_bottleneck_matches_oracle_and_the_three_launches(hip_lib, case):
     diff = (got - sep).abs()
     assert diff.max().item() <= 1e-2 * scale, f"{name}: fused vs separate launches max abs diff {diff.max().item():.3e}"
     assert (diff > 0).float().mean().item() < 0.05, "fused and separate launches should agree bit for bit almost everywhere"
+    if P != 64:
+        assert prog.calls[0][0] == "ft_bottleneck_stream_fwd", prog.calls[0][0]
 
     # determinism: same bits on a second run (poisoned output first)
     y_fused.t.fill_(5.0)

@@ -1,0 +1,281 @@
+// Microbenchmark for the streamed-weights bottleneck kernel (csrc/bottleneck_stream.hip): one workgroup per CU pulls a
+// SHARED, fragment-ordered weight stream (every 1-KiB wave load contiguous) through a ring of 16-KiB LDS slots while
+// its waves run the 2 co x 3 px (4 waves) or 1 co x 3 px (8 waves) MFMA micro-tile against an LDS-resident pixel
+// operand.  Question it answers: how many bytes per clock per CU does L2 -> LDS deliver in this regime, and how much of
+// the matrix pipe survives beside it?   hipcc --offload-arch=gfx950 -O3 stream_ring.hip -o stream_ring
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void unroll_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    unroll_for<N, I + 1>(f);
+  }
+}
+
+// NW waves; a step consumes SI slots (16 KiB each) = SI*16 A fragments; RING slots in the ring (multiple of SI);
+// MFMA: 0 = none (pure delivery), 1 = full micro-tile
+template <int NW, int SI, int RING, int MFMA, int AUX>
+__global__ __launch_bounds__(64 * NW, 1) void stream_kernel(const char* __restrict__ w, unsigned w_bytes, int steps, float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int kT1 = 65536;                 // pixel operand region (garbage is fine)
+  char* ring = lds + kT1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, w_bytes, 0x00020000);
+  constexpr int LPW = SI * 16 / NW;          // 1-KiB loads per wave per step
+  constexpr int NSTEP_RING = RING / SI;      // steps the ring holds
+  const unsigned lane_off = lane * 16u;
+  unsigned goff = 0;                         // stream position of the next step to issue
+  auto issue_step = [&](int rslot) {
+#pragma unroll
+    for (int t = 0; t < LPW; ++t) {
+      const int piece = t * NW + wave;       // 1-KiB piece of the step
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ring + rslot * (SI * 16384) + piece * 1024), 16, lane_off,
+                                               goff + piece * 1024, 0, AUX);
+    }
+    goff += SI * 16384;
+    if (goff + SI * 16384 > w_bytes) goff = 0;
+  };
+  constexpr int CO = NW == 4 ? 2 : 1;        // co tiles per wave
+  float16_t acc[CO][3];
+#pragma unroll
+  for (int i = 0; i < CO; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int b_off[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = j * 32 + l31 + 13;
+    b_off[j] = r * 512 + ((lhi ^ (r & 15)) << 4);
+  }
+#pragma unroll
+  for (int s = 0; s < NSTEP_RING - 1; ++s) issue_step(s);
+  int rs_cur = 0, rs_nxt = NSTEP_RING - 1;
+  constexpr int K16 = SI * 2;
+  for (int st = 0; st < steps; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPW * (NSTEP_RING - 2)) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    issue_step(rs_nxt);
+    if (MFMA) {
+      const char* sl = ring + rs_cur * (SI * 16384);
+#pragma unroll
+      for (int k = 0; k < K16; ++k) {
+        uint4_t fa[CO], fb[3];
+#pragma unroll
+        for (int i = 0; i < CO; ++i) fa[i] = *reinterpret_cast<const uint4_t*>(sl + ((k * 8 + (NW == 4 ? wave * 2 + i : wave)) * 1024) + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fb[j] = *reinterpret_cast<const uint4_t*>(lds + (b_off[j] ^ (((k & 15) * 2) << 4)));
+#pragma unroll
+        for (int i = 0; i < CO; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[i]), __builtin_bit_cast(half8_t, fb[j]), acc[i][j], 0, 0, 0);
+      }
+    }
+    rs_cur = rs_cur + 1 == NSTEP_RING ? 0 : rs_cur + 1;
+    rs_nxt = rs_nxt + 1 == NSTEP_RING ? 0 : rs_nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CO; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 123.456f) sink[0] = s + ((float*)lds)[lane];
+#endif
+}
+
+// Software-pipelined variant (4 waves, 2 co x 3 px): the fragments of K16 slice k+1 are read into a second register
+// set while the MFMAs of slice k run; the (wait, barrier, refill) event of a step sits in front of the LAST slice of the
+// previous step, so the first slice of a step is prefetched like any other.
+template <int SI, int RING, int PRIO>
+__global__ __launch_bounds__(256, 1) void stream_pipe_kernel(const char* __restrict__ w, unsigned w_bytes, int steps, float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int kT1 = 65536, NW = 4;
+  char* ring = lds + kT1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, w_bytes, 0x00020000);
+  constexpr int LPW = SI * 16 / NW;
+  constexpr int NSTEP_RING = RING / SI;
+  constexpr int K16 = SI * 2;
+  const unsigned lane_off = lane * 16u;
+  unsigned goff = 0;
+  auto issue_step = [&](int rslot) {
+#pragma unroll
+    for (int t = 0; t < LPW; ++t) {
+      const int piece = t * NW + wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ring + rslot * (SI * 16384) + piece * 1024), 16, lane_off,
+                                               goff + piece * 1024, 0, 0);
+    }
+    goff += SI * 16384;
+    if (goff + SI * 16384 > w_bytes) goff = 0;
+  };
+  float16_t acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int b_off[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = j * 32 + l31 + 13;
+    b_off[j] = r * 512 + ((lhi ^ (r & 15)) << 4);
+  }
+  uint4_t fa[2][2], fb[2][3];
+  auto read_slice = [&](auto setc, const char* sl, int k) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[S][i] = *reinterpret_cast<const uint4_t*>(sl + ((k * 8 + wave * 2 + i) * 1024) + lane * 16);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(lds + (b_off[j] ^ (((k & 15) * 2) << 4)));
+  };
+  auto mma = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[S][i]), __builtin_bit_cast(half8_t, fb[S][j]), acc[i][j], 0, 0, 0);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+#pragma unroll
+  for (int s = 0; s < NSTEP_RING - 1; ++s) issue_step(s);
+  int rs_cur = 0, rs_nxt = NSTEP_RING - 1;
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * (NSTEP_RING - 2)) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+  issue_step(rs_nxt);
+  rs_nxt = rs_nxt + 1 == NSTEP_RING ? 0 : rs_nxt + 1;
+  read_slice(std::integral_constant<int, 0>{}, ring, 0);
+  static_assert(K16 % 2 == 0, "even slices per step");
+  for (int st = 0; st < steps; ++st) {
+    const char* sl = ring + rs_cur * (SI * 16384);
+    const int rs_n = rs_cur + 1 == NSTEP_RING ? 0 : rs_cur + 1;
+    unroll_for<K16>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k == K16 - 1) {
+        // next step's data: this wave's loads landed, then everyone's; everyone is past the reads of the slot refilled below
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * (NSTEP_RING - 2)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue_step(rs_nxt);
+        read_slice(std::integral_constant<int, (k + 1) & 1>{}, ring + rs_n * (SI * 16384), 0);
+      } else {
+        read_slice(std::integral_constant<int, (k + 1) & 1>{}, sl, k + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(std::integral_constant<int, k & 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    rs_cur = rs_n;
+    rs_nxt = rs_nxt + 1 == NSTEP_RING ? 0 : rs_nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 123.456f) sink[0] = s + ((float*)lds)[lane];
+#endif
+}
+
+template <int SI, int RING, int PRIO>
+void run_pipe(const char* w, unsigned wb, int grid, int steps, float* sink, const char* label) {
+  auto k = stream_pipe_kernel<SI, RING, PRIO>;
+  const int ldsb = 65536 + RING * 16384;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, 0, w, wb, 8, sink);
+  CK(hipDeviceSynchronize());
+  float best = 1e9f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, 0, w, wb, steps, sink);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = ms < best ? ms : best;
+  }
+  const double bytes = (double)grid * steps * SI * 16384.0;
+  const double us = best * 1e3;
+  const double flops = (double)grid * steps * (SI * 2) * (8 * 3) * 32768.0;
+  printf("%-44s grid %3d  %7.1f us  %6.2f TB/s  %5.1f B/clk/CU(2.4GHz)  %7.1f TFLOP/s  cycles/step %6.0f\n", label, grid, us,
+         bytes / us * 1e-6, bytes / grid / (us * 2400.0), flops / us * 1e-6, us * 2400.0 / steps);
+}
+
+template <int NW, int SI, int RING, int MFMA, int AUX>
+void run(const char* w, unsigned wb, int grid, int steps, float* sink, const char* label) {
+  auto k = stream_kernel<NW, SI, RING, MFMA, AUX>;
+  const int ldsb = 65536 + RING * 16384;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), ldsb, 0, w, wb, 8, sink);
+  CK(hipDeviceSynchronize());
+  float best = 1e9f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), ldsb, 0, w, wb, steps, sink);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = ms < best ? ms : best;
+  }
+  const double bytes = (double)grid * steps * SI * 16384.0;
+  const double us = best * 1e3;
+  const double flops = MFMA ? (double)grid * steps * (SI * 2) * (8 * 3) * 32768.0 : 0.0;   // 8 co tiles x 3 px tiles per K16 slice
+  printf("%-44s grid %3d  %7.1f us  %6.2f TB/s  %5.1f B/clk/CU(2.4GHz)  %7.1f TFLOP/s  cycles/step %6.0f\n", label, grid, us,
+         bytes / us * 1e-6, bytes / grid / (us * 2400.0), flops / us * 1e-6, us * 2400.0 / steps);
+}
+
+int main() {
+  const unsigned wb = 2304u << 10;   // 2.25 MiB weight stream (one 256-plane bottleneck), shared by every workgroup
+  char* w; float* sink;
+  CK(hipMalloc(&w, wb)); CK(hipMemset(w, 0, wb)); CK(hipMalloc(&sink, 64));
+  // random-ish fp16 payload so the matrix pipe burns real power (DVFS, guide rule 25)
+  {
+    unsigned short* h = (unsigned short*)malloc(wb);
+    unsigned x = 12345;
+    for (unsigned i = 0; i < wb / 2; ++i) { x = x * 1664525u + 1013904223u; h[i] = 0x3000 | ((x >> 9) & 0x0fff) | ((x >> 3) & 0x8000); }
+    CK(hipMemcpy(w, h, wb, hipMemcpyHostToDevice));
+    free(h);
+  }
+  const int steps = 144 * 4;         // 2.25 MiB / 32 KiB = 72 steps of two slots per pass; a few passes
+  for (int grid : {128, 256}) {
+    run<4, 2, 6, 0, 0>(w, wb, grid, steps, sink, "4 waves, 32K/step, ring 6, no mfma");
+    run<4, 2, 6, 1, 0>(w, wb, grid, steps, sink, "4 waves, 32K/step, ring 6, mfma 2x3");
+    run<4, 2, 6, 1, 2>(w, wb, grid, steps, sink, "4 waves, 32K/step, ring 6, mfma 2x3, nt");
+    run<4, 2, 4, 1, 0>(w, wb, grid, steps, sink, "4 waves, 32K/step, ring 4, mfma 2x3");
+    run<4, 1, 6, 1, 0>(w, wb, grid, steps * 2, sink, "4 waves, 16K/step, ring 6, mfma 2x3");
+    run<4, 1, 3, 1, 0>(w, wb, grid, steps * 2, sink, "4 waves, 16K/step, ring 3, mfma 2x3");
+    run_pipe<2, 6, 0>(w, wb, grid, steps, sink, "4 waves PIPELINED, 32K/step, ring 6");
+    run_pipe<2, 6, 1>(w, wb, grid, steps, sink, "4 waves PIPELINED, 32K/step, ring 6, setprio");
+    run_pipe<1, 6, 0>(w, wb, grid, steps * 2, sink, "4 waves PIPELINED, 16K/step, ring 6");
+    run_pipe<3, 6, 0>(w, wb, grid, steps * 2 / 3, sink, "4 waves PIPELINED, 48K/step, ring 6");
+    run<8, 2, 6, 0, 0>(w, wb, grid, steps, sink, "8 waves, 32K/step, ring 6, no mfma");
+    run<8, 2, 6, 1, 0>(w, wb, grid, steps, sink, "8 waves, 32K/step, ring 6, mfma 1x3");
+    run<8, 2, 4, 1, 0>(w, wb, grid, steps, sink, "8 waves, 32K/step, ring 4, mfma 1x3");
+  }
+  return 0;
+}
