@@ -9,7 +9,14 @@ One "step" = one pass of the pose hot path over one batch that is already reside
 NCHW fp32 crops -> NHWC pack -> ResNet-50 + 3x deconv + heatmap conv (HIP graph) -> per-map arg-max /
 sub-pixel nudge (ft_heatmap_max_preds) [-> RCCL all-gather of the keypoint rows when N > 1].
 Workload = BASELINE.json configs[1]: ResNet-50 pose head, fp16, batch 64 x 256x192 per GPU (weak scaling).
-`--workload flow` times FlowNet2S on configs[3]'s 16 x 512x384 frame pairs instead (pairs/s).
+BASELINE.json's metric is "pose crops/sec + flow frame-pairs/sec ...; mAP@OKS vs CPU ref": the headline `value` is the
+pose half; the default run adds, in the SAME JSON line, the sub-records
+  "flow"             FlowNet2S fp16 on configs[3]'s 16 x 512x384 pairs per GPU, timed with the same protocol (its own
+                     roofline, cpu_baseline and `roofline_ops` = the correlation / warp / channelnorm kernels at C4 shapes);
+  "fp32_parity_mode" the pose step in the arithmetic whose arg-max is bit-exact vs the CPU reference;
+  "parity"           heat-map error / identical-arg-max fraction / mAP@OKS of both modes on the benchmarked batch vs the
+                     CPU oracle (N = 1 only, outside every timed region).
+`--workload flow` makes FlowNet2S the headline instead; `--no-extras` prints the headline alone.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -152,11 +159,163 @@ def cpu_baseline_flow(seconds=15.0):
                       f"(fastest of the tried counts; {avail} logical CPUs visible)"}
 
 
+HBM_PEAK_TBS = 8.0   # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+
+
+def timed_region(step, steps, device):
+    """Barrier + synchronize on both sides of exactly `steps` steps; returns the MAX over ranks of the elapsed seconds."""
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    return parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+
+
+def spin_up(step, device, seconds=0.5):
+    """Untimed: keep stepping until the GPU has been busy for `seconds`, so a timed region does not start on the idle
+    clocks of a freshly woken GPU.  Every rank runs the same number of steps (step() may hold a collective): the ranks
+    agree on "keep going" through a MAX all-reduce of their own verdict."""
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter()
+    while True:
+        more = 1.0 if time.perf_counter() - t_warm < seconds else 0.0
+        if parallel.max_over_ranks(more, device=device) < 0.5:
+            break
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+
+
+def flow_op_rooflines(device, B=16, H=384, W=512, iters=20):
+    """The three custom operators of the FLOW path at BASELINE configs[3] shapes (SURVEY §8 "Reading of C4"), each
+    against the HBM roof: algorithmic bytes (in the kernel's own storage type) / hipEvent time."""
+    import ctypes
+    from flowtrack.pytorch_amd import _lib
+    from flowtrack.pytorch_amd.hip_ops import ActView, Program, new_rowpacked_act
+    prog = Program(torch.cuda.Stream(device))
+    f16 = _lib.dtype_code(torch.float16)
+    h8, w8 = H // 8, W // 8
+    c3 = torch.randn((2 * B, h8, w8, 256), device=device).half()
+    cin31 = torch.zeros((B, h8, w8, 480), dtype=torch.float16, device=device)
+    prog.add("ft_correlation_nhwc_fwd", c3[:B].data_ptr(), c3[B:].data_ptr(), cin31.data_ptr(), B, 256, h8, w8, 20, 2, 256, 480, 32,
+             _lib.FT_ACT_LEAKY, ctypes.c_float(0.1), f16, keep=(c3, cin31))
+    x6 = new_rowpacked_act(B, H, W, 6, 3, torch.float16, device)
+    x6.t.normal_()
+    flow = torch.randn((B, 2, H, W), device=device) * 4
+    cat1 = new_rowpacked_act(B, H, W, 12, 3, torch.float16, device)
+    prog.add("ft_flow_warp_concat", x6.t.data_ptr(), flow.data_ptr(), ctypes.c_float(20.0), cat1.t.data_ptr(), B, H, W, x6.lpad,
+             x6.wpitch, cat1.lpad, cat1.wpitch, f16, keep=(x6.t, flow, cat1.t))
+    img = torch.randn((B, 3, H, W), device=device)
+    warped = torch.empty_like(img)
+    prog.add("ft_resample2d_fwd", img.data_ptr(), flow.data_ptr(), warped.data_ptr(), B, 3, H, W, keep=(img, flow, warped))
+    norm = torch.empty((B, 1, H, W), device=device)
+    prog.add("ft_channelnorm_fwd", img.data_ptr(), norm.data_ptr(), B, 3, H, W, keep=(img, norm))
+    torch.cuda.synchronize()
+    prog.run_eager()
+    prog.stream.synchronize()
+    times = prog.time_calls(iters=iters)
+    px = B * H * W
+    algo = {
+        # fp16 NHWC: two [B,256,48,64] feature maps in, 441 channels out (SURVEY §8(d): 5.86 MB / pair)
+        "ft_correlation_nhwc_fwd": (2 * B * 256 * h8 * w8 * 2 + B * 441 * h8 * w8 * 2, 2.0 * B * 441 * h8 * w8 * 256),
+        # x6 (8 fp16 ch) + flow (2 fp32) in, 16 fp16 channels out
+        "ft_flow_warp_concat": (px * (16 + 8 + 32), 0.0),
+        "ft_resample2d_fwd": (px * 4 * (3 + 2 + 3), 0.0),       # 6.29 MB / pair (fp32 NCHW, the reference's own form)
+        "ft_channelnorm_fwd": (px * 4 * (3 + 1), 0.0),          # (reads 3 channels, writes 1)
+    }
+    out = []
+    for name, ms in times:
+        nbytes, flops = algo[name]
+        tbs = nbytes / (ms * 1e-3) / 1e12
+        row = {"kernel": name, "shape": f"[{B},256,{h8},{w8}] x2 -> 441 ch" if "corr" in name else f"[{B},*,{H},{W}]",
+               "bound": "hbm", "us": round(ms * 1e3, 1), "algorithmic_bytes": nbytes, "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS,
+               "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4)}
+        if flops:
+            row["tflops"] = round(flops / (ms * 1e-3) / 1e12, 1)
+        out.append(row)
+    return out
+
+
+def pose_parity(models_by_mode, x_cpu, seed, H, W, oracle_out=None):
+    """The "mAP@OKS vs CPU ref" half of the metric on the benchmarked batch: GPU heat maps / key points of each mode vs
+    the CPU oracle (its key points are the annotations).  Also the margin of every arg-max flip in the
+    oracle's own heat map: oracle[top-1] - oracle[GPU's pick] (a flip is only possible inside twice the heat-map error)."""
+    import numpy as np
+    from flowtrack.pytorch_amd.pose import evaluation
+    from oracle import keypoints_ref, pose_ref
+    m0 = next(iter(models_by_mode.values()))
+    sd = {k: v.detach().float().cpu() for k, v in m0.state_dict().items()}
+    B = x_cpu.shape[0]
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    want = torch.cat([pose_ref.pose_forward(sd, x_cpu[i:i + 4]) for i in range(0, B, 4)])
+    center = np.stack((np.full(B, W / 2.0), np.full(B, H / 2.0)), 1)
+    scale = np.full(B, H / 200.0)
+    ref_coords, ref_scores, ref_idx, _ = keypoints_ref.final_preds_ref(want.numpy(), center, scale, adjust_coords=True)
+    anno = np.concatenate((ref_coords, np.ones_like(ref_scores)), axis=2)
+    out = {"crops": B, "annotations": "CPU-oracle key points (final_preds, adjust_coords) of the benchmarked batch",
+           "heatmap_range": round(float(want.max() - want.min()), 4)}
+    wflat = want.flatten(2).numpy()
+    for mode, m in models_by_mode.items():
+        hm = m(x_cpu.to(next(m.parameters()).device))
+        coords, scores = evaluation.final_preds(hm, center, scale, adjust_coords=True)
+        _, _, idx = keypoints_ref.max_preds_ref(hm.float().cpu().numpy())
+        pred = np.concatenate((coords, scores), axis=2)
+        aps = evaluation.eval_mAP([pred], [anno], [scale * scale], evaluation.COCO_DELTA)
+        err = float((hm.float().cpu() - want).abs().max())
+        flips = idx != ref_idx
+        margin = np.take_along_axis(wflat, ref_idx[..., None], 2)[..., 0] - np.take_along_axis(wflat, idx[..., None], 2)[..., 0]
+        out[mode] = {"heatmap_max_abs_err": err, "argmax_identical_frac": round(float(1.0 - flips.mean()), 6),
+                     "argmax_flips": int(flips.sum()), "max_flip_margin_in_oracle_heatmap": float(margin[flips].max()) if flips.any() else 0.0,
+                     "keypoint_max_abs_err_px": float(np.abs(coords - ref_coords).max()),
+                     "mAP_at_OKS": round(float(np.mean(aps)), 4)}
+    return out
+
+
+def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B):
+    """(model, x, step): the pose hot path on a batch resident in HBM, arg-max inside the plan's graph."""
+    model = build_pose(device, dtype, backbone=backbone)
+    model.keypoints_in_plan = True                          # arg-max + 0.25 px nudge run inside the plan's graph
+    x = model.static_input(B, H, W)                         # zero-copy binding: the batch is resident in HBM at the
+    x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
+    kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
+
+    def step():
+        _, _, score, coords = model.forward_keypoints(x)
+        rows = torch.cat((coords, score), dim=2)            # [B,17,3] keypoint rows
+        rows = parallel.all_gather_rows(rows, B * world) if world > 1 else rows
+        kp_host.copy_(rows[rank * B:(rank + 1) * B] if world > 1 else rows, non_blocking=True)
+        return rows
+    return model, x, step
+
+
+def make_flow_runner(args, device, dtype, rank, world, name, B):
+    model = build_flow(device, dtype, name=name)
+    x = model.static_input(B, 384, 512)                     # zero-copy binding (see the pose runner)
+    x.copy_(synth.frame_pairs(100 + rank, B))
+
+    def step():
+        flow = model(x, copy_output=False)
+        return parallel.all_gather_rows(flow, B * world) if world > 1 else flow
+    return model, x, step
+
+
+def measure(step, steps, warmup, device, fixed_warmup=False):
+    for _ in range(max(warmup, 2)):   # >= 2: first run is eager (+ tile benchmark) + graph capture, second replays the graph
+        step()
+    if not fixed_warmup:
+        spin_up(step, device)
+    return timed_region(step, steps, device)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=800, help="timed steps (default: ~1.1 s of the 64-crop pose step)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["pose", "flow"], default="pose")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 crops / 16 pairs)")
@@ -168,6 +327,7 @@ def main():
     ap.add_argument("--fixed-warmup", action="store_true", help="exactly max(W,2) untimed steps (profiling runs that count launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no flow / fp32_parity_mode / parity sub-records")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     args = ap.parse_args()
 
@@ -180,71 +340,29 @@ def main():
     torch.cuda.set_device(device)
     dtype = torch.float16 if args.dtype == "fp16" else torch.float32
 
-    from flowtrack.pytorch_amd.hip_ops import heatmap_max_preds
-
     if args.workload == "pose":
         B = args.batch or 64
         H, W = (int(v) for v in args.res.lower().split("x"))
         depth = args.backbone[len("resnet"):]
         default_cfg = args.backbone == "resnet50" and (H, W) == (256, 192)
-        model = build_pose(device, dtype, backbone=args.backbone)
-        model.keypoints_in_plan = True                          # arg-max + 0.25 px nudge run inside the plan's graph
-        x = model.static_input(B, H, W)                         # zero-copy binding: the batch is resident in HBM at the
-        x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
+        model, x, step = make_pose_runner(args, device, dtype, rank, world, args.backbone, H, W, B)
         unit, metric = "crops/s", f"pose crops/sec (ResNet-{depth} + 3-deconv head, {H}x{W})"
-        kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
-
-        def step():
-            _, _, score, coords = model.forward_keypoints(x)
-            rows = torch.cat((coords, score), dim=2)            # [B,17,3] keypoint rows
-            rows = parallel.all_gather_rows(rows, B * world) if world > 1 else rows
-            kp_host.copy_(rows[rank * B:(rank + 1) * B] if world > 1 else rows, non_blocking=True)
-            return rows
         cfg = "configs[1]" if default_cfg else ("configs[2]" if (args.backbone, H, W) == ("resnet101", 384, 288) else "variant")
         workload = f"ResNet-{depth} pose head {args.dtype}, batch {B} x {H}x{W} synthetic crops per GPU (BASELINE.json {cfg})"
     else:
         B = args.batch or 16
         default_cfg = args.flow_model == "FlowNet2S"
-        model = build_flow(device, dtype, name=args.flow_model)
-        x = model.static_input(B, 384, 512)                     # zero-copy binding (see the pose branch)
-        x.copy_(synth.frame_pairs(100 + rank, B))
+        model, x, step = make_flow_runner(args, device, dtype, rank, world, args.flow_model, B)
         unit, metric = "pairs/s", f"flow frame-pairs/sec ({args.flow_model}, 512x384)"
-
-        def step():
-            flow = model(x, copy_output=False)
-            return parallel.all_gather_rows(flow, B * world) if world > 1 else flow
         workload = (f"{args.flow_model} {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU "
                     f"(BASELINE.json configs[3]{'' if default_cfg else ' shape, other stack'})")
 
-    for _ in range(max(args.warmup, 2)):   # >= 2: first run is eager (+ tile benchmark) + graph capture, second replays the graph
-        step()
-    # untimed: keep replaying until the GPU has been busy for ~0.5 s, so the timed region does not start on the
-    # idle clocks of a freshly woken GPU (observed: an occasional 2x slower 30-step region right after start-up)
-    torch.cuda.synchronize()
-    t_warm = time.perf_counter()
-    while not args.fixed_warmup:
-        # every rank must run the same number of steps (step() holds a collective when world > 1): the ranks agree
-        # on "keep going" through a MAX all-reduce of their own elapsed-time verdict
-        more = 1.0 if time.perf_counter() - t_warm < 0.5 else 0.0
-        if parallel.max_over_ranks(more, device=device) < 0.5:
-            break
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
-
+    elapsed = measure(step, args.steps, args.warmup, device, args.fixed_warmup)
     value = B * world * args.steps / elapsed
     out = {
         "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (counter-hash crops ~N(0,1) / translated-texture frame pairs, He-scaled random weights)",
         "config": {"workload": workload, "per_gpu_batch": B,
                    "parallelism": f"dp{world}: batch sharded, one process per GPU" + (", RCCL all-gather of outputs" if world > 1 else "")},
@@ -265,6 +383,51 @@ def main():
                           file=sys.stderr)
         if not args.no_cpu_baseline and world == 1 and default_cfg:
             out["cpu_baseline"] = cpu_baseline_pose() if args.workload == "pose" else cpu_baseline_flow()
+
+    # ---- the rest of BASELINE.json's metric, in the same line (default pose run only) -----------------------------------
+    extras = (not args.no_extras and args.workload == "pose" and args.dtype == "fp16" and default_cfg and not args.batch
+              and not args.fixed_warmup)
+    if extras:
+        # (1) FlowNet2S fp16 on configs[3]'s pairs, every rank, same protocol; sized for >= ~1 s like the headline
+        fsteps = max(20, min(args.steps, 1200))
+        fmodel, fx, fstep = make_flow_runner(args, device, torch.float16, rank, world, "FlowNet2S", 16)
+        fel = measure(fstep, fsteps, args.warmup, device)
+        if rank == 0:
+            fplan = next(iter(fmodel._plans.values()))
+            fval = 16 * world * fsteps / fel
+            rec = {"metric": "flow frame-pairs/sec (FlowNet2S, 512x384)", "value": round(fval, 2), "unit": "pairs/s", "steps": fsteps,
+                   "ms_per_step": round(1e3 * fel / fsteps, 4), "timed_region_s": round(fel, 4), "dtype": "fp16",
+                   "config": {"workload": "FlowNet2S fp16, batch 16 x 512x384 synthetic frame pairs per GPU (BASELINE.json configs[3])",
+                              "per_gpu_batch": 16},
+                   "gflop_per_unit": round(fplan.prog.flops / 16 / 1e9, 3)}
+            if not args.no_roofline:
+                froof, _ = conv_roofline(fplan.prog, "fp16")
+                froof["traffic"] = pmc_traffic("flow")
+                froof["traffic_unit"] = "HBM bytes per conv launch (avg), rocprofv3 PMC, profiles/"
+                rec["roofline"] = froof
+                rec["roofline_ops"] = flow_op_rooflines(device)
+            if not args.no_cpu_baseline and world == 1:
+                rec["cpu_baseline"] = cpu_baseline_flow(seconds=8.0)
+            out["flow"] = rec
+        del fmodel, fx, fstep
+        # (2) the pose step in fp32 parity mode (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, peak 157.3 TFLOP/s)
+        psteps = max(10, min(args.steps // 10, 80))
+        pmodel, px, pstep = make_pose_runner(args, device, torch.float32, rank, world, "resnet50", 256, 192, 64)
+        pel = measure(pstep, psteps, 3, device)
+        if rank == 0:
+            pplan = next(iter(pmodel._plans.values()))
+            pval = 64 * world * psteps / pel
+            rec = {"value": round(pval, 2), "unit": "crops/s", "steps": psteps, "ms_per_step": round(1e3 * pel / psteps, 4),
+                   "timed_region_s": round(pel, 4), "dtype": "fp32",
+                   "note": "same workload in the parity arithmetic: heat maps <= 1e-3 and arg-max identical vs the CPU reference"}
+            if not args.no_roofline:
+                proof, _ = conv_roofline(pplan.prog, "fp32")
+                rec["roofline"] = {k: proof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us")}
+            out["fp32_parity_mode"] = rec
+            # (3) parity of both modes on the benchmarked batch vs the CPU oracle (checker role only, outside timed regions)
+            if world == 1:
+                out["parity"] = pose_parity({"fp16": model, "fp32": pmodel}, synth.pose_crops(100 + rank, 64, 256, 192), 1234, 256, 192)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     parallel.barrier()
 

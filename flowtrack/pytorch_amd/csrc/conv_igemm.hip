@@ -76,7 +76,7 @@ struct ConvParams {
   int epi_lds;        // fp16 NHWC, 8-channel aligned: transpose the tile through LDS for 16-byte coalesced stores
   int sk;             // split-K across workgroups (1: none): grid = tiles * sk, fp32 partial tiles go to `ws`
   float* ws;          // [sk][nph * M][Cout_pad] partial sums, reduced by conv_splitk_reduce_kernel
-  const char* tail_w; // fused tail 1x1 conv: fp16 [32][Cout] weights + fp32 [32] bias, or nullptr
+  const char* tail_w; // fused tail 1x1 conv: fp16 [32][Cout] weights (hi) + fp32 [32] bias + fp16 [32][Cout] (lo = w - hi), or nullptr
   int tail_cout;
   const char* x2;     // second input (K-concat), or nullptr
   int kc2;            // its K-steps (0: none)
@@ -263,8 +263,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
       if (p.tail_w) {
         // fused tail 1x1 conv on the LDS-resident tile (BC == Cout: every channel of these pixels is here):
         // out2[co2][pix] = sum_c Wt[co2][c] * tile[pix][c]; one 32-pixel group per wave, K = BC in steps of 16
+        // tail weights arrive as an fp16 hi / lo pair (w = hi + lo to ~22 bits): the heatmap conv runs on fp32-grade
+        // weights, two MFMAs per K slice (the head's last step decides the arg-max)
         const half_t* wt = reinterpret_cast<const half_t*>(p.tail_w);
         const float* bt = reinterpret_cast<const float*>(p.tail_w + (size_t)32 * BC * 2);
+        const half_t* wl = reinterpret_cast<const half_t*>(p.tail_w + (size_t)32 * BC * 2 + 128);
         for (int g = wave; g < BP / 32; g += NT / 64) {
           const int pl = g * 32 + l31;
           float16_t a2;
@@ -274,7 +277,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
           for (int k0 = 0; k0 < BC; k0 += 16) {
             const uint4_t wa = *reinterpret_cast<const uint4_t*>(wt + l31 * BC + k0 + lhi * 8);
             const uint4_t tb = *reinterpret_cast<const uint4_t*>(s_tile + pl * ROWB + ((((k0 >> 3) + lhi) ^ (pl & (NCH - 1))) << 4));
+            const uint4_t wb = *reinterpret_cast<const uint4_t*>(wl + l31 * BC + k0 + lhi * 8);
             a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wa), __builtin_bit_cast(half8_t, tb), a2, 0, 0, 0);
+            if (!(p.dbg & 128))
+              a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wb), __builtin_bit_cast(half8_t, tb), a2, 0, 0, 0);
           }
           const long long o = s_opix[pl];
           if (o >= 0) {
@@ -967,7 +973,31 @@ void conv_igemm_dma_kernel(const ConvParams p) {
       // ... after the barrier everyone's have, and everyone is done reading the slot refilled below
       FT_LDS_BARRIER();
       const char* st = smem + slot * STAGE;
-      uint4_t fa[KK][MT_C], fb[KK][MT_P];
+      // 8 accumulator tiles per wave (the 256 x 256 tile): fragments are read slice by slice, 24 instead of 96 registers
+      // (two waves per SIMD share the 512-entry file: 128 accumulators + all four slices at once spilled 300 registers)
+      constexpr bool kPerSlice = sizeof(T) == 2 && MT_C * MT_P >= 8 && KK > 2;
+      if constexpr (kPerSlice) {
+        static_for<KK>([&](auto kkc) {
+          constexpr int kk = decltype(kkc)::value;
+          uint4_t fa1[MT_C], fb1[MT_P];
+#pragma unroll
+          for (int i = 0; i < MT_C; ++i) fa1[i] = *reinterpret_cast<const uint4_t*>(st + (a_off[i] ^ (kk << 5)));
+#pragma unroll
+          for (int j = 0; j < MT_P; ++j) fb1[j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
+          static_for<MT_C * MT_P>([&](auto mi) {
+            constexpr int m = kk * MT_C * MT_P + decltype(mi)::value;
+            constexpr int i = (m / MT_P) % MT_C, j = m % MT_P;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa1[i]),
+                                                               __builtin_bit_cast(half8_t, fb1[j]), acc[i][j], 0, 0, 0);
+            if constexpr (do_issue && (m % GAP) == GAP - 1 && m / GAP < NL) {
+              lean_issue_one(std::integral_constant<int, m / GAP>{}, std::integral_constant<int, nslot>{});
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+        });
+      }
+      uint4_t fa[kPerSlice ? 1 : KK][MT_C], fb[kPerSlice ? 1 : KK][MT_P];
+      if constexpr (!kPerSlice) {
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -975,6 +1005,8 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < MT_P; ++j) fb[kk][j] = *reinterpret_cast<const uint4_t*>(st + (b_off[j] ^ (kk << 5)));
       }
+      }
+      if constexpr (!kPerSlice)
       static_for<NM>([&](auto mi) {
         constexpr int m = decltype(mi)::value;
         constexpr int i = (m / MT_P) % MT_C, j = m % MT_P;
@@ -2420,7 +2452,8 @@ static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc,
   if (wide && !(d->dtype == FT_F16 && g.kc % (1 << wide) == 0)) return false;
   if (wide && ks > 1) return false;         // (wide + split-K likewise)
   if (bc == 256) {   // all-256-channel tiles (8 waves at 128 pixels, 4 at 64): the pixel tile is loaded once per 256 outputs
-    if (!(d->dtype == FT_F16 && (bp == 64 || bp == 128) && ks == 1 && sk == 1 && g.cout_pad % 256 == 0)) return false;
+    if (!(d->dtype == FT_F16 && (bp == 64 || bp == 128 || bp == 256) && ks == 1 && sk == 1 && g.cout_pad % 256 == 0)) return false;
+    if (bp == 256 && wide != 1) return false;   // 256 x 256 (8 waves, half the operand bytes per MAC of 128 x 128): wide-K form only
     return true;
   }
   if (!((bp == 64 || bp == 128 || bp == 256) && (bc == 64 || bc == 128) && (ks == 1 || ks == 2 || ks == 4))) return false;
@@ -2457,7 +2490,7 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
       if (n < max && tile_valid(d, g, t[0], t[1], ks)) hints[n++] = t[0] | (t[1] << 12) | (ks << 24);
   for (const auto& t : kTiles)
     if (n < max && tile_valid(d, g, t[0], t[1], 1, 1)) hints[n++] = t[0] | (t[1] << 12) | (1 << 24) | (1 << kHintWideShift);
-  for (int bp = 128; bp >= 64; bp >>= 1)
+  for (int bp = 256; bp >= 64; bp >>= 1)
     for (int wide = 0; wide <= 1; ++wide)
       if (n < max && tile_valid(d, g, bp, 256, 1, wide)) hints[n++] = bp | (256 << 12) | (1 << 24) | (wide << kHintWideShift);
   // cross-workgroup split-K where the layer has less than ~one workgroup per CU even on 64-wide tiles (long K, few
@@ -2650,11 +2683,23 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
     p.tail_w = static_cast<const char*>(residual);
     p.tail_cout = d->tail_cout;
     p.epi_lds = 1;
-    p.npt = ceil_div(p.M, 128);
+    // FT_TAIL_BP=256 (dev A/B): 256 pixels x 256 channels per 8-wave workgroup (wide-K form).  Half the weight-tile traffic
+    // per pixel, but one workgroup per CU with its 8 waves in lock-step: measured 160 vs 146 us on deconv.6 + heatmap at
+    // batch 64 — the 128-pixel tile (two workgroups per CU) stays the default.
+    static const int tail_bp = env_int("FT_TAIL_BP");
+    const bool big = d->Cout == 256 && g.kc % 2 == 0 && tail_bp == 256;
+    static const bool tail_lo_off = getenv("FT_TAIL_LO") && atoi(getenv("FT_TAIL_LO")) == 0;   // dev A/B: hi weights only
+    if (tail_lo_off) p.dbg |= 128;
+    p.npt = ceil_div(p.M, big ? 256 : 128);
     p.nct = 1;
     if ((long long)p.npt * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
     dim3 grid(p.npt * p.nph);
-    const int rc = d->Cout == 256 ? launch_dma<half_t, 128, 256, 2, 4>(p, grid, s)
+    if (big) {
+      p.kc = g.kc >> 1;
+      p.nk = g.nk >> 1;
+    }
+    const int rc = big ? launch_dma<half_t, 256, 256, 4, 2, 1, 128, 2>(p, grid, s)
+                   : d->Cout == 256 ? launch_dma<half_t, 128, 256, 2, 4>(p, grid, s)
                    : d->Cout == 128 ? launch_dma<half_t, 128, 128, 2, 2>(p, grid, s) : launch_dma<half_t, 128, 64, 2, 2>(p, grid, s);
     if (rc != FT_OK) return rc;
     FT_LAUNCH_CHECK("conv_igemm_dma_kernel (tail)");
@@ -2732,7 +2777,8 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
     }
     int rc;
     if (bc == 256) {
-      if (wide == 1) rc = bp == 128 ? launch_dma<half_t, 128, 256, 2, 4, 1, 128, 2>(p, grid, s) : launch_dma<half_t, 64, 256, 1, 4, 1, 128, 2>(p, grid, s);
+      if (wide == 1 && bp == 256) rc = launch_dma<half_t, 256, 256, 4, 2, 1, 128, 2>(p, grid, s);
+      else if (wide == 1) rc = bp == 128 ? launch_dma<half_t, 128, 256, 2, 4, 1, 128, 2>(p, grid, s) : launch_dma<half_t, 64, 256, 1, 4, 1, 128, 2>(p, grid, s);
       else rc = bp == 128 ? launch_dma<half_t, 128, 256, 2, 4>(p, grid, s) : launch_dma<half_t, 64, 256, 1, 4>(p, grid, s);
     } else if (wide == 1) {
       if (bp == 256) rc = launch_dma<half_t, 256, 128, 4, 2, 1, 128, 2>(p, grid, s);

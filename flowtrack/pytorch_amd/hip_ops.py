@@ -517,12 +517,18 @@ class FusedConv:
             n = tail_weight.shape[0]
             if dtype != torch.float16 or tuple(tail_weight.shape[1:]) != (self.cout, 1, 1) or n > 32 or self.cout not in (64, 128, 256):
                 raise FlowtrackHipError(f"{label}: the fused tail needs fp16, a 1x1 conv to <= 32 channels on 64/128/256 inputs")
+            # fp32-grade tail weights as an fp16 hi / lo pair (w = hi + lo up to ~2^-22 relative): the heatmap conv decides
+            # the arg-max, its weights are not rounded to fp16 (the activations of the last deconv still are)
+            w32 = tail_weight.detach().float().cpu()[:, :, 0, 0]
             w16 = torch.zeros((32, self.cout), dtype=torch.float16)
-            w16[:n] = tail_weight.detach().float().cpu()[:, :, 0, 0].half()
+            w16[:n] = w32.half()
+            wlo = torch.zeros((32, self.cout), dtype=torch.float16)
+            wlo[:n] = (w32 - w16[:n].float()).half()
             b32 = torch.zeros(32, dtype=torch.float32)
             if tail_bias is not None:
                 b32[:n] = tail_bias.detach().float().cpu()
-            self._tail = torch.cat((w16.view(torch.uint8).flatten(), b32.view(torch.uint8).flatten())).to(device)
+            self._tail = torch.cat((w16.view(torch.uint8).flatten(), b32.view(torch.uint8).flatten(),
+                                    wlo.view(torch.uint8).flatten())).to(device)
             self.tail_cout = n
 
     def _packed_for(self, d: ConvDesc):

@@ -136,7 +136,8 @@ typedef struct ft_conv_desc {
    * intermediate (all Cout channels of a pixel tile) stays in LDS and is never written: it fuses the pose head's
    * last layers, `heatmap(deconv(...))` (lib/pose/models/pose_deconv.py:43-45), and saves the round trip of the
    * largest tensor of the head.  Requirements: FT_F16, Cout in {64, 128, 256}, has_residual = 0, x2_cin = 0; the
-   * tail pack — fp16 [32][Cout] weights (rows >= tail_cout zero) followed by fp32 [32] bias — is passed in
+   * tail pack — fp16 [32][Cout] weights `hi` (rows >= tail_cout zero), fp32 [32] bias, fp16 [32][Cout] `lo` with
+   * w = hi + lo (the tail weights keep ~22 bits: the heatmap conv decides the arg-max) — is passed in
    * ft_conv2d_fwd's `residual` argument; `y` / out_layout / y_cstride / y_coff describe the TAIL output
    * (Ho x Wo x tail_cout).  tail_cout = 0: none. */
   int tail_cout;
