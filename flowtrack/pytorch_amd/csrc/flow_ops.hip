@@ -6,6 +6,8 @@
 // plus the fused warp/diff/norm/concat stage that sits between stacked FlowNets (models.py:396-403).
 // The reference's NCHW->padded-NHWC copy kernels (`channels_first`) do not exist here: padding is a
 // bounds test, and the in-network form reads the NHWC activations the conv stack already produces.
+#include <stdlib.h>
+
 #include "ft_common.h"
 
 namespace ft {
@@ -260,6 +262,148 @@ __global__ __launch_bounds__(256) void correlation_mfma_kernel(const half_t* __r
 #endif
 }
 
+// ---- the same band GEMM with R output rows per workgroup -------------------------------------------------------
+// stride2 = 2 also ties the ROWS together: output row y only meets f2 rows of its own parity, and an f2 row is
+// shared by the D output rows around it.  A workgroup therefore owns R consecutive output rows of one row-parity class
+// (y = 2i + q, i = i0 .. i0+R-1) of a 64-pixel column chunk, keeps their f1 fragments in REGISTERS (R x C/16 x 4
+// VGPRs) and streams the R + 2*drad f2 rows of that class through a 3-slot LDS ring ONCE: every f2 row feeds up to R
+// band products.  At R = 3 that is 23 row loads for 63 products instead of 63 (3.6 x fewer L2 -> LDS bytes, and 2-3
+// products of matrix work per barrier instead of one).  The ring runs two rows ahead on a counted vmcnt: the band
+// leaves as unconditional 2-byte buffer stores (lanes outside the band / the image store to an out-of-range offset), so
+// the number of vector-memory operations between a row load and its wait is a compile-time constant.
+template <int KS, int R, int DRAD>
+__global__ __launch_bounds__(256, 1) void correlation_mfma_rows_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
+                                                                        half_t* __restrict__ y, int H, int W, unsigned f2_bytes,
+                                                                        unsigned y_bytes, int f_cstride, int y_cstride, int y_coff,
+                                                                        int act, float slope) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = KS * 16, ROWB = C * 2, RPI = 1024 / ROWB, CHUNKS = ROWB / 16;
+  constexpr int D = 2 * DRAD + 1, WROWS = 64 + 4 * DRAD;
+  constexpr int STAGE = (WROWS * ROWB + 1023) / 1024 * 1024, NINSTR = STAGE / 1024, NL = NINSTR / 4;
+  constexpr int NJ = R + 2 * DRAD;          // f2 rows of the class this workgroup walks
+  static_assert(ROWB <= 1024 && CHUNKS >= 16 && NINSTR % 4 == 0 && 3 * STAGE <= 160 * 1024, "shape");
+  static_assert(NL + 16 * R <= 63, "vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = wave & 1, jt = wave >> 1;
+  const int c = lane & 31, h = lane >> 5;
+  const int x0 = blockIdx.x * 64, n = blockIdx.z;
+  const int q = blockIdx.y & 1, i0 = (blockIdx.y >> 1) * R;
+  const int Hq = (H - q + 1) >> 1;          // rows of this parity class
+  const float inv_c = 1.0f / (float)C;
+
+  // f1 fragments of the R rows (operand A: row = f1 pixel of this column parity, k = channel)
+  constexpr unsigned kOOB = 0x80000000u;
+  uint4_t a[R][KS];
+  {
+    // buffer loads: pixels / rows outside the image are out-of-range offsets (zeros), no branches, all in flight at once
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(f1), 0, f2_bytes, 0x00020000);
+    const int x = x0 + 2 * c + par;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int yy = 2 * (i0 + r) + q;
+      const unsigned voff = (x < W && yy < H) ? (unsigned)((((n * H + yy) * W + x) * f_cstride + h * 8) * 2) : kOOB;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a[r][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, voff, s * 32, 0);
+    }
+  }
+  // operand B: column = window pixel 64*jt + 2*c + par (clamped: columns past the window are never in the band)
+  int wr = 64 * jt + 2 * c + par;
+  wr = wr < WROWS ? wr : WROWS - 1;
+  const int b_base = wr * ROWB;
+  const int b_key = (wr >> 1) & 15;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(f2), 0, f2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
+  // loader lanes: wave-load i covers window rows i*RPI .. ; XOR swizzle on the source chunk as in correlation_mfma_kernel
+  unsigned l_voff[NL];
+#pragma unroll
+  for (int t = 0; t < NL; ++t) {
+    const int i = t * 4 + wave;
+    const int row = i * RPI + lane / CHUNKS, pos = lane % CHUNKS;
+    const int lc = pos ^ ((row >> 1) & 15);
+    const int x2 = x0 - 2 * DRAD + row;
+    l_voff[t] = (row < WROWS && (unsigned)x2 < (unsigned)W) ? (unsigned)(((n * H) * W + x2) * f_cstride * 2 + lc * 16) : kOOB;
+  }
+  const int row_bytes = W * f_cstride * 2;
+  auto issue = [&](int jj, int slot) {       // always NL loads per wave: rows outside the image / past the walk are out of range
+    const int j = i0 - DRAD + jj;
+    const bool row_ok = jj < NJ && (unsigned)j < (unsigned)Hq;
+    const int soff = row_ok ? (2 * j + q) * row_bytes : 0;
+#pragma unroll
+    for (int t = 0; t < NL; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + slot * STAGE + (t * 4 + wave) * 1024), 16,
+                                               row_ok ? l_voff[t] : kOOB, soff, 0, 0);
+  };
+  // band extraction: accumulator register g of lane (c, h) = f1 pixel rr(g) x window column c -> displacement c + 32*jt - rr
+  unsigned s_voff[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int rr = (g & 3) + 8 * (g >> 2) + 4 * h;
+    const int x = x0 + 2 * rr + par;
+    const int dxi = c + 32 * jt - rr;
+    s_voff[g] = (x < W && (unsigned)dxi < (unsigned)D) ? (unsigned)(((n * H) * W + x) * y_cstride + y_coff + dxi) * 2u : kOOB;
+  }
+  const int yrow_bytes = W * y_cstride * 2;
+  // act(v) = max(v, s*v) for s in [0, 1] (relu: 0, leaky: slope, none: 1); the 1/C of the correlation rides along
+  const float k_pos = inv_c, k_neg = inv_c * (act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f));
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting
+  issue(0, 0);
+  issue(1, 1);
+  int slot = 0;
+  for (int jj = 0; jj < NJ; ++jj) {
+    // row jj has landed (this wave's share): behind it only row jj+1 and the 16*R stores of the previous step may fly
+    if (jj == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 16 * R) : "memory");
+    asm volatile("s_barrier" ::: "memory");             // everyone's share has; everyone is done reading the slot refilled now
+    issue(jj + 2, slot == 0 ? 2 : slot - 1);
+    const int j = i0 - DRAD + jj;
+    const bool row_ok = (unsigned)j < (unsigned)Hq;
+    const char* st = smem + slot * STAGE + b_base;
+    uint4_t b[KS];
+    if (row_ok) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const uint4_t*>(st + (((2 * s + h) ^ b_key) << 4));
+    }
+    // all R band products first (independent accumulators keep the matrix pipe busy), then their stores
+    float16_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+      const int dyi = jj - r;                           // f2 row j is displacement dyi - DRAD of output row i0 + r
+      if ((unsigned)dyi < (unsigned)D && i0 + r < Hq && row_ok) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[r][s]), __builtin_bit_cast(half8_t, b[s]), acc[r], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int dyi = jj - r;
+      const bool live = (unsigned)dyi < (unsigned)D && i0 + r < Hq;
+      if (live) {                                        // wave-uniform
+        const int soff = (2 * (i0 + r) + q) * yrow_bytes + dyi * D * 2;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float v = __builtin_fmaxf(acc[r][g] * k_pos, acc[r][g] * k_neg);   // act(v / C), slopes in [0, 1]
+          const half_t hv = (half_t)v;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rsrc_y, s_voff[g], soff, 0);
+        }
+      } else {                                           // same count of vector-memory operations, nothing stored
+#pragma unroll
+        for (int g = 0; g < 16; ++g) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rsrc_y, kOOB, 0, 0);
+      }
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the two (all out-of-range) look-ahead rows of the last steps
+#endif
+}
+
 // ---- Resample2d: backward bilinear warp with border clamp -----------------------------------------
 // Weights from the UNclamped floor, neighbour indices clamped, no renormalisation
 // (Resample2d_kernel.cu:42-59).  Thread = output pixel, all channels (flow read once).
@@ -506,6 +650,26 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
   if (dtype == FT_F16 && stride2 == 2 && max_displacement % 2 == 0 && max_displacement <= 32 && C == 256 &&
       f_bytes < (1ull << 31)) {
     const int drad = max_displacement / 2;
+    const unsigned long long y_bytes = (unsigned long long)B * H * W * y_cstride * 2;
+    static const bool no_rows = getenv("FT_CORR_ROWS") && atoi(getenv("FT_CORR_ROWS")) == 0;   // dev A/B: one row per workgroup
+    if (drad == 10 && y_bytes < (1ull << 31) && !no_rows) {     // FlowNetC's shape: 3 output rows per workgroup
+      constexpr int R = 3;
+      auto k = correlation_mfma_rows_kernel<16, R, 10>;
+      constexpr size_t lds3 = 3 * (((size_t)(64 + 40) * 512 + 1023) / 1024 * 1024);
+      static bool raised[64] = {};
+      int dev = 0;
+      FT_HIP_CHECK(hipGetDevice(&dev));
+      if (dev < 0 || dev >= 64 || !raised[dev]) {
+        FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        if (dev >= 0 && dev < 64) raised[dev] = true;
+      }
+      const int groups = ceil_div((H + 1) / 2, R);
+      hipLaunchKernelGGL(k, dim3(ceil_div(W, 64), 2 * groups, B), dim3(256), lds3, as_stream(stream), static_cast<const half_t*>(f1),
+                         static_cast<const half_t*>(f2), static_cast<half_t*>(y), H, W, (unsigned)f_bytes, (unsigned)y_bytes,
+                         f_cstride, y_cstride, y_coff, act, slope);
+      FT_LAUNCH_CHECK("correlation_mfma_rows_kernel");
+      return FT_OK;
+    }
     const size_t stage = ((size_t)(64 + 4 * drad) * C * 2 + 1023) / 1024 * 1024;
     const size_t lds2 = 2 * stage;
     auto k = correlation_mfma_kernel<16>;
