@@ -544,6 +544,397 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 #endif
 }
 
+// ---- 256 planes, weights straight to registers -----------------------------------------------------------------------
+// At 256 planes every wave owns its own two output-channel tiles, so no weight fragment is shared between waves: the
+// LDS round trip of the weight stream (DMA write + ds_read, competing with the pixel-operand reads for the LDS port) is
+// pure overhead.  Here each wave loads ITS fragments of a step (8 x 1 KiB, contiguous in the fragment-ordered stream)
+// straight into VGPRs two steps ahead; only the pixel operand (x chunks, T1, T2) lives in LDS.  No ring, no ring
+// barriers: the waves only meet at the phase transitions.  tools/dev/ubench/stream_ring.hip: 447 vs ~680 ns per 32-KiB
+// step on the 2 x 2 micro-tile at 256 workgroups (30 vs 20 B/clk/CU of weights beside the matrix pipe).
+// LDS: [0, 48 K) x-chunk buffers / [0, 60 K) T1 then T2, zero row at 60 K, all six folded-BN tables at 64 K (loaded
+// once), two output staging tiles from 80 K.
+template <int MT1, int MT2>
+__global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const BnsParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 256;
+  using G = BnsGeom<P>;
+  constexpr int NCT = G::NCT, NC1 = G::NC1, KC = G::KC, WSTEP = G::WSTEP, ROWB = G::ROWB;
+  constexpr int XROWS = MT1 * 32, LX = MT1;                  // one pixel group: 4 wave columns
+  constexpr int NOUT = MT2 * 32;
+  constexpr int ZROW = 61440, TABS = 65536, STG = 81920, STGB = NOUT * ROWB;
+  constexpr int LDS_BYTES = STG + 2 * STGB;
+  static_assert(XROWS * 128 <= G::XSTRIDE && NOUT * ROWB <= 61440 && LDS_BYTES <= 163840, "LDS map");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wcol = wave;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int logical;
+  {
+    const int b = blockIdx.x;
+    const int q = p.total >> 3, r = p.total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int n = logical / p.ppi;
+  const int y0 = (logical - n * p.ppi) * p.TH;
+  const int W = p.W;
+  const int rows_out = p.H - y0 < p.TH ? p.H - y0 : p.TH;
+  const int npix_out = rows_out * W;
+  const int npix_halo = (p.TH + 2) * W;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 6 * G::TABB, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  unsigned x_voff[LX];
+#pragma unroll
+  for (int t = 0; t < LX; ++t) {
+    const int hp = (t * 4 + wave) * 8 + (lane >> 3);
+    const int hr = hp / W, hc = hp - hr * W;
+    const int iy = y0 - 1 + hr;
+    unsigned v = kOOB;
+    if (hp < npix_halo && (unsigned)iy < (unsigned)p.H)
+      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ (hp & 7)) << 4));
+    x_voff[t] = v;
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto issue_x = [&](int c, int buf) {
+    char* dst = smem + buf * G::XSTRIDE;
+#pragma unroll
+    for (int t = 0; t < LX; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x_voff[t], c * 128, 0, 0);
+  };
+  // the weight fragments of step g for this wave: (kk, tile 2*wcol + i) at g * WSTEP + (kk * NCT + 2*wcol + i) KiB
+  uint4_t areg[3][4][2];
+  auto load_a = [&](auto slotc, int g) {        // past the end of the stream: out of range, zeros, never multiplied
+    constexpr int SL = decltype(slotc)::value;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + 2 * wcol + i) * 1024, 0);
+  };
+
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BNSD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  BNSD_TS(0);
+  // prologue: all six tables (12 KiB, 3 x 256-byte pieces per wave ... 48 pieces), x chunks 0..2, weights of steps 0 and 1, zero row
+#pragma unroll
+  for (int t = 0; t < 12; ++t)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * 4 + wave) * 256), 4, (unsigned)lane * 4u, (t * 4 + wave) * 256, 0, 0);
+  issue_x(0, 0);
+  issue_x(1, 1);
+  issue_x(2, 2);
+  load_a(c0{}, 0);
+  load_a(c1{}, 1);
+  if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
+
+  uint4_t res[4][2][MT2][2];
+  int m_out[MT2];
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) m_out[j] = j * 32 + l31;
+
+  // ================= phase 1 ============================================================================================
+  float16_t acc1[2][MT1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT1; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+  int b1_off[MT1];
+#pragma unroll
+  for (int j = 0; j < MT1; ++j) {
+    const int hp = j * 32 + l31;
+    b1_off[j] = hp * 128 + ((lhi ^ (hp & 7)) << 4);
+  }
+  {
+    uint4_t fx[2][MT1];
+    auto ldx = [&](auto setc, int buf, int kk) {
+      constexpr int S = decltype(setc)::value;
+      const char* xb = smem + buf * G::XSTRIDE;
+#pragma unroll
+      for (int j = 0; j < MT1; ++j) fx[S][j] = *reinterpret_cast<const uint4_t*>(xb + (b1_off[j] ^ (kk << 5)));
+    };
+    auto mma1 = [&](auto setc, auto slotc, auto kkc) {
+      constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MT1; ++j)
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]),
+                                                              __builtin_bit_cast(half8_t, fx[S][j]), acc1[i][j], 0, 0, 0);
+    };
+    // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight steps (8 loads each) may fly
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 16) : "memory");
+    BNS_BARRIER();
+    ldx(c0{}, 0, 0);
+    bns_unroll<NC1>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int buf = c % 3;
+      using slot = std::integral_constant<int, c % 3>;
+      load_a(std::integral_constant<int, (c + 2) % 3>{}, c + 2);
+      ldx(c1{}, buf, 1);
+      mma1(c0{}, slot{}, std::integral_constant<int, 0>{});
+      ldx(c0{}, buf, 2);
+      if (c % 4 == wcol) {           // this chunk holds the channels of this wave column for quarter c / 4
+        constexpr int q = c / 4;
+        const char* xb = smem + buf * G::XSTRIDE;
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) {
+          const int hp = m_out[j] + W;
+          const char* rowp = xb + hp * 128;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ (hp & 7)) << 4));
+        }
+      }
+      mma1(c1{}, slot{}, std::integral_constant<int, 1>{});
+      ldx(c1{}, buf, 3);
+      mma1(c0{}, slot{}, std::integral_constant<int, 2>{});
+      if constexpr (c + 1 < NC1) {
+        // x chunk c+1 has landed and every read of chunk c's buffer is complete: refill it with chunk c+3.  Younger than x
+        // chunk c+1 are the weights of step c+1 (needed next anyway), x chunk c+2 and the weights of step c+2.
+        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8) : "memory");
+        BNS_BARRIER();
+        if constexpr (c + 3 < NC1) issue_x(c + 3, buf);
+        ldx(c0{}, (c + 1) % 3, 0);
+      }
+      mma1(c1{}, slot{}, std::integral_constant<int, 3>{});
+    });
+  }
+  BNSD_TS(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNS_BARRIER();          // every wave is past its last x-chunk read: the x buffers become T1
+  {
+    const float* tb = reinterpret_cast<const float*>(smem + TABS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < MT1; ++j) {
+        const int hp = j * 32 + l31;
+        const int hr = hp / W;
+        const int iy = y0 - 1 + hr;
+        const bool inside = (unsigned)iy < (unsigned)p.H;
+        half8_t h8[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = __builtin_fmaxf(acc1[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
+          h8[r >> 3][r & 7] = inside ? (half_t)v : (half_t)0.f;
+        }
+        if (hp < npix_halo) {
+          char* rowp = smem + hp * ROWB;
+          const int cb = (2 * wcol + i) * 4 + 2 * lhi;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<half8_t*>(rowp + (((cb + h) ^ (hp & 15)) << 4)) = h8[h];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNS_BARRIER();          // T1 complete
+  BNSD_TS(2);
+
+  // ================= phases 2 + 3 =======================================================================================
+  float16_t acc[2][MT2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  int edge[MT2];
+#pragma unroll
+  for (int j = 0; j < MT2; ++j) {
+    const int ox = m_out[j] % W;
+    edge[j] = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+  }
+  auto row_bases = [&](int off, int kc, int bad, int (&rb)[MT2]) {
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) {
+      const int row = m_out[j] + off;
+      const int v = row * ROWB + (((row & 15) ^ lhi) << 4);
+      rb[j] = ((edge[j] & bad) ? ZROW + (lhi << 4) : v) ^ (kc << 7);
+    }
+  };
+  uint4_t fb[2][MT2];
+  auto ldb = [&](auto setc, int kk, const int (&rb)[MT2]) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int j = 0; j < MT2; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (kk << 5)));
+  };
+  auto mma2 = [&](auto setc, auto slotc, auto kkc) {
+    constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]),
+                                                           __builtin_bit_cast(half8_t, fb[S][j]), acc[i][j], 0, 0, 0);
+  };
+  // one weight step g (ring slot SL = g % 3): slice 0 of the pixel operand already sits in register set 0; `rbn` = row
+  // bases of the next step
+  auto dstep = [&](auto slotc, int g, const int (&rb)[MT2], bool has_next, const int (&rbn)[MT2]) {
+    constexpr int SL = decltype(slotc)::value;
+    using slot = std::integral_constant<int, SL>;
+    load_a(std::integral_constant<int, (SL + 2) % 3>{}, g + 2);
+    ldb(c1{}, 1, rb);
+    mma2(c0{}, slot{}, std::integral_constant<int, 0>{});
+    ldb(c0{}, 2, rb);
+    mma2(c1{}, slot{}, std::integral_constant<int, 1>{});
+    ldb(c1{}, 3, rb);
+    mma2(c0{}, slot{}, std::integral_constant<int, 2>{});
+    if (has_next) ldb(c0{}, 0, rbn);
+    mma2(c1{}, slot{}, std::integral_constant<int, 3>{});
+  };
+
+  // ---- phase 2: nine taps x KC chunks, three taps per loop trip (12 steps: a multiple of the register ring period) -------
+  {
+    static_assert((3 * KC) % 3 == 0, "ring phase of the unrolled body");
+    int rb[MT2], rbn[MT2];
+    row_bases(-1, 0, 1, rb);
+    ldb(c0{}, 0, rb);
+    for (int ky = 0; ky < 3; ++ky) {
+      bns_unroll<3 * KC>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int kx = s / KC, kc = s % KC;
+        constexpr int nkc = (kc + 1) % KC, nkx = kc + 1 == KC ? (kx + 1) % 3 : kx;
+        const int nky = (kc + 1 == KC && kx == 2) ? ky + 1 : ky;
+        row_bases(nky * W + nkx - 1, nkc, nkx == 0 ? 1 : (nkx == 2 ? 2 : 0), rbn);
+        dstep(std::integral_constant<int, (G::G2 + s) % 3>{}, G::G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn);
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
+      });
+    }
+  }
+  BNSD_TS(3);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNS_BARRIER();          // every wave is past its last T1 read: T2 overwrites T1
+  {
+    const float* tb = reinterpret_cast<const float*>(smem + TABS + G::TABB);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < MT2; ++j) {
+        const int m = m_out[j];
+        half8_t h8[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          h8[r >> 3][r & 7] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
+        char* rowp = smem + m * ROWB;
+        const int cb = (2 * wcol + i) * 4 + 2 * lhi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<half8_t*>(rowp + (((cb + h) ^ (m & 15)) << 4)) = h8[h];
+      }
+    }
+  }
+  zero_acc();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BNS_BARRIER();          // T2 complete
+  BNSD_TS(4);
+
+  // ---- phase 3: four quarters of P output channels; the tile of a quarter leaves through one of two LDS staging tiles ----
+  {
+    constexpr int CPR = ROWB / 16, NSTG = NOUT * CPR / 256;
+    unsigned s_voff[NSTG];
+    int s_off[NSTG];
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) {
+      const int idx = tid + 256 * k, m = idx / CPR, ch = idx % CPR;
+      s_voff[k] = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
+      s_off[k] = m * ROWB + ((ch ^ (m & 15)) << 4);
+    }
+    int rb[MT2], rbn[MT2];
+    row_bases(0, 0, 0, rb);
+    ldb(c0{}, 0, rb);
+    bns_unroll<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      bns_unroll<KC>([&](auto kcc) {
+        constexpr int kc = decltype(kcc)::value;
+        constexpr int g = G::G3 + q * KC + kc;
+        row_bases(0, (kc + 1) % KC, 0, rbn);
+        dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn);
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
+      });
+      char* stg = smem + STG + (q & 1) * STGB;
+      const float* tb = reinterpret_cast<const float*>(smem + TABS + (2 + q) * G::TABB);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+        float4_t sc[4], sh[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) {
+          const int m = m_out[j];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int r = h * 8 + e;
+              o[e] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
+            }
+            *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
+          }
+        }
+      }
+      zero_acc();
+      // the two staging tiles alternate: a tile's previous readers (quarter q-2) are two barriers behind
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      BNS_BARRIER();
+#pragma unroll
+      for (int k = 0; k < NSTG; ++k) {
+        const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
+        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, 0);
+      }
+    });
+  }
+  if (p.dbg & 32) {
+    ts[5] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y + ((size_t)((n * p.H + y0) * W) * p.y_cstride + p.y_coff) * 2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    }
+  }
+#endif
+}
+
 // ---- weight stream packing -------------------------------------------------------------------------------------------
 // w1 [P][C], w2 [P][9P] (k = tap * P + ci), w3 [C][P]: the K-major layouts of ft_conv_pack_geometry.  One thread per
 // 16-byte piece of the stream: step g, slice kk, channel tile i, lane -> 8 consecutive k of one output channel.
@@ -632,6 +1023,22 @@ static int bns_launch(const BnsParams& p, hipStream_t s) {
   return FT_OK;
 }
 
+template <int MT1, int MT2>
+static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
+  auto k = bottleneck_stream_direct_kernel<MT1, MT2>;
+  constexpr int lds = 81920 + 2 * MT2 * 32 * 512;
+  static bool attr_done[64] = {};          // the LDS opt-in is per device
+  int dev = 0;
+  FT_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(k, dim3(p.total), dim3(256), lds, s, p);
+  FT_LAUNCH_CHECK("bottleneck_stream_direct_kernel");
+  return FT_OK;
+}
+
 }  // namespace
 }  // namespace ft
 
@@ -690,6 +1097,10 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   switch (pl.variant) {
     case 0: return bns_launch<128, 4, 3>(p, s);
     case 1: return bns_launch<256, 4, 3>(p, s);
-    default: return bns_launch<256, 3, 2>(p, s);
+    default: {
+      // 64-pixel strips at 256 planes: weights straight to registers (FT_BNS_DIRECT=0: through the LDS ring, dev A/B)
+      static const bool no_direct = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;
+      return no_direct ? bns_launch<256, 3, 2>(p, s) : bns_launch_direct<3, 2>(p, s);
+    }
   }
 }

@@ -226,6 +226,100 @@ void run_pipe(const char* w, unsigned wb, int grid, int steps, float* sink, cons
          bytes / us * 1e-6, bytes / grid / (us * 2400.0), flops / us * 1e-6, us * 2400.0 / steps);
 }
 
+// Variant: the weight fragments never touch LDS.  Each wave's A fragments are private (distinct channel tiles), the stream
+// is fragment-ordered, so a wave loads them straight into VGPRs (1 KiB contiguous per instruction) DEPTH steps ahead and
+// only the pixel operand is read from LDS: no DMA writes into LDS, no A-fragment ds_reads, no ring barriers.
+template <int MTP, int DEPTH, int U = 1>
+__global__ __launch_bounds__(256, 1) void stream_direct_kernel(const char* __restrict__ w, unsigned w_bytes, int steps, float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, w_bytes, 0x00020000);
+  const unsigned lane_off = lane * 16u;
+  float16_t acc[2][MTP];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MTP; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int b_off[MTP];
+#pragma unroll
+  for (int j = 0; j < MTP; ++j) {
+    const int r = j * 32 + l31 + 13;
+    b_off[j] = r * 512 + ((lhi ^ (r & 15)) << 4);
+  }
+  uint4_t areg[DEPTH + 1][4][2];
+  unsigned goff = 0;
+  auto load_step = [&](auto slotc) {
+    constexpr int S = decltype(slotc)::value;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[S][k][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, goff + (k * 8 + wave * 2 + i) * 1024, 0);
+    goff += 32768;
+    if (goff + 32768 > w_bytes) goff = 0;
+  };
+  auto compute = [&](auto slotc) {
+    constexpr int S = decltype(slotc)::value;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint4_t fb[MTP];
+#pragma unroll
+      for (int j = 0; j < MTP; ++j) fb[j] = *reinterpret_cast<const uint4_t*>(lds + (b_off[j] ^ (k << 5)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MTP; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[S][k][i]), __builtin_bit_cast(half8_t, fb[j]), acc[i][j], 0, 0, 0);
+    }
+  };
+  unroll_for<DEPTH>([&](auto s) { load_step(s); });
+  for (int st = 0; st < steps; st += (DEPTH + 1) * U) {     // U > 1: a long straight-line body (instruction-fetch probe)
+    unroll_for<(DEPTH + 1) * U>([&](auto s) {
+      constexpr int S = decltype(s)::value % (DEPTH + 1);
+      load_step(std::integral_constant<int, (S + DEPTH) % (DEPTH + 1)>{});
+      compute(std::integral_constant<int, S>{});
+    });
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MTP; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 123.456f) sink[0] = s + ((float*)lds)[lane];
+#endif
+}
+
+template <int MTP, int DEPTH, int U = 1>
+void run_direct(const char* w, unsigned wb, int grid, int steps, float* sink, const char* label) {
+  auto k = stream_direct_kernel<MTP, DEPTH, U>;
+  const int ldsb = 65536;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  steps = steps / ((DEPTH + 1) * U) * ((DEPTH + 1) * U);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, 0, w, wb, (DEPTH + 1) * U, sink);
+  CK(hipDeviceSynchronize());
+  float best = 1e9f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), ldsb, 0, w, wb, steps, sink);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = ms < best ? ms : best;
+  }
+  const double bytes = (double)grid * steps * 32768.0;
+  const double us = best * 1e3;
+  const double flops = (double)grid * steps * 4 * (8 * MTP) * 32768.0;
+  printf("%-44s grid %3d  %7.1f us  %6.2f TB/s  %5.1f B/clk/CU(2.4GHz)  %7.1f TFLOP/s  ns/step %6.0f\n", label, grid, us,
+         bytes / us * 1e-6, bytes / grid / (us * 2400.0), flops / us * 1e-6, us * 1000.0 / steps);
+}
+
 template <int NW, int SI, int RING, int MFMA, int AUX>
 void run(const char* w, unsigned wb, int grid, int steps, float* sink, const char* label) {
   auto k = stream_kernel<NW, SI, RING, MFMA, AUX>;
@@ -273,6 +367,13 @@ int main() {
     run_pipe<2, 6, 1>(w, wb, grid, steps, sink, "4 waves PIPELINED, 32K/step, ring 6, setprio");
     run_pipe<1, 6, 0>(w, wb, grid, steps * 2, sink, "4 waves PIPELINED, 16K/step, ring 6");
     run_pipe<3, 6, 0>(w, wb, grid, steps * 2 / 3, sink, "4 waves PIPELINED, 48K/step, ring 6");
+    run_direct<3, 2>(w, wb, grid, steps, sink, "4 waves DIRECT A->VGPR, 2x3, depth 2");
+    run_direct<3, 3>(w, wb, grid, steps, sink, "4 waves DIRECT A->VGPR, 2x3, depth 3");
+    run_direct<2, 2>(w, wb, grid, steps, sink, "4 waves DIRECT A->VGPR, 2x2, depth 2");
+    run_direct<2, 3>(w, wb, grid, steps, sink, "4 waves DIRECT A->VGPR, 2x2, depth 3");
+    run_direct<2, 2, 12>(w, wb, grid, 36, sink, "DIRECT 2x2 depth 2, 36 steps straight-line, ONE pass");
+    run_direct<2, 2, 1>(w, wb, grid, 36, sink, "DIRECT 2x2 depth 2, 36 steps looped, ONE pass");
+    run_direct<2, 2, 12>(w, wb, grid, steps, sink, "DIRECT 2x2 depth 2, 36-step body, many passes");
     run<8, 2, 6, 0, 0>(w, wb, grid, steps, sink, "8 waves, 32K/step, ring 6, no mfma");
     run<8, 2, 6, 1, 0>(w, wb, grid, steps, sink, "8 waves, 32K/step, ring 6, mfma 1x3");
     run<8, 2, 4, 1, 0>(w, wb, grid, steps, sink, "8 waves, 32K/step, ring 4, mfma 1x3");
