@@ -169,6 +169,7 @@ def timed_region(step, steps, device):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    getattr(step, "drain", lambda: None)()      # the last step's exchange is consumed inside the timed region
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -276,30 +277,75 @@ def pose_parity(models_by_mode, x_cpu, seed, H, W, oracle_out=None):
 
 
 def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B):
-    """(model, x, step): the pose hot path on a batch resident in HBM, arg-max inside the plan's graph."""
+    """(model, x, step): the pose hot path on a batch resident in HBM, arg-max inside the plan's graph.  N > 1: the
+    [B,17,3] key-point rows of every rank are all-gathered (3.3 kB per rank) on a communication stream, one step behind
+    the compute stream (parallel.RowGatherer): step t's graph replays while step t-1's rows travel."""
     model = build_pose(device, dtype, backbone=backbone)
     model.keypoints_in_plan = True                          # arg-max + 0.25 px nudge run inside the plan's graph
     x = model.static_input(B, H, W)                         # zero-copy binding: the batch is resident in HBM at the
     x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
     kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
+    gather = parallel.RowGatherer(B, (17, 3), torch.float32, device) if world > 1 else None
+    rows = torch.empty((B, 17, 3), dtype=torch.float32, device=device)
+    state = {"pending": None}
+
+    def consume(h):
+        kp_host.copy_(gather.finish(h)[rank * B:(rank + 1) * B], non_blocking=True)   # (the consumer: the rank's own rows back on the host)
 
     def step():
         _, _, score, coords = model.forward_keypoints(x)
-        rows = torch.cat((coords, score), dim=2)            # [B,17,3] keypoint rows
-        rows = parallel.all_gather_rows(rows, B * world) if world > 1 else rows
-        kp_host.copy_(rows[rank * B:(rank + 1) * B] if world > 1 else rows, non_blocking=True)
+        torch.cat((coords, score), dim=2, out=rows)         # [B,17,3] keypoint rows, no allocation
+        if gather is None:
+            kp_host.copy_(rows, non_blocking=True)
+            return rows
+        h = gather.start(rows)
+        if state["pending"] is not None:
+            consume(state["pending"])
+        state["pending"] = h
         return rows
+
+    def drain():
+        if state["pending"] is not None:
+            consume(state["pending"])
+            state["pending"] = None
+    step.drain = drain
     return model, x, step
 
 
-def make_flow_runner(args, device, dtype, rank, world, name, B):
+def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sampled"):
+    """FlowNet on B frame pairs resident in HBM.  What leaves the GPU per step is what the consumer of the flow needs:
+    the tracking glue reads the field at the previous frame's key points (lib/tracking/flow_utils.py:21-26), so by default
+    the step samples the field at 8 x 17 points per pair and (N > 1) all-gathers those rows (1 kB per pair); `full`
+    gathers the whole fields (1.57 MB per pair) instead."""
     model = build_flow(device, dtype, name=name)
     x = model.static_input(B, 384, 512)                     # zero-copy binding (see the pose runner)
     x.copy_(synth.frame_pairs(100 + rank, B))
+    npts = 8 * 17
+    pts = torch.from_numpy(synth.uniform01(7, "flow_sample_points", (npts,))).to(device)
+    idx = (pts * (384 * 512 - 1)).long()
+    full = gather_mode == "full"
+    gather = None
+    if world > 1 and gather_mode != "none":
+        gather = parallel.RowGatherer(B, (2, 384, 512) if full else (2, npts), torch.float32, device)
+    samples = torch.empty((B, 2, npts), dtype=torch.float32, device=device)
+    state = {"pending": None}
 
     def step():
         flow = model(x, copy_output=False)
-        return parallel.all_gather_rows(flow, B * world) if world > 1 else flow
+        if not full:
+            torch.index_select(flow.flatten(2), 2, idx, out=samples)
+        if gather is not None:
+            h = gather.start(flow if full else samples)
+            if state["pending"] is not None:
+                gather.finish(state["pending"])
+            state["pending"] = h
+        return flow
+
+    def drain():
+        if state["pending"] is not None:
+            gather.finish(state["pending"])
+            state["pending"] = None
+    step.drain = drain
     return model, x, step
 
 
@@ -324,6 +370,8 @@ def main():
     ap.add_argument("--res", default="256x192", help="pose crop HxW (multiples of 32)")
     ap.add_argument("--flow-model", default="FlowNet2S",
                     choices=["FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2CSS", "FlowNet2SD", "FlowNet2"])
+    ap.add_argument("--gather", choices=["sampled", "full", "none"], default="sampled",
+                    help="flow, N > 1: all-gather the field sampled at 8 x 17 key points per pair (what the tracker reads), the full fields, or nothing")
     ap.add_argument("--fixed-warmup", action="store_true", help="exactly max(W,2) untimed steps (profiling runs that count launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -352,7 +400,7 @@ def main():
     else:
         B = args.batch or 16
         default_cfg = args.flow_model == "FlowNet2S"
-        model, x, step = make_flow_runner(args, device, dtype, rank, world, args.flow_model, B)
+        model, x, step = make_flow_runner(args, device, dtype, rank, world, args.flow_model, B, args.gather)
         unit, metric = "pairs/s", f"flow frame-pairs/sec ({args.flow_model}, 512x384)"
         workload = (f"{args.flow_model} {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU "
                     f"(BASELINE.json configs[3]{'' if default_cfg else ' shape, other stack'})")
@@ -365,7 +413,8 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (counter-hash crops ~N(0,1) / translated-texture frame pairs, He-scaled random weights)",
         "config": {"workload": workload, "per_gpu_batch": B,
-                   "parallelism": f"dp{world}: batch sharded, one process per GPU" + (", RCCL all-gather of outputs" if world > 1 else "")},
+                   "parallelism": f"dp{world}: batch sharded, one process per GPU" +
+                                  (", RCCL all-gather of the output rows on a comm stream, one step behind" if world > 1 else "")},
     }
     if rank == 0:
         plan = next(iter(model._plans.values()))
@@ -390,7 +439,7 @@ def main():
     if extras:
         # (1) FlowNet2S fp16 on configs[3]'s pairs, every rank, same protocol; sized for >= ~1 s like the headline
         fsteps = max(20, min(args.steps, 1200))
-        fmodel, fx, fstep = make_flow_runner(args, device, torch.float16, rank, world, "FlowNet2S", 16)
+        fmodel, fx, fstep = make_flow_runner(args, device, torch.float16, rank, world, "FlowNet2S", 16, args.gather)
         fel = measure(fstep, fsteps, args.warmup, device)
         if rank == 0:
             fplan = next(iter(fmodel._plans.values()))

@@ -60,6 +60,52 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat(pieces, 0)
 
 
+class RowGatherer:
+    """Pre-allocated, double-buffered all-gather of equal-sized per-rank row blocks, issued on a communication stream.
+
+    The per-step exchange of the N > 1 path (bench.py, tools/): `start(rows)` copies the rank's rows into a send slot on
+    the compute stream and launches ONE all_gather_into_tensor on a side stream behind an event; the compute stream is
+    not blocked, so the next step's HIP graph replays while the previous step's rows travel over xGMI.  `finish(handle)`
+    makes the current stream wait for that exchange and returns the gathered [world * n_local, ...] view (rank-major =
+    batch order for contiguous equal shards).  Nothing is allocated, padded or concatenated per call; `depth` slots
+    allow that many exchanges in flight.  On CPU tensors / gloo (the tests) the same calls run synchronously."""
+
+    def __init__(self, n_local: int, row_shape, dtype, device, depth: int = 2):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.n_local, self.depth = n_local, depth
+        shape = (n_local,) + tuple(row_shape)
+        self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [torch.empty((self.world * n_local,) + tuple(row_shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.cuda = torch.device(device).type == "cuda"
+        self.stream = torch.cuda.Stream(device) if self.cuda and self.world > 1 else None
+        self.ready = [None] * depth      # per slot: event recorded on the comm stream once the exchange is queued
+        self.slot = 0
+
+    def start(self, rows: torch.Tensor) -> int:
+        k = self.slot
+        self.slot = (k + 1) % self.depth
+        if self.world == 1:
+            self.recv[k].copy_(rows)     # same contract (a stable buffer the caller may read later), no collective
+            return k
+        self.send[k].copy_(rows)
+        if self.stream is None:
+            dist.all_gather_into_tensor(self.recv[k], self.send[k])
+            return k
+        self.stream.wait_stream(torch.cuda.current_stream(rows.device))
+        with torch.cuda.stream(self.stream):
+            dist.all_gather_into_tensor(self.recv[k], self.send[k])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.ready[k] = ev
+        return k
+
+    def finish(self, k: int) -> torch.Tensor:
+        if self.stream is not None and self.ready[k] is not None:
+            torch.cuda.current_stream(self.recv[k].device).wait_event(self.ready[k])
+            self.ready[k] = None
+        return self.recv[k]
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

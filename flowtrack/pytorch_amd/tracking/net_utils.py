@@ -91,6 +91,39 @@ def pose_est(net, frame_dev: torch.Tensor, boxes: np.ndarray, inp_res=(256, 192)
     return np.concatenate((np.concatenate(out_c), np.concatenate(out_s)), axis=2).astype(np.float32)
 
 
+def pose_est_frames(net, frames_dev, boxes_list, inp_res=(256, 192), normalize=True):
+    """pose_est for the boxes of SEVERAL frames in one network call: crops of every frame (one ft_crop_affine_fwd launch
+    per frame) are stacked into one batch, padded to the plan bucket, and leave through one final_preds.  Returns a list of
+    [n_t,K,3] arrays.  (Phase 2 of the clip pipeline: ~5 boxes per frame would otherwise pay one plan replay, one arg-max
+    and one device->host sync per frame.)"""
+    counts = [len(np.asarray(b).reshape(-1, 4)) for b in boxes_list]
+    total = sum(counts)
+    if total == 0:
+        return [np.zeros((0, 17, 3), dtype=np.float32) for _ in counts]
+    crops, cs, ss = [], [], []
+    for frame, boxes in zip(frames_dev, boxes_list):
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+        if len(boxes) == 0:
+            continue
+        c, s_ = boxes_to_center_scale(boxes, inp_res)
+        crops.append(crop_boxes(frame, c, s_, inp_res, normalize))
+        cs.append(c)
+        ss.append(s_)
+    batch = torch.cat(crops, 0)
+    centers, scales = np.concatenate(cs), np.concatenate(ss)
+    bucket = next(b for b in (8, 16, 32, 64, 128, 256, 1 << 30) if b >= total)
+    if bucket > total and bucket < (1 << 30):
+        batch = torch.cat((batch, batch.new_zeros((bucket - total,) + tuple(batch.shape[1:]))), 0)
+    hm = net(batch)[:total]
+    c, s_ = final_preds(hm, centers, scales, adjust_coords=True)
+    kp = np.concatenate((c, s_), axis=2).astype(np.float32)
+    out, lo = [], 0
+    for n in counts:
+        out.append(kp[lo:lo + n])
+        lo += n
+    return out
+
+
 def flow_est(net, prev_frame: torch.Tensor, cur_frame: torch.Tensor) -> np.ndarray:
     """prev / cur: uint8 [H,W,3] BGR (device or host) -> flow [2,H,W] fp32 numpy (net_utils.py:73-92):
     BGR -> RGB, pack [1,3,2,H,W] float 0..255, pad to a multiple of 64, crop the flow back."""

@@ -48,3 +48,90 @@ def test_all_gather_rows_world2(n_total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in results) and all(t == 2.0 for _, _, t in results)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    g = parallel.RowGatherer(3, (17, 3), torch.float32, "cpu", depth=2)
+    ok = True
+    handles = []
+    for step in range(5):                       # lagged consumption, as bench.py does: finish step t-1 after starting step t
+        rows = torch.full((3, 17, 3), float(100 * step + rank))
+        handles.append((step, g.start(rows)))
+        if len(handles) == 2:
+            st, h = handles.pop(0)
+            got = g.finish(h)
+            want = torch.cat([torch.full((3, 17, 3), float(100 * st + r)) for r in range(world)])
+            ok = ok and torch.equal(got, want)
+    parallel.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_row_gatherer_world2_lagged():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results)
+
+
+def _clip_worker(rank, world, port, q):
+    """tools/tracking/demo.run_clip with stand-in networks on CPU tensors: the sharded run (pairs and frames split over the
+    ranks, gloo all-gather) must give rank 0 exactly what the unsharded run gives."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import numpy as np
+    from tools.tracking import demo
+    T = 13
+    frames, dets = demo.synthetic_clip(T, H=128, W=192, n_people=3)
+    rel = np.stack((0.21 + 0.58 * ((np.arange(17) * 7) % 17) / 16.0, 0.065 + 0.87 * np.arange(17) / 16.0), 1)
+
+    def pose_fn(frame, boxes):                 # key points from the box AND the frame content (so a wrong frame shows)
+        b = np.asarray(boxes, np.float64).reshape(-1, 4)
+        k = np.zeros((len(b), 17, 3), np.float32)
+        k[:, :, :2] = b[:, None, :2] + rel[None] * (b[:, None, 2:4] - b[:, None, :2])
+        k[:, :, 2] = 0.5 + float(frame[0, 0, 0]) / 512.0
+        return k
+
+    def flow_fn(ims):                          # a field that depends on both frames of the pair
+        d = (ims[:, :, 1] - ims[:, :, 0]).mean(dim=(1, 2, 3))
+        return d[:, None, None, None].expand(-1, 2, ims.shape[-2], ims.shape[-1]) * 0.01 + 0.25
+
+    ref, _ = demo.run_clip(frames, dets, None, None, 0, 1, pose_fn=pose_fn, flow_fn=flow_fn, device="cpu")
+    parallel.init_from_env(backend="gloo")
+    got, _ = demo.run_clip(frames, dets, None, None, rank, world, pose_fn=pose_fn, flow_fn=flow_fn, device="cpu")
+    ok = True
+    if rank == 0:
+        ok = len(got) == len(ref) and all(
+            np.array_equal(a["boxes"], b["boxes"]) and np.array_equal(a["keypoints"], b["keypoints"]) and a["ids"] == b["ids"]
+            for a, b in zip(got, ref))
+    else:
+        ok = got is None
+    parallel.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_clip_sharding_world2_matches_unsharded():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_clip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results)

@@ -167,3 +167,106 @@ def test_clip_pipeline_runs_and_tracks(hip_lib):
     # flow_est wrapper: shape, finite, and == the batched path used by run_clip
     f = net_utils.flow_est(flow_net, frames[0], frames[1])
     assert f.shape == (2, 192, 256) and np.isfinite(f).all()
+
+
+# ---- the clip pipeline (tools/tracking/demo.py) with stand-in networks: functional signal + sharding ----------------------
+# heat-map peaks of the stand-in pose net, (column, row) in the 48 x 64 map: symmetric around the crop centre (24, 32) and
+# spanning 56 rows / 28 columns, so that the key-point hull grown by 15 % (box_propagation) reproduces the crop box: the
+# propagated box of a propagated box neither drifts nor shrinks
+_PEAKS = np.stack((10 + np.round(((np.arange(17) * 7) % 17) * 28 / 16.0), 4 + np.round(np.arange(17) * 56 / 16.0)), 1)
+_REL = np.stack((0.21 + 0.58 * ((np.arange(17) * 7) % 17) / 16.0, 0.065 + 0.87 * np.arange(17) / 16.0), 1)   # (x, y) in a box
+
+
+def _gt_pose(gt_boxes, boxes):
+    """A perfect "pose net": every query box gets the 17 key points of the ground-truth person it overlaps most."""
+    boxes = np.asarray(boxes, np.float64).reshape(-1, 4)
+    out = np.zeros((len(boxes), 17, 3), np.float32)
+    for i, b in enumerate(boxes):
+        ix = np.maximum(0, np.minimum(b[2], gt_boxes[:, 2]) - np.maximum(b[0], gt_boxes[:, 0]))
+        iy = np.maximum(0, np.minimum(b[3], gt_boxes[:, 3]) - np.maximum(b[1], gt_boxes[:, 1]))
+        g = gt_boxes[int(np.argmax(ix * iy))]
+        out[i, :, :2] = g[:2] + _REL * (g[2:4] - g[:2])
+        out[i, :, 2] = 0.9
+    return out
+
+
+def _separated_people(T, H=384, W=512):
+    """Five people who never overlap (box NMS cannot merge two of them), constant velocities, detector jitter +-3 px.
+    Returns detector boxes, ground-truth boxes and the true flow fields (each person's velocity inside its box + 12 px)."""
+    x0 = np.array([20.0, 120.0, 225.0, 330.0, 430.0])
+    y0 = np.array([30.0, 180.0, 60.0, 150.0, 40.0])
+    w = np.array([55.0, 60.0, 50.0, 58.0, 52.0])
+    h = np.array([130.0, 150.0, 120.0, 160.0, 140.0])
+    vx = np.array([0.15, -0.1, 0.1, -0.15, 0.1])
+    vy = np.array([0.4, -0.5, 0.6, 0.3, -0.2])
+    dets, gts = [], []
+    flows = np.zeros((T - 1, 2, H, W), np.float32)
+    for t in range(T):
+        g = np.stack((x0 + vx * t, y0 + vy * t, x0 + vx * t + w, y0 + vy * t + h), 1)
+        jit = (synth.uniform01(3, "jit%d" % t, (5, 4)) - 0.5) * 6.0
+        score = 0.5 + 0.5 * synth.uniform01(3, "score%d" % t, (5, 1))
+        gts.append(g)
+        dets.append(np.concatenate((g + jit, score), 1).astype(np.float32))
+        if t < T - 1:
+            for i in range(5):
+                xa, ya, xb, yb = (int(max(0, g[i, 0] - 12)), int(max(0, g[i, 1] - 12)), int(min(W, g[i, 2] + 12)), int(min(H, g[i, 3] + 12)))
+                flows[t, 0, ya:yb, xa:xb] = vx[i]
+                flows[t, 1, ya:yb, xa:xb] = vy[i]
+    return dets, gts, flows
+
+
+def test_tracking_pass_keeps_five_ids_for_five_people():
+    """process_frame's union + NMS (tools/tracking/demo.py:35-42) + the flow tracker on the synthetic clip with a perfect
+    pose stand-in and zero flow: the box count stays at the number of people and so does the number of ids."""
+    from tools.tracking import demo
+    T = 80
+    dets, gts, flows = _separated_people(T)
+    kp_det = [_gt_pose(gts[t], dets[t][:, :4]) for t in range(T)]
+    out = demo.tracking_pass(dets, kp_det, flows, lambda t, boxes: _gt_pose(gts[t], boxes))
+    assert all(len(f["boxes"]) == 5 for f in out), sorted({len(f["boxes"]) for f in out})
+    ids = [tuple(sorted(f["ids"])) for f in out]
+    assert len({i for f in out for i in f["ids"]}) == 5 and all(i == ids[0] for i in ids)
+    # an untrained pose net (key points anywhere) cannot blow the per-frame work up: the union is capped
+    rng = np.random.default_rng(0)
+    junk = lambda t, boxes: np.concatenate((rng.uniform(0, 380, (len(boxes), 17, 2)), np.full((len(boxes), 17, 1), 0.5)), 2)
+    out = demo.tracking_pass(dets, [junk(t, dets[t]) for t in range(T)], flows, junk, max_boxes=12)
+    assert max(len(f["boxes"]) for f in out) <= 12
+
+
+@pytest.mark.gpu
+def test_clip_pipeline_functional_signal_on_gpu(hip_lib):
+    """The GPU pieces of the clip pipeline (device-resident clip, ft_crop_affine_fwd crops, heat-map arg-max + inverse
+    affine, flow fields read back for the propagation) around a stand-in pose module whose heat maps peak at fixed
+    crop-relative points and a stand-in flow net that returns the true motion: five people keep five ids, one box each."""
+    from tools.tracking import demo
+
+    class PeakPose(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.anchor = torch.nn.Parameter(torch.zeros(1))
+            hm = torch.zeros((17, 64, 48))
+            for k in range(17):
+                hm[k, int(_PEAKS[k, 1]), int(_PEAKS[k, 0])] = 1.0
+            self.register_buffer("hm", hm)
+
+        def forward(self, crops):
+            return self.hm[None].expand(crops.shape[0], -1, -1, -1).contiguous()
+
+    T = 40
+    frames, _ = demo.synthetic_clip(T)
+    dets, _, flows = _separated_people(T)
+    pose = PeakPose().cuda().eval()
+    nxt = [0]
+
+    def true_flow(ims):                       # run_clip walks the pairs in order: hand out the true fields one by one
+        b = ims.shape[0]
+        f = torch.from_numpy(flows[nxt[0]:nxt[0] + b]).to(ims.device)
+        nxt[0] += b
+        return f
+    out, tm = demo.run_clip(frames, dets, pose, None, flow_fn=true_flow)
+    assert all(len(f["boxes"]) == 5 for f in out), sorted({len(f["boxes"]) for f in out})
+    assert len({i for f in out for i in f["ids"]}) == 5
+    k0 = out[0]["keypoints"]
+    b0 = out[0]["boxes"]
+    assert np.all(k0[..., 2] > 0.5) and np.all(k0[..., 0] >= b0[:, None, 0] - 16) and np.all(k0[..., 0] <= b0[:, None, 2] + 16)
+    assert np.all(k0[..., 1] >= b0[:, None, 1] - 16) and np.all(k0[..., 1] <= b0[:, None, 3] + 16)
