@@ -60,12 +60,14 @@ def build_flow(device, dtype, seed=1234, name="FlowNet2S"):
 def pmc_traffic(workload):
     """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE; tools/dev/prof_traffic.sh + pmc_traffic.py on this same command). None if not measured."""
-    path = os.path.join(ROOT, "profiles", f"r01_{workload}_hbm_traffic_pmc.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["conv_kernels"]["hbm_bytes_per_launch_avg"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for tag in ("r02", "r01"):       # the latest committed round
+        path = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic_pmc.json")
+        try:
+            with open(path) as f:
+                return json.load(f)["conv_kernels"]["hbm_bytes_per_launch_avg"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def conv_roofline(prog, dtype_name, iters=5):

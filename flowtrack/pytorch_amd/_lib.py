@@ -83,6 +83,10 @@ _PROTOTYPES = {
     "ft_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "ft_conv_flops": (c_double, [POINTER(ConvDesc)]),
+    "ft_conv_direct_supported": (c_int, [POINTER(ConvDesc)]),
+    "ft_conv_direct_weight_bytes": (ctypes.c_longlong, [POINTER(ConvDesc)]),
+    "ft_conv_direct_pack": (c_int, [POINTER(ConvDesc), c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ft_conv_direct_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_supported": (c_int, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_flops": (c_double, [POINTER(BottleneckDesc)]),

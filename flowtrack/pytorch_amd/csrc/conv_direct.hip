@@ -1,0 +1,545 @@
+// 1x1 convolutions of the deep, small-map stages (fp16) as a weight-streaming GEMM whose weight fragments never touch
+// LDS (reference: the 1x1 convs of Bottleneck, lib/pose/models/blocks.py:89,95 + the projection shortcut :98-103, run
+// there through torch.nn -> cuDNN).
+//
+// Why: at 16x12 / 8x6 maps a layer has 12 k / 3 k pixels at batch 64.  The GEMM tiles that fill 256 CUs are then so small
+// (64x64) that every operand byte is re-delivered L2 -> LDS many times and a K-step is a barrier-bound ~0.5 us: layer4's
+// 1x1 convs run at 260-290 TFLOP/s in conv_igemm_dma_kernel.  Here a workgroup owns 96 pixels; the pixel operand streams
+// through a 3-slot LDS ring in K chunks (whole lines per pixel, DMA), and each wave pulls ITS weight fragments straight
+// from the fragment-ordered stream into registers two chunks ahead (1-KiB contiguous loads, nothing shared between waves,
+// so an LDS round trip would only add traffic on the LDS port; tools/dev/ubench/stream_ring.hip).  Two shapes:
+//   KSPLIT = 1  N-tile 256: wave w owns output-channel tiles {2w, 2w+1}, all four K16 slices of a 64-channel chunk
+//   KSPLIT = 4  N-tile  64: all waves own tiles {0, 1}; a chunk is 256 channels and wave w takes its w-th quarter; the four
+//               partial accumulators meet in LDS (for N <= 512 layers, whose 96 x 256 tiles would leave CUs idle)
+// Either way a wave runs 2 x 3 MFMA tiles over four K16 slices per chunk from 8 register-resident fragments.
+// Epilogue: folded BN (+ identity residual) + ReLU, fp16, through an LDS staging tile, whole-line stores.
+// Optional second input (K-concat, ft_conv_desc.x2_*: conv3 + projection shortcut as one GEMM): its chunks follow x's.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "ft_common.h"
+
+namespace ft {
+namespace {
+
+struct CdParams {
+  const char* x;
+  const char* x2;
+  const char* res;
+  char* y;
+  const char* ws;
+  const float* scale;
+  const float* shift;
+  int M;                       // pixels
+  int nc1, nc2;                // chunks of x / of x2
+  int x_cstride, x_coff;
+  int HqWq, Wq;                // output pixel grid (for the strided second input)
+  int x2_hi, x2_wi, x2_cstride, x2_coff, x2_stride;
+  int y_cstride, y_coff, res_cstride, res_coff;
+  int Cout, act;
+  float slope;
+  int npt, ncb;                // pixel tiles, output-channel blocks
+  unsigned x_bytes, x2_bytes, y_bytes, res_bytes, ws_bytes;
+  int dbg;                     // FT_CD_DBG (dev): 32 = phase timestamps of wave 0 into the tile's first output row
+};
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void cd_unroll(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    cd_unroll<N, I + 1>(f);
+  }
+}
+
+#define CD_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__host__ __device__ constexpr int cd_sigma(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }   // as bns_sigma
+
+template <int KSPLIT>
+struct CdGeom {
+  static constexpr int MT = 3, BP = 96;                       // pixel tiles per wave, pixels per workgroup
+  static constexpr int BN = KSPLIT == 1 ? 256 : 64;           // output channels per workgroup
+  static constexpr int CHUNK_K = KSPLIT == 1 ? 64 : 256;      // channels per ring slot
+  static constexpr int ROWB = CHUNK_K * 2;                    // bytes of a ring row
+  static constexpr int XB = BP * ROWB;                        // bytes of a ring slot
+  static constexpr int LX = XB / 1024 / 4;                    // 1-KiB x loads per wave per chunk
+  static constexpr int WCHUNK = 4 * 8 * 1024;                 // weight bytes per chunk: 4 waves x 8 fragments
+  static constexpr int STG_ROWB = BN * 2;
+  static constexpr int RING = 3 * XB;
+  static constexpr int PART = KSPLIT == 1 ? 0 : 4 * 6 * 4096; // fp32 partial tiles of the four waves
+  static constexpr int LDS_BYTES = (RING > PART + BP * STG_ROWB ? RING : PART + BP * STG_ROWB) + 2 * BN * 4;
+  static_assert(LDS_BYTES <= 163840, "LDS map");   // ring [0, RING) during the K walk; afterwards partials [0, PART) + staging tile behind them
+};
+
+// NCH > 0: the chunk walk is unrolled for exactly NCH chunks — every vector-memory wait is then a compile-time count.  (With
+// a run-time trip count hipcc joins its wait-count states at the loop header and drains the whole queue, vmcnt(0), at the
+// first use of a prefetched weight fragment: the look-ahead is lost, 22 instead of 12 us on layer4's conv3.)  NCH = 0 is
+// the run-time-loop fallback for K sizes without an instantiation.
+template <int KSPLIT, bool HAS_RES, int NCH>
+__global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using G = CdGeom<KSPLIT>;
+  constexpr int MT = G::MT, BP = G::BP, BN = G::BN, ROWB = G::ROWB, XB = G::XB, LX = G::LX;
+  constexpr int TAB = G::LDS_BYTES - 2 * BN * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  using c2 = std::integral_constant<int, 2>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // XCD-aware order: output-channel block fastest, so the workgroups that share a pixel tile sit in one XCD's L2
+  int logical;
+  {
+    const int total = p.npt * p.ncb;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  const int m0 = pt * BP;
+  const int nchunk = NCH > 0 ? NCH : p.nc1 + p.nc2;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.nc2 ? p.x2 : p.x), 0, p.nc2 ? p.x2_bytes : p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- loaders ---------------------------------------------------------------------------------------------------------
+  // ring row = pixel, ROWB bytes; a 1-KiB wave load covers 1024 / ROWB rows; XOR swizzle on the SOURCE 16-byte position
+  constexpr int CPR = ROWB / 16;                  // 16-byte positions per row: 8 or 32
+  constexpr int RPL = 64 / CPR;                   // rows per wave load: 8 or 2
+  unsigned x_voff[LX], x2_voff[LX];
+#pragma unroll
+  for (int t = 0; t < LX; ++t) {
+    const int row = (t * 4 + wave) * RPL + lane / CPR, pos = lane % CPR;
+    const int m = m0 + row;
+    const unsigned swz = (unsigned)((pos ^ (row & (CPR < 16 ? CPR - 1 : 15))) << 4);
+    unsigned v = kOOB, v2 = kOOB;
+    if (m < p.M) {
+      v = (unsigned)((m * p.x_cstride + p.x_coff) * 2) + swz;
+      if (p.nc2) {
+        const int n = m / p.HqWq, rem = m - n * p.HqWq, qy = rem / p.Wq, qx = rem - qy * p.Wq;
+        v2 = (unsigned)((((n * p.x2_hi + qy * p.x2_stride) * p.x2_wi + qx * p.x2_stride) * p.x2_cstride + p.x2_coff) * 2) + swz;
+      }
+    }
+    x_voff[t] = v;
+    x2_voff[t] = v2;
+  }
+  auto issue_x = [&](int c, int buf) {            // chunk c of the K walk: x's chunks, then x2's
+    char* dst = smem + buf * XB;
+    if (c < p.nc1) {
+#pragma unroll
+      for (int t = 0; t < LX; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x_voff[t], c * ROWB, 0, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < LX; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x2, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x2_voff[t], (c - p.nc1) * ROWB, 0, 0);
+    }
+  };
+  // weights of chunk c for this wave: 8 contiguous KiB at ((cb * nchunk + c) * 4 + wave) * 8 KiB; past the stream: zeros
+  const unsigned lane16 = (unsigned)lane * 16u;
+  uint4_t areg[3][4][2];
+  auto load_a = [&](auto slotc, int c) {
+    constexpr int SL = decltype(slotc)::value;
+    const int base = c < nchunk ? ((cb * nchunk + c) * 4 + wave) * 8192 : 0x7fff0000;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, base + (kk * 2 + i) * 1024, 0);
+  };
+
+  // folded-BN table of this channel block -> LDS (scale may be absent: the K-concat form folds it into the weights)
+  if (tid < BN / 4) {
+    const float4_t one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const int ch = cb * BN + tid * 4;
+    reinterpret_cast<float4_t*>(smem + TAB)[tid] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + ch) : one;
+    reinterpret_cast<float4_t*>(smem + TAB + BN * 4)[tid] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + ch) : zero;
+  }
+  // residual rows of this wave's output tiles, accumulator layout (lane = pixel, 16 consecutive channels): two 16-byte loads per tile
+  constexpr int NTILE = 2 * MT;                    // output tiles a wave finalises at most
+  const int wtile0 = KSPLIT == 1 ? 2 * wave : 0;   // first channel tile (inside the block) of the MFMA phase
+  uint4_t rres[HAS_RES ? (KSPLIT == 1 ? NTILE : 2) : 1][2];
+  if constexpr (HAS_RES) {
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.res), 0, p.res_bytes, 0x00020000);
+    if constexpr (KSPLIT == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const int m = m0 + j * 32 + l31;
+          const unsigned v = m < p.M ? (unsigned)((m * p.res_cstride + p.res_coff + cb * BN + (wtile0 + i) * 32 + 16 * lhi) * 2) : kOOB;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) rres[i * MT + j][h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, v, h * 16, 0);
+        }
+    } else {
+      // after the reduction wave w finalises tiles w and w + 4 (tile = i * MT + j over 2 channel tiles x 3 pixel tiles)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int tl = wave + 4 * k, i = tl / MT, j = tl - i * MT;
+        const int m = m0 + j * 32 + l31;
+        const unsigned v = (tl < NTILE && m < p.M) ? (unsigned)((m * p.res_cstride + p.res_coff + cb * BN + i * 32 + 16 * lhi) * 2) : kOOB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rres[k][h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, v, h * 16, 0);
+      }
+    }
+  }
+
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  CD_TS(0);
+  issue_x(0, 0);
+  issue_x(1, 1);
+  issue_x(2, 2);
+  load_a(c0{}, 0);
+  load_a(c1{}, 1);
+
+  float16_t acc[2][MT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // B fragment offsets (slot-relative): row j*32 + l31, slice (KSPLIT == 4 ? 4 * wave : 0) + kk
+  int b_off[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int row = j * 32 + l31;
+    const int s0 = KSPLIT == 1 ? 0 : 4 * wave;
+    b_off[j] = row * ROWB + ((((s0 * 2 + lhi) ^ (row & (CPR < 16 ? CPR - 1 : 15)))) << 4);
+  }
+  uint4_t fx[2][MT];
+  auto ldx = [&](auto setc, int buf, int kk) {
+    constexpr int S = decltype(setc)::value;
+    const char* xb = smem + buf * XB;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) fx[S][j] = *reinterpret_cast<const uint4_t*>(xb + (b_off[j] ^ (kk << 5)));
+  };
+  auto mma = [&](auto setc, auto slotc, auto kkc) {
+    constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]), __builtin_bit_cast(half8_t, fx[S][j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+  auto issue_x_dummy = [&](int buf) {               // keeps the count of vector-memory operations per chunk constant
+    char* dst = smem + buf * XB;
+#pragma unroll
+    for (int t = 0; t < LX; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, kOOB, 0, 0, 0);
+  };
+  // one chunk (ring slot = register slot = c % 3): slice 0 of the pixel operand already sits in register set 0
+  auto chunk = [&](auto slotc, int c) {
+    constexpr int SL = decltype(slotc)::value;
+    using slot = std::integral_constant<int, SL>;
+    load_a(std::integral_constant<int, (SL + 2) % 3>{}, c + 2);
+    ldx(c1{}, SL, 1);
+    mma(c0{}, slot{}, std::integral_constant<int, 0>{});
+    ldx(c0{}, SL, 2);
+    mma(c1{}, slot{}, std::integral_constant<int, 1>{});
+    ldx(c1{}, SL, 3);
+    mma(c0{}, slot{}, std::integral_constant<int, 2>{});
+    if (c + 1 < nchunk) {
+      // x chunk c+1 has landed and every read of chunk c's slot is complete: refill it with chunk c+3.  Younger than x chunk
+      // c+1 are the weights of chunk c+1 (needed next anyway), x chunk c+2 and the weights of chunk c+2.
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + 8) : "memory");
+      CD_BARRIER();
+      if (c + 3 < nchunk) issue_x(c + 3, SL);
+      else issue_x_dummy(SL);
+      ldx(c0{}, (SL + 1) % 3, 0);
+    }
+    mma(c1{}, slot{}, std::integral_constant<int, 3>{});
+  };
+
+  // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight chunks may fly
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 16) : "memory");
+  CD_BARRIER();
+  CD_TS(1);
+  ldx(c0{}, 0, 0);
+  if constexpr (NCH > 0) {
+    cd_unroll<NCH>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      chunk(std::integral_constant<int, c % 3>{}, c);
+    });
+  } else {
+    for (int c = 0; c < nchunk; c += 3) {
+      chunk(c0{}, c);
+      if (c + 1 < nchunk) chunk(c1{}, c + 1);
+      if (c + 2 < nchunk) chunk(c2{}, c + 2);
+    }
+  }
+  CD_TS(2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the look-ahead (dummy) loads must not outlive the ring
+  CD_BARRIER();                                                    // every wave is past its last ring read
+  CD_TS(3);
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------
+  const float* tsc = reinterpret_cast<const float*>(smem + TAB);
+  const float* tsh = tsc + BN;
+  constexpr int SCPR = G::STG_ROWB / 16;            // 16-byte chunks per staging row: 32 or 8
+  constexpr int SMASK = SCPR < 16 ? SCPR - 1 : 15;
+  char* stg = smem + G::PART;
+  // act(v) = max(v, k*v) with k = 0 (relu), slope (leaky, <= 1) or 1 (none): branch-free
+  const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
+  auto finish_tile = [&](const float16_t& a, int i, int j, const uint4_t* rr) {   // channel tile i (inside the block), pixel tile j
+    const int ch = i * 32 + 16 * lhi;
+    const int row = j * 32 + l31;
+    float4_t sc[4], sh[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      sc[g4] = *reinterpret_cast<const float4_t*>(tsc + ch + g4 * 4);
+      sh[g4] = *reinterpret_cast<const float4_t*>(tsh + ch + g4 * 4);
+    }
+    half8_t o[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      half8_t rs;
+      if constexpr (HAS_RES) rs = __builtin_bit_cast(half8_t, rr[h]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = h * 8 + e;
+        float v = a[r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3];
+        if constexpr (HAS_RES) v += (float)rs[e];
+        o[h][e] = (half_t)__builtin_fmaxf(v, v * act_k);
+      }
+      *reinterpret_cast<half8_t*>(stg + row * G::STG_ROWB + ((((ch >> 3) + h) ^ (row & SMASK)) << 4)) = o[h];
+    }
+  };
+  if constexpr (KSPLIT == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) finish_tile(acc[i][j], wtile0 + i, j, HAS_RES ? rres[i * MT + j] : nullptr);
+  } else {
+    // the four K quarters meet in LDS: partial tile (wave, tile, register group) as lane-contiguous float4 rows
+    float4_t* part = reinterpret_cast<float4_t*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4_t v = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+          part[((wave * NTILE + i * MT + j) * 4 + g4) * 64 + lane] = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CD_BARRIER();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int tl = wave + 4 * k;
+      if (tl < NTILE) {
+        float16_t sum;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float4_t v = part[((0 * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) v += part[((w * NTILE + tl) * 4 + g4) * 64 + lane];
+          sum[4 * g4] = v[0]; sum[4 * g4 + 1] = v[1]; sum[4 * g4 + 2] = v[2]; sum[4 * g4 + 3] = v[3];
+        }
+        finish_tile(sum, tl / MT, tl % MT, HAS_RES ? rres[k] : nullptr);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  constexpr int NST = BP * SCPR / 256;              // 16-byte chunks per thread: 12 or 3
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int idx = tid + 256 * k, row = idx / SCPR, ch = idx % SCPR;
+    const int m = m0 + row;
+    const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + row * G::STG_ROWB + ((ch ^ (row & SMASK)) << 4));
+    const unsigned voff = (m < p.M && cb * BN + ch * 8 < p.Cout) ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + ch * 8) * 2) : kOOB;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, 0);
+  }
+  if (p.dbg & 32) {
+    ts[4] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[5] = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && m0 < p.M) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y + ((size_t)m0 * p.y_cstride + p.y_coff + cb * BN) * 2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    }
+  }
+#endif
+}
+
+// ---- weight stream: [channel block][chunk][wave][kk][i] fragments of 1 KiB -----------------------------------------------
+// from the K-major packed layout of ft_conv_pack_geometry ([Cout_pad][kpad], k over x's channels then x2's).
+template <int KSPLIT>
+__global__ __launch_bounds__(256) void cd_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int nchunk, int ncb,
+                                                      int kpad, int cout_pad) {
+  using G = CdGeom<KSPLIT>;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int total = ncb * nchunk * (G::WCHUNK / 16);
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  int f = idx >> 6;                                  // fragment index
+  const int i = f & 1; f >>= 1;
+  const int kk = f & 3; f >>= 2;
+  const int wv = f & 3; f >>= 2;
+  const int c = f % nchunk, cb = f / nchunk;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int co, k;
+  if (KSPLIT == 1) {
+    co = cb * 256 + (2 * wv + i) * 32 + cd_sigma(l31);
+    k = c * 64 + kk * 16 + 8 * lhi;
+  } else {
+    co = cb * 64 + i * 32 + cd_sigma(l31);
+    k = c * 256 + (4 * wv + kk) * 16 + 8 * lhi;
+  }
+  uint4_t v = {0u, 0u, 0u, 0u};
+  if (co < cout_pad && k < kpad) v = *reinterpret_cast<const uint4_t*>(w + (size_t)co * kpad + k);
+  out[idx] = v;
+}
+
+struct CdPlan {
+  int ksplit;          // 1 or 4
+  int nc1, nc2, npt, ncb;
+};
+
+static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
+  if (!d) return FT_ERR_INVALID_ARG;
+  if (d->dtype != FT_F16 || d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return FT_ERR_UNSUPPORTED;
+  if (d->tail_cout || d->pool || d->x_wpitch || d->out_layout != FT_LAYOUT_NHWC) return FT_ERR_UNSUPPORTED;
+  if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
+  if (d->x_coff % 8 || d->x_cstride % 8 || d->y_coff % 8 || d->y_cstride % 8 || d->Cout % 64) return FT_ERR_UNSUPPORTED;
+  if (d->x_cstride < d->x_coff + d->Cin || d->y_cstride < d->y_coff + d->Cout) return FT_ERR_INVALID_ARG;
+  if (d->has_residual && (d->x2_cin || d->res_coff % 8 || d->res_cstride % 8)) return FT_ERR_UNSUPPORTED;
+  if (d->x2_cin && (d->x2_coff % 8 || d->x2_cstride % 8 || d->x2_stride < 1 || d->Ho != (d->x2_hi - 1) / d->x2_stride + 1 ||
+                    d->Wo != (d->x2_wi - 1) / d->x2_stride + 1)) return FT_ERR_UNSUPPORTED;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long lim = 1LL << 31;
+  if (M * d->x_cstride * 2 >= lim || M * d->y_cstride * 2 >= lim || (d->has_residual && M * d->res_cstride * 2 >= lim) ||
+      (d->x2_cin && (long long)d->N * d->x2_hi * d->x2_wi * d->x2_cstride * 2 >= lim)) return FT_ERR_UNSUPPORTED;
+  const int npt = (int)((M + 95) / 96);
+  static const int force = getenv("FT_CD_KSPLIT") ? atoi(getenv("FT_CD_KSPLIT")) : 0;
+  const bool a_ok = d->Cout % 256 == 0 && d->Cin % 64 == 0 && d->x2_cin % 64 == 0;
+  const bool b_ok = d->Cin % 256 == 0 && d->x2_cin % 256 == 0;
+  if (!a_ok && !b_ok) return FT_ERR_UNSUPPORTED;
+  // N-tile 256 unless that leaves most CUs idle and the 64-wide, K-split form is available
+  int ks = a_ok ? 1 : 4;
+  if (a_ok && b_ok && (long long)npt * (d->Cout / 256) < 160) ks = 4;
+  if (force == 1 && a_ok) ks = 1;
+  if (force == 4 && b_ok) ks = 4;
+  const int ck = ks == 1 ? 64 : 256;
+  *out = CdPlan{ks, d->Cin / ck, d->x2_cin / ck, npt, d->Cout / (ks == 1 ? 256 : 64)};
+  return FT_OK;
+}
+
+template <int KSPLIT, bool HAS_RES, int NCH>
+static int cd_launch(const CdParams& p, hipStream_t s) {
+  auto k = conv_direct_kernel<KSPLIT, HAS_RES, NCH>;
+  constexpr int lds = CdGeom<KSPLIT>::LDS_BYTES;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  FT_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(k, dim3(p.npt * p.ncb), dim3(256), lds, s, p);
+  FT_LAUNCH_CHECK("conv_direct_kernel");
+  return FT_OK;
+}
+
+template <int KSPLIT, bool HAS_RES>
+static int cd_dispatch(const CdParams& p, hipStream_t s) {
+  static const bool no_unroll = getenv("FT_CD_NO_UNROLL") != nullptr;     // dev A/B: the run-time-loop form
+  const int n = no_unroll ? 0 : p.nc1 + p.nc2;
+  if (KSPLIT == 1) {
+    switch (n) {     // K = 512 / 768 / 1024 / 1536 (ResNet layer3 / layer4 1x1 convs and their K-concatenated block exits)
+      case 8: return cd_launch<KSPLIT, HAS_RES, 8>(p, s);
+      case 12: return cd_launch<KSPLIT, HAS_RES, 12>(p, s);
+      case 16: return cd_launch<KSPLIT, HAS_RES, 16>(p, s);
+      case 24: return cd_launch<KSPLIT, HAS_RES, 24>(p, s);
+      default: return cd_launch<KSPLIT, HAS_RES, 0>(p, s);
+    }
+  }
+  switch (n) {       // K = 1024 / 2048 in 256-channel chunks
+    case 4: return cd_launch<KSPLIT, HAS_RES, 4>(p, s);
+    case 8: return cd_launch<KSPLIT, HAS_RES, 8>(p, s);
+    default: return cd_launch<KSPLIT, HAS_RES, 0>(p, s);
+  }
+}
+
+}  // namespace
+}  // namespace ft
+
+extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
+  ft::CdPlan pl;
+  return ft::cd_plan(d, &pl);
+}
+
+extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
+  ft::CdPlan pl;
+  if (ft::cd_plan(d, &pl) != FT_OK) return 0;
+  return (long long)pl.ncb * (pl.nc1 + pl.nc2) * 32768;
+}
+
+extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, int kpad, int cout_pad, void* wstream, ft_stream_t stream) {
+  using namespace ft;
+  CdPlan pl;
+  const int st = cd_plan(d, &pl);
+  if (st != FT_OK) return st;
+  if (!w_packed || !wstream || kpad < d->Cin + d->x2_cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
+  const int nchunk = pl.nc1 + pl.nc2;
+  const int total = pl.ncb * nchunk * 2048;
+  hipStream_t s = as_stream(stream);
+  if (pl.ksplit == 1)
+    hipLaunchKernelGGL(cd_pack_kernel<1>, dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const half_t*>(w_packed),
+                       static_cast<uint4_t*>(wstream), nchunk, pl.ncb, kpad, cout_pad);
+  else
+    hipLaunchKernelGGL(cd_pack_kernel<4>, dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const half_t*>(w_packed),
+                       static_cast<uint4_t*>(wstream), nchunk, pl.ncb, kpad, cout_pad);
+  FT_LAUNCH_CHECK("cd_pack_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const void* wstream, const float* scale, const float* shift,
+                                  const void* residual, void* y, ft_stream_t stream) {
+  using namespace ft;
+  CdPlan pl;
+  const int st = cd_plan(d, &pl);
+  if (st != FT_OK) return st;
+  if (!x || !wstream || !y || ((d->has_residual || d->x2_cin) && !residual)) return FT_ERR_INVALID_ARG;
+  CdParams p{};
+  p.x = static_cast<const char*>(x);
+  p.y = static_cast<char*>(y);
+  p.ws = static_cast<const char*>(wstream);
+  p.scale = scale;
+  p.shift = shift;
+  p.M = d->N * d->Ho * d->Wo;
+  p.nc1 = pl.nc1; p.nc2 = pl.nc2; p.npt = pl.npt; p.ncb = pl.ncb;
+  p.x_cstride = d->x_cstride; p.x_coff = d->x_coff;
+  p.HqWq = d->Ho * d->Wo; p.Wq = d->Wo;
+  p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
+  p.Cout = d->Cout; p.act = d->act; p.slope = d->slope;
+  p.x_bytes = (unsigned)((size_t)p.M * d->x_cstride * 2);
+  p.y_bytes = (unsigned)((size_t)p.M * d->y_cstride * 2);
+  p.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+  if (d->x2_cin) {
+    p.x2 = static_cast<const char*>(residual);
+    p.x2_hi = d->x2_hi; p.x2_wi = d->x2_wi; p.x2_cstride = d->x2_cstride; p.x2_coff = d->x2_coff; p.x2_stride = d->x2_stride;
+    p.x2_bytes = (unsigned)((size_t)d->N * d->x2_hi * d->x2_wi * d->x2_cstride * 2);
+  }
+  if (d->has_residual) {
+    p.res = static_cast<const char*>(residual);
+    p.res_cstride = d->res_cstride; p.res_coff = d->res_coff;
+    p.res_bytes = (unsigned)((size_t)p.M * d->res_cstride * 2);
+  }
+  static const int dbg = getenv("FT_CD_DBG") ? atoi(getenv("FT_CD_DBG")) : 0;
+  p.dbg = dbg;
+  hipStream_t s = as_stream(stream);
+  if (pl.ksplit == 1) return d->has_residual ? cd_dispatch<1, true>(p, s) : cd_dispatch<1, false>(p, s);
+  return d->has_residual ? cd_dispatch<4, true>(p, s) : cd_dispatch<4, false>(p, s);
+}

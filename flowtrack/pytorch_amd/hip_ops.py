@@ -93,7 +93,7 @@ def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int
 # --------------------------------------------------------------------------------------------
 def is_conv_call(name: str) -> bool:
     """Launches whose work is convolution MACs (the roofline's kernels): ft_conv2d_fwd[_ws] and ft_bottleneck_fwd."""
-    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd")
+    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd", "ft_conv_direct_fwd")
 
 
 class Program:
@@ -303,9 +303,12 @@ class Program:
             return sum(1 for k in keys if _TILE_CACHE[k])
         cands = []
         hints = (ctypes.c_int * 32)()
-        for (_, d), key in zip(convs, keys):
+        for (_, d), key in zip(convs, keys):     # (_ = index of the launch in self.calls)
             if key in _TILE_CACHE:        # picks are sticky within a process: two plans of one model (other batch-
                 cands.append([_TILE_CACHE[key]])   # independent keys aside) must run the same variants, bit for bit
+                continue
+            if self.calls[_][0] == "ft_conv_direct_fwd":   # one kernel, nothing to pick
+                cands.append([0])
                 continue
             n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
             if n < 0:
@@ -595,6 +598,12 @@ class FusedConv:
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
+        ws = _direct_stream(self, d, w, x.t.device) if (self.k == 1 and isinstance(y, ActView) and not self.tail_cout and not pool) else None
+        if ws is not None:
+            prog.add("ft_conv_direct_fwd", ctypes.byref(d), x.t.data_ptr(), ws.data_ptr(),
+                     scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, res_ptr,
+                     yt.data_ptr(), keep=(d, x.t, yt, ws, scale, shift, residual.t if residual is not None else None))
+            return
         if prog._side:     # side-branch launches may overlap main-branch ones: they must not share the plan's workspace
             prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
                      scale.data_ptr() if scale is not None else None,
@@ -606,6 +615,31 @@ class FusedConv:
                  scale.data_ptr() if scale is not None else None,
                  shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(), prog._ws_ptr, prog._ws_size,
                  keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
+
+
+#: 1x1 layers with few pixels and a long K run on ft_conv_direct_fwd (weights straight to registers); FT_CONV_DIRECT=0 keeps
+#: them on ft_conv2d_fwd, FT_CONV_DIRECT_MAX_PIXELS moves the pixel bound (default 16384: ResNet layer3 / layer4 at batch 64)
+CONV_DIRECT = os.environ.get("FT_CONV_DIRECT", "1") != "0"
+CONV_DIRECT_MAX_PIXELS = int(os.environ.get("FT_CONV_DIRECT_MAX_PIXELS", "16384"))
+
+
+def _direct_stream(owner, d: ConvDesc, w: torch.Tensor, device) -> Optional[torch.Tensor]:
+    """The ft_conv_direct weight stream of `d` (built once per packed weight set, cached on the layer), or None when the
+    layer does not qualify."""
+    lib = _lib.load()
+    if not CONV_DIRECT or d.dtype != _lib.FT_F16 or d.N * d.Ho * d.Wo > CONV_DIRECT_MAX_PIXELS or d.Cin + d.x2_cin < 256:
+        return None
+    if lib.ft_conv_direct_supported(ctypes.byref(d)) != 0:
+        return None
+    key = ("direct", int(lib.ft_conv_direct_weight_bytes(ctypes.byref(d))), d.N * d.Ho * d.Wo <= 0, w.data_ptr())
+    hit = owner._packed.get(key)
+    if hit is None:
+        ws = torch.empty(key[1], dtype=torch.uint8, device=device)
+        check(lib.ft_conv_direct_pack(ctypes.byref(d), w.data_ptr(), int(w.shape[-1]), int(w.shape[-2]), ws.data_ptr(),
+                                      current_stream_handle(device)), "ft_conv_direct_pack")
+        torch.cuda.current_stream(device).synchronize()
+        hit = owner._packed[key] = ws
+    return hit
 
 
 class FusedShortcutConv:
@@ -665,6 +699,11 @@ class FusedShortcutConv:
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
+        ws = _direct_stream(self, d, w, t2.t.device)
+        if ws is not None:
+            prog.add("ft_conv_direct_fwd", ctypes.byref(d), t2.t.data_ptr(), ws.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
+                     y.t.data_ptr(), keep=(d, t2.t, x.t, y.t, ws, shift))
+            return
         prog.add("ft_conv2d_fwd", ctypes.byref(d), t2.t.data_ptr(), w.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
                  y.t.data_ptr(), keep=(d, t2.t, x.t, y.t, w, shift))
 

@@ -188,6 +188,22 @@ int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int max);
 /* algorithmic FLOPs (2*MACs, unpadded) of one ft_conv2d_fwd call */
 double ft_conv_flops(const ft_conv_desc* d);
 
+/* ---- 1x1 convolutions of the deep, small-map stages: weight-streaming GEMM, weights straight to registers ----------
+ * Same math as ft_conv2d_fwd for a 1x1 / stride 1 / pad 0 fp16 NHWC layer (optionally with the K-concat second input
+ * x2_* or an identity residual), for layers with few pixels and long K (ResNet layer3/4 at batch 64, blocks.py:89,95,
+ * 98-103): a workgroup owns 96 pixels, the pixel operand streams through an LDS ring, each wave loads its weight
+ * fragments from a fragment-ordered stream directly into registers (csrc/conv_direct.hip).
+ *   ft_conv_direct_supported     FT_OK when the shape qualifies (Cin, x2_cin multiples of 64, Cout multiple of 256 — or
+ *                                Cin, x2_cin multiples of 256 and Cout of 64 for the K-split form)
+ *   ft_conv_direct_weight_bytes  size of the weight stream
+ *   ft_conv_direct_pack          builds it from the ft_conv_pack_geometry layout w_packed [cout_pad][kpad] (once per weight set)
+ *   ft_conv_direct_fwd           arguments as ft_conv2d_fwd (residual = identity residual or the second input x2) */
+int ft_conv_direct_supported(const ft_conv_desc* d);
+long long ft_conv_direct_weight_bytes(const ft_conv_desc* d);
+int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, int kpad, int cout_pad, void* wstream, ft_stream_t stream);
+int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const void* wstream, const float* scale, const float* shift,
+                       const void* residual, void* y, ft_stream_t stream);
+
 /* ---- whole-bottleneck fusion (fp16) --------------------------------------------------------------
  * One launch for an identity-shortcut Bottleneck (reference: Bottleneck.forward, lib/pose/models/blocks.py:105-120,
  * the blocks whose `downsample` is empty, resnet.py:29-36):

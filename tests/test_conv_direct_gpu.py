@@ -1,0 +1,101 @@
+"""ft_conv_direct_fwd (1x1 convs of the deep stages as a weight-streaming GEMM, weights straight to registers) vs the CPU
+oracle for the stock layers (torch CPU fp32 functional = the reference's own arithmetic, blocks.py:89-103) and vs
+ft_conv2d_fwd on the same packed weights."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from flowtrack.pytorch_amd import hip_ops, synth
+from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv, FusedShortcutConv
+from util import make_program, nchw_to_view, run_program, view_to_nchw
+
+pytestmark = pytest.mark.gpu
+
+# name, N, H, W, Cin, Cout, residual, ksplit the library should pick
+CASES = [
+    ("l4_conv3_res", 64, 8, 6, 512, 2048, True, 1),          # layer4.x.conv3 + identity residual: 32 x 8 workgroups
+    ("l4_conv1", 64, 8, 6, 2048, 512, False, 4),             # layer4.x.conv1: N-tile 64, K split over the waves
+    ("l3_conv1_like", 10, 16, 12, 1024, 256, False, 4),      # few pixels: K-split form
+    ("ragged_pixels", 3, 7, 5, 256, 256, True, 4),           # 105 pixels: a ragged second pixel tile
+    ("ragged_pixels_wide", 5, 9, 7, 320, 512, False, 1),     # K = 5 chunks (not a multiple of the ring), 315 pixels
+    ("many_tiles", 64, 16, 12, 256, 1024, True, 1),          # 128 x 4 workgroups: two rounds on 256 CUs
+]
+
+
+def _bn(seed, name, c):
+    return {"weight": synth.uniform(seed, name + "g", (c,), 0.5, 1.5), "bias": synth.normal(seed, name + "b", (c,), 0.1),
+            "running_mean": synth.normal(seed, name + "m", (c,), 0.1), "running_var": synth.uniform(seed, name + "v", (c,), 0.5, 1.5),
+            "eps": 1e-5}
+
+
+def _bnf(y, bn):
+    return F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], training=False, eps=1e-5)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_direct_conv1x1_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
+    name, N, H, W, Cin, Cout, with_res, ksplit = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 31
+    w = synth.normal(seed, name + ".w", (Cout, Cin, 1, 1), std=(2.0 / Cin) ** 0.5)
+    bn = _bn(seed, name + ".bn", Cout)
+    x = synth.normal(seed, name + ".x", (N, Cin, H, W)).half().float()
+    r = synth.normal(seed, name + ".r", (N, Cout, H, W)).half().float()
+    want = _bnf(F.conv2d(x, w), bn)
+    want = F.relu(want + r) if with_res else F.relu(want)
+    conv = FusedConv(w, bn=bn, act="relu", dtype=dtype, device=dev, label=name)
+    xv = nchw_to_view(x, dtype, dev, cstride=Cin + 32, coff=32)
+    rv = nchw_to_view(r, dtype, dev) if with_res else None
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT_MAX_PIXELS", 1 << 20)
+        y = ActView(torch.full((N, H, W, Cout + 64), 3.0, dtype=dtype, device=dev), Cout, 64)
+        prog = make_program()
+        conv.record(prog, xv, y, residual=rv)
+        assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd_ws"), prog.calls[0][0]
+        run_program(prog)
+        outs[mode] = view_to_nchw(y)
+        assert torch.all(y.t[..., :64] == 3.0), "channels outside the output slice were written"
+        if mode:
+            d = prog.conv_records[0][3]
+            assert hip_lib.ft_conv_direct_weight_bytes(d) == (Cout // (256 if ksplit == 1 else 64)) * (Cin // (64 if ksplit == 1 else 256)) * 32768
+            y.t.fill_(5.0)
+            run_program(prog)                      # determinism
+            assert torch.equal(view_to_nchw(y), outs[True])
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[True] - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: direct conv vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    diff = (outs[True] - outs[False]).abs()
+    assert diff.max().item() <= 1e-2 * scale, f"{name}: direct vs igemm max abs diff {diff.max().item():.3e}"
+    assert (diff > 0).float().mean().item() < 0.05, "same fp16 inputs, fp32 accumulation: only the summation order differs"
+
+
+@pytest.mark.parametrize("case", [("l4_entry", 64, 16, 12, 512, 1024, 2048, 2), ("l3_entry_small", 6, 32, 24, 256, 512, 1024, 2),
+                                  ("stride1", 4, 9, 7, 256, 256, 1024, 1)], ids=lambda c: c[0])
+def test_direct_shortcut_conv_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
+    """conv3 + bn3 + projection shortcut (stride-s 1x1 conv + bn on the block input) + relu as one GEMM over K = [t2 | x]."""
+    name, N, Hx, Wx, planes, cin_x, cout, s = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 33
+    H, W = (Hx - 1) // s + 1, (Wx - 1) // s + 1
+    w3 = synth.normal(seed, name + ".w3", (cout, planes, 1, 1), std=(2.0 / planes) ** 0.5)
+    wd = synth.normal(seed, name + ".wd", (cout, cin_x, 1, 1), std=(2.0 / cin_x) ** 0.5)
+    bn3, bnd = _bn(seed, name + ".bn3", cout), _bn(seed, name + ".bnd", cout)
+    t2 = synth.normal(seed, name + ".t2", (N, planes, H, W)).half().float()
+    x = synth.normal(seed, name + ".x", (N, cin_x, Hx, Wx)).half().float()
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + _bnf(F.conv2d(x, wd, stride=s), bnd))
+    fused = FusedShortcutConv(w3, bn3, wd, bnd, s, dtype=dtype, device=dev, act="relu", label=name)
+    t2v, xv = nchw_to_view(t2, dtype, dev), nchw_to_view(x, dtype, dev)
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT_MAX_PIXELS", 1 << 20)
+        y = ActView(torch.zeros((N, H, W, cout), dtype=dtype, device=dev), cout, 0)
+        prog = make_program()
+        fused.record(prog, t2v, xv, y)
+        assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd"), prog.calls[0][0]
+        run_program(prog)
+        outs[mode] = view_to_nchw(y)
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[True] - want).abs().max().item()
+    assert err <= 3e-2 * scale, f"{name}: direct shortcut conv vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    assert (outs[True] - outs[False]).abs().max().item() <= 1e-2 * scale

@@ -80,6 +80,39 @@ def test_correlation_nhwc_fused(hip_lib, oracle_lib, dtype, shape):
     assert torch.all(y[..., :32] == 5.0) and torch.all(y[..., 473:] == 5.0)
 
 
+def test_correlation_impulse_known_answers_gpu(hip_lib):
+    """The hand-derived impulse responses (tests/golden/correlation_kat.npz) through the C ABI: the reference-API kernel on
+    every case, the in-network NHWC kernels (fp32 VALU form and the fp16 matrix-core forms) where their fixed parameters
+    (kernel 1, stride1 1, pad = max_displacement) apply.  A transposed displacement grid or a flipped sign fails here."""
+    import os
+    from conftest import GOLDEN
+    G = np.load(os.path.join(GOLDEN, "correlation_kat.npz"))
+    for n in sorted({k.split(".")[0] for k in G.files}):
+        pad, k, d, s1, s2 = (int(v) for v in G[n + ".params"])
+        a, b, want = G[n + ".in1"], G[n + ".in2"], G[n + ".out"]
+        B, C, H, W = a.shape
+        ga, gb = _cuda(a), _cuda(b)
+        out = torch.full(want.shape, 9.0, dtype=torch.float32, device="cuda")
+        check(hip_lib.ft_correlation_fwd(ga.data_ptr(), gb.data_ptr(), out.data_ptr(), B, C, H, W, pad, k, d, s1, s2, 1, _stream()))
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - want).max() <= 1e-6, n
+        if k == 1 and s1 == 1 and pad == d:
+            D2 = want.shape[1]
+            for dtype, cpad in ((torch.float32, 8), (torch.float16, 8), (torch.float16, 256)):   # 256 channels: the MFMA kernels
+                if cpad == 256 and not (s2 == 2 and d % 2 == 0):
+                    continue
+                fa = torch.zeros((B, H, W, cpad), dtype=dtype, device="cuda")
+                fb = torch.zeros((B, H, W, cpad), dtype=dtype, device="cuda")
+                fa[..., :C] = torch.from_numpy(a).permute(0, 2, 3, 1).to("cuda", dtype)
+                fb[..., :C] = torch.from_numpy(b).permute(0, 2, 3, 1).to("cuda", dtype)
+                y = torch.full((B, H, W, D2 + 7), 5.0, dtype=dtype, device="cuda")
+                check(hip_lib.ft_correlation_nhwc_fwd(fa.data_ptr(), fb.data_ptr(), y.data_ptr(), B, cpad, H, W, d, s2, cpad, D2 + 7, 0,
+                                                      _lib.FT_ACT_NONE, 0.0, _lib.dtype_code(dtype), _stream()))
+                torch.cuda.synchronize()
+                got = y[..., :D2].permute(0, 3, 1, 2).float().cpu().numpy() * (cpad / C)      # nelems = the padded channel count
+                assert np.abs(got - want).max() <= 1e-3, (n, dtype, cpad)
+
+
 def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
     B, C, H, W = 2, 3, 24, 40
     img = synth.normal(5, "img", (B, C, H, W)).numpy()

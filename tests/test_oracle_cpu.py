@@ -116,6 +116,23 @@ def test_correlation_closed_form(oracle_lib):
     assert np.all(out[0, 0, :4, :] == 0)         # displaced outside the frame: zero padding
 
 
+def test_correlation_impulse_known_answers(oracle_lib):
+    """Hand-derived impulse responses (tests/golden/make_correlation_kat.py, from the index arithmetic of
+    correlation_cuda_kernel.cu:34-106): both oracle formulations must put the single product in the channel
+    tc = (tj + r) * D + (ti + r) with tj the ROW displacement, at the right pixel, with the 1 / (k*k*C) scale."""
+    G = np.load(os.path.join(GOLDEN, "correlation_kat.npz"))
+    names = sorted({k.split(".")[0] for k in G.files})
+    assert len(names) >= 5
+    for n in names:
+        pad, k, d, s1, s2 = (int(v) for v in G[n + ".params"])
+        want = G[n + ".out"]
+        for fn in (ops_ref.correlation_c, ops_ref.correlation_np):
+            got = fn(G[n + ".in1"], G[n + ".in2"], pad, k, d, s1, s2)
+            assert got.shape == want.shape and np.abs(got - want).max() <= 1e-6, (n, fn.__name__)
+    w = G["rows_are_tj_cols_are_ti.out"]      # the by-hand numbers themselves: in2 impulse 2 rows below, 2 columns left
+    assert np.argwhere(w != 0).tolist() == [[0, 16, 2, 3]] and w[0, 16, 2, 3] == 2.0
+
+
 def test_resample_channelnorm_two_formulations_agree(oracle_lib):
     img = synth.normal(5, "img", (2, 3, 24, 40)).numpy()
     flow = synth.flow_field(5, 2, 24, 40).numpy()
