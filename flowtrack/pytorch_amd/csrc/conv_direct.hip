@@ -373,6 +373,297 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
 #endif
 }
 
+// ---- 3x3 / stride 1 / pad 1 on whole small maps (layer4's conv2: 8x6 at 256x192, 12x9 at 384x288) -----------------------
+// A workgroup owns `ipw` whole images (<= MT*32 pixels) x 64 output channels.  The input tile (every channel of those images,
+// <= 128 KiB) is loaded into LDS ONCE and serves all nine taps as a row shift (taps that leave the image read a zero row);
+// the four waves split K by channel quarter (wave w: channels [w*C/4, (w+1)*C/4) of every tap), each streaming its own
+// weight fragments straight into registers — no barrier inside the K walk at all.  The four partial accumulators meet in
+// LDS as in the K-split 1x1 form.
+struct C3Params {
+  const char* x;
+  char* y;
+  const char* ws;
+  const float* scale;
+  const float* shift;
+  int M, HW, W, H, ipw;        // pixels, map size, images per workgroup
+  int x_cstride, x_coff, y_cstride, y_coff;
+  int Cout, act;
+  float slope;
+  int npt, ncb;
+  unsigned x_bytes, y_bytes, ws_bytes;
+};
+
+template <int MT, int SPT>     // pixel tiles per workgroup; 4-slice steps per tap per wave (= C / 256)
+__global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = SPT * 256, ROWB = C * 2, BN = 64, NTILE = 2 * MT;
+  constexpr int TROWS = MT * 32;
+  constexpr int ZROW = 131072, TAB = ZROW + ROWB, STG = TAB + 2 * BN * 4, STG_ROWB = BN * 2;
+  constexpr int PART = 4 * NTILE * 4096;
+  constexpr int NSTEP = 9 * SPT;
+  static_assert(TROWS * ROWB <= ZROW && PART <= ZROW && STG + TROWS * STG_ROWB <= 163840 && ZROW % ROWB == 0, "LDS map");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int logical;
+  {
+    const int total = p.npt * p.ncb;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  const int npix = p.ipw * p.HW;                    // pixels of this workgroup's images
+  const int m0 = pt * npix;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- the input tile: row = pixel, all C channels; 1 KiB per wave load = 1024 / ROWB rows; XOR swizzle (low 4 bits of the
+  //      16-byte position ^= row & 15) on the source side
+  constexpr int CPR = ROWB / 16, RPL = 1024 / ROWB > 0 ? 1024 / ROWB : 1;
+  constexpr int LPR = ROWB > 1024 ? ROWB / 1024 : 1;   // wave loads per row (C = 1024: 2)
+  constexpr int NLOAD = TROWS * ROWB / 1024 / 4;       // wave loads per wave
+#pragma unroll
+  for (int t = 0; t < NLOAD; ++t) {
+    const int piece = t * 4 + wave;
+    const int row = ROWB > 1024 ? piece / LPR : piece * RPL + lane / CPR;
+    const int pos = ROWB > 1024 ? (piece % LPR) * 64 + lane : lane % CPR;
+    const int m = m0 + row;
+    const unsigned voff = (row < npix && m < p.M)
+                              ? (unsigned)((m * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)) : kOOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + piece * 1024), 16, voff, 0, 0, 0);
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  uint4_t areg[3][4][2];
+  auto load_a = [&](auto slotc, int st) {            // step st of this wave's stream: 8 contiguous KiB; past the end: zeros
+    constexpr int SL = decltype(slotc)::value;
+    const int base = st < NSTEP ? ((cb * 4 + wave) * NSTEP + st) * 8192 : 0x7fff0000;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, base + (kk * 2 + i) * 1024, 0);
+  };
+  load_a(c0{}, 0);
+  load_a(c1{}, 1);
+  if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
+  if (tid < BN / 4) {
+    const float4_t one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const int ch = cb * BN + tid * 4;
+    reinterpret_cast<float4_t*>(smem + TAB)[tid] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + ch) : one;
+    reinterpret_cast<float4_t*>(smem + TAB + BN * 4)[tid] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + ch) : zero;
+  }
+  // per-lane pixel geometry: 9-bit tap validity of the lane's pixel in each pixel tile
+  int pix[MT], tmask[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int pp = j * 32 + l31;
+    pix[j] = pp;
+    int mk = 0;
+    if (pp < npix) {
+      const int rem = pp % p.HW, yy = rem / p.W, xx = rem - yy * p.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ny = yy + t / 3 - 1, nx = xx + t % 3 - 1;
+        if ((unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
+      }
+    }
+    tmask[j] = mk;
+  }
+  float16_t acc[2][MT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // byte base of the lane's operand row for tap t (slice s inside the wave's channel quarter is one more XOR, s << 5)
+  constexpr int WCH = C / 32;                       // 16-byte positions per wave quarter
+  auto row_bases = [&](int t, int (&rb)[MT]) {
+    const int off = (t / 3 - 1) * p.W + (t % 3 - 1);
+    const int wq = wave * WCH;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = pix[j] + off;
+      const int v = row * ROWB + ((wq & ~15) << 4) + (((((wq & 15) + lhi) ^ row) & 15) << 4);
+      rb[j] = ((tmask[j] >> t) & 1) ? v : ZROW + (lhi << 4);
+    }
+  };
+  uint4_t fb[2][MT];
+  auto ldb = [&](auto setc, int s, const int (&rb)[MT]) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (s << 5)));
+  };
+  auto mma = [&](auto setc, auto slotc, auto kkc) {
+    constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]), __builtin_bit_cast(half8_t, fb[S][j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+  // the tile has landed (this wave's share; the two weight steps may fly), then everyone's
+  asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  int rb[MT], rbn[MT];
+  row_bases(0, rb);
+  ldb(c0{}, 0, rb);
+  cd_unroll<NSTEP>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int tap = st / SPT, s0 = (st % SPT) * 4;       // first slice (inside the quarter) of this step
+    using slot = std::integral_constant<int, st % 3>;
+    load_a(std::integral_constant<int, (st + 2) % 3>{}, st + 2);
+    ldb(c1{}, s0 + 1, rb);
+    mma(c0{}, slot{}, std::integral_constant<int, 0>{});
+    ldb(c0{}, s0 + 2, rb);
+    mma(c1{}, slot{}, std::integral_constant<int, 1>{});
+    ldb(c1{}, s0 + 3, rb);
+    mma(c0{}, slot{}, std::integral_constant<int, 2>{});
+    if constexpr (st + 1 < NSTEP) {
+      constexpr int ntap = (st + 1) / SPT, ns0 = ((st + 1) % SPT) * 4;
+      if constexpr (ntap != tap) {
+        row_bases(ntap, rbn);
+        ldb(c0{}, ns0, rbn);
+      } else {
+        ldb(c0{}, ns0, rb);
+      }
+    }
+    mma(c1{}, slot{}, std::integral_constant<int, 3>{});
+    if constexpr (st + 1 < NSTEP && (st + 1) / SPT != tap) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) rb[j] = rbn[j];
+    }
+  });
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();                                     // every wave is past its last read of the tile: the partials overwrite it
+
+  // ---- K quarters meet in LDS, then the epilogue (as the K-split 1x1 form) ---------------------------------------------------
+  const float* tsc = reinterpret_cast<const float*>(smem + TAB);
+  const float* tsh = tsc + BN;
+  const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
+  char* stg = smem + STG;
+  float4_t* part = reinterpret_cast<float4_t*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4_t v = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+        part[((wave * NTILE + i * MT + j) * 4 + g4) * 64 + lane] = v;
+      }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+#pragma unroll
+  for (int k = 0; k < (NTILE + 3) / 4; ++k) {
+    const int tl = wave + 4 * k;
+    if (tl < NTILE) {
+      const int i = tl / MT, j = tl - i * MT;
+      const int ch = i * 32 + 16 * lhi, row = j * 32 + l31;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tsc + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tsh + ch + g4 * 4);
+      }
+      half8_t o[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float4_t v = part[((0 * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += part[((w * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = v[e] * sc[g4][e] + sh[g4][e];
+          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)__builtin_fmaxf(u, u * act_k);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<half8_t*>(stg + row * STG_ROWB + ((((ch >> 3) + h) ^ (row & 7)) << 4)) = o[h];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  constexpr int NST = TROWS * 8 / 256;
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int idx = tid + 256 * k, row = idx >> 3, ch = idx & 7;
+    const int m = m0 + row;
+    const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + row * STG_ROWB + ((ch ^ (row & 7)) << 4));
+    const unsigned voff = (row < npix && m < p.M && cb * BN + ch * 8 < p.Cout) ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + ch * 8) * 2) : kOOB;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, 0);
+  }
+#endif
+}
+
+// weight stream of the 3x3 form: [channel block][wave][step = tap * SPT + q][kk][i] fragments; K-major source, k = tap * C + ci
+template <int SPT>
+__global__ __launch_bounds__(256) void c3_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int ncb, int kpad, int cout_pad) {
+  constexpr int C = SPT * 256, NSTEP = 9 * SPT;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncb * 4 * NSTEP * 512) return;
+  const int lane = idx & 63;
+  int f = idx >> 6;
+  const int i = f & 1; f >>= 1;
+  const int kk = f & 3; f >>= 2;
+  const int st = f % NSTEP; f /= NSTEP;
+  const int wv = f & 3, cb = f >> 2;
+  const int tap = st / SPT, s = (st % SPT) * 4 + kk;          // slice inside the wave's channel quarter
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int co = cb * 64 + i * 32 + cd_sigma(l31);
+  const int k = tap * C + wv * (C / 4) + s * 16 + 8 * lhi;
+  uint4_t v = {0u, 0u, 0u, 0u};
+  if (co < cout_pad && k < kpad) v = *reinterpret_cast<const uint4_t*>(w + (size_t)co * kpad + k);
+  out[idx] = v;
+}
+
+struct C3Plan {
+  int mt, spt, ipw, npt, ncb;
+};
+
+static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
+  if (!d) return FT_ERR_INVALID_ARG;
+  if (d->dtype != FT_F16 || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return FT_ERR_UNSUPPORTED;
+  if (d->tail_cout || d->pool || d->x_wpitch || d->x2_cin || d->has_residual || d->out_layout != FT_LAYOUT_NHWC) return FT_ERR_UNSUPPORTED;
+  if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
+  if (d->x_coff % 8 || d->x_cstride % 8 || d->y_coff % 8 || d->y_cstride % 8 || d->Cout % 64) return FT_ERR_UNSUPPORTED;
+  if (d->Cin != 512) return FT_ERR_UNSUPPORTED;                  // (instantiated for the 512-plane stage)
+  if (d->x_cstride < d->x_coff + d->Cin || d->y_cstride < d->y_coff + d->Cout) return FT_ERR_INVALID_ARG;
+  const int hw = d->Hi * d->Wi;
+  if (hw > 128) return FT_ERR_UNSUPPORTED;
+  const long long M = (long long)d->N * hw;
+  if (M * d->x_cstride * 2 >= (1LL << 31) || M * d->y_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
+  const int ipw = hw <= 96 ? 96 / hw : 1;
+  const int mt = ipw * hw <= 96 ? 3 : 4;
+  *out = C3Plan{mt, d->Cin / 256, ipw, (d->N + ipw - 1) / ipw, d->Cout / 64};
+  return FT_OK;
+}
+
+template <int MT, int SPT>
+static int c3_launch(const C3Params& p, hipStream_t s) {
+  auto k = conv3x3_direct_kernel<MT, SPT>;
+  constexpr int lds = 131072 + SPT * 512 + 2 * 64 * 4 + MT * 32 * 128;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  FT_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(k, dim3(p.npt * p.ncb), dim3(256), lds, s, p);
+  FT_LAUNCH_CHECK("conv3x3_direct_kernel");
+  return FT_OK;
+}
+
 // ---- weight stream: [channel block][chunk][wave][kk][i] fragments of 1 KiB -----------------------------------------------
 // from the K-major packed layout of ft_conv_pack_geometry ([Cout_pad][kpad], k over x's channels then x2's).
 template <int KSPLIT>
@@ -477,17 +768,35 @@ static int cd_dispatch(const CdParams& p, hipStream_t s) {
 
 extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
   ft::CdPlan pl;
+  ft::C3Plan p3;
+  if (d && d->kh == 3) return ft::c3_plan(d, &p3);
   return ft::cd_plan(d, &pl);
 }
 
 extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
   ft::CdPlan pl;
+  if (d && d->kh == 3) {
+    ft::C3Plan p3;
+    if (ft::c3_plan(d, &p3) != FT_OK) return 0;
+    return (long long)p3.ncb * 4 * 9 * p3.spt * 8192;
+  }
   if (ft::cd_plan(d, &pl) != FT_OK) return 0;
   return (long long)pl.ncb * (pl.nc1 + pl.nc2) * 32768;
 }
 
 extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, int kpad, int cout_pad, void* wstream, ft_stream_t stream) {
   using namespace ft;
+  if (d && d->kh == 3) {
+    C3Plan p3;
+    const int st3 = c3_plan(d, &p3);
+    if (st3 != FT_OK) return st3;
+    if (!w_packed || !wstream || kpad < 9 * d->Cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
+    const int total = p3.ncb * 4 * 9 * p3.spt * 512;
+    hipLaunchKernelGGL(c3_pack_kernel<2>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const half_t*>(w_packed),
+                       static_cast<uint4_t*>(wstream), p3.ncb, kpad, cout_pad);
+    FT_LAUNCH_CHECK("c3_pack_kernel");
+    return FT_OK;
+  }
   CdPlan pl;
   const int st = cd_plan(d, &pl);
   if (st != FT_OK) return st;
@@ -508,6 +817,27 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
 extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const void* wstream, const float* scale, const float* shift,
                                   const void* residual, void* y, ft_stream_t stream) {
   using namespace ft;
+  if (d && d->kh == 3) {
+    C3Plan p3;
+    const int st3 = c3_plan(d, &p3);
+    if (st3 != FT_OK) return st3;
+    if (!x || !wstream || !y) return FT_ERR_INVALID_ARG;
+    C3Params q{};
+    q.x = static_cast<const char*>(x);
+    q.y = static_cast<char*>(y);
+    q.ws = static_cast<const char*>(wstream);
+    q.scale = scale;
+    q.shift = shift;
+    q.HW = d->Hi * d->Wi; q.W = d->Wi; q.H = d->Hi; q.ipw = p3.ipw;
+    q.M = d->N * q.HW;
+    q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.y_cstride = d->y_cstride; q.y_coff = d->y_coff;
+    q.Cout = d->Cout; q.act = d->act; q.slope = d->slope;
+    q.npt = p3.npt; q.ncb = p3.ncb;
+    q.x_bytes = (unsigned)((size_t)q.M * d->x_cstride * 2);
+    q.y_bytes = (unsigned)((size_t)q.M * d->y_cstride * 2);
+    q.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+    return p3.mt == 3 ? c3_launch<3, 2>(q, as_stream(stream)) : c3_launch<4, 2>(q, as_stream(stream));
+  }
   CdPlan pl;
   const int st = cd_plan(d, &pl);
   if (st != FT_OK) return st;

@@ -598,7 +598,7 @@ class FusedConv:
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
-        ws = _direct_stream(self, d, w, x.t.device) if (self.k == 1 and isinstance(y, ActView) and not self.tail_cout and not pool) else None
+        ws = _direct_stream(self, d, w, x.t.device) if (self.k in (1, 3) and isinstance(y, ActView) and not self.tail_cout and not pool) else None
         if ws is not None:
             prog.add("ft_conv_direct_fwd", ctypes.byref(d), x.t.data_ptr(), ws.data_ptr(),
                      scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, res_ptr,

@@ -99,3 +99,34 @@ def test_direct_shortcut_conv_matches_oracle_and_igemm(hip_lib, case, monkeypatc
     err = (outs[True] - want).abs().max().item()
     assert err <= 3e-2 * scale, f"{name}: direct shortcut conv vs oracle max abs err {err:.3e} (scale {scale:.2f})"
     assert (outs[True] - outs[False]).abs().max().item() <= 1e-2 * scale
+
+
+@pytest.mark.parametrize("case", [("l4_conv2_8x6", 64, 8, 6), ("odd_batch", 5, 8, 6), ("r101_12x9", 7, 12, 9), ("tiny_3x5", 3, 3, 5)],
+                         ids=lambda c: c[0])
+def test_direct_conv3x3_whole_maps_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
+    """layer4's conv2 (3x3 / stride 1 / pad 1, 512 -> 512) on whole small maps: input tile resident in LDS, taps as row
+    shifts (zero row outside the image), waves split K, weights straight to registers."""
+    name, N, H, W = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 35
+    C = 512
+    w = synth.normal(seed, name + ".w", (C, C, 3, 3), std=(2.0 / (9 * C)) ** 0.5)
+    bn = _bn(seed, name + ".bn", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    want = F.relu(_bnf(F.conv2d(x, w, padding=1), bn))
+    conv = FusedConv(w, pad=1, bn=bn, act="relu", dtype=dtype, device=dev, label=name)
+    xv = nchw_to_view(x, dtype, dev)
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
+        prog = make_program()
+        conv.record(prog, xv, y)
+        assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd_ws"), prog.calls[0][0]
+        run_program(prog)
+        outs[mode] = view_to_nchw(y)
+        assert torch.all(y.t[..., :32] == 3.0)
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[True] - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: direct 3x3 vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    diff = (outs[True] - outs[False]).abs()
+    assert diff.max().item() <= 1e-2 * scale and (diff > 0).float().mean().item() < 0.05
