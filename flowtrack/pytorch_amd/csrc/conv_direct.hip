@@ -717,9 +717,11 @@ static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
   const bool a_ok = d->Cout % 256 == 0 && d->Cin % 64 == 0 && d->x2_cin % 64 == 0;
   const bool b_ok = d->Cin % 256 == 0 && d->x2_cin % 256 == 0;
   if (!a_ok && !b_ok) return FT_ERR_UNSUPPORTED;
-  // N-tile 256 unless that leaves most CUs idle and the 64-wide, K-split form is available
+  // N-tile 256 unless that leaves most CUs idle and the 64-wide, K-split form is available.  Only for narrow layers: with many
+  // output-channel blocks every one of them re-reads the whole pixel tile (measured at 1728 pixels, 512 -> 2048: 26 us K-split
+  // vs 18 us in conv_igemm_dma_kernel)
   int ks = a_ok ? 1 : 4;
-  if (a_ok && b_ok && (long long)npt * (d->Cout / 256) < 160) ks = 4;
+  if (a_ok && b_ok && (long long)npt * (d->Cout / 256) < 160 && d->Cout <= 512) ks = 4;
   if (force == 1 && a_ok) ks = 1;
   if (force == 4 && b_ok) ks = 4;
   const int ck = ks == 1 ? 64 : 256;
@@ -748,7 +750,9 @@ static int cd_dispatch(const CdParams& p, hipStream_t s) {
   static const bool no_unroll = getenv("FT_CD_NO_UNROLL") != nullptr;     // dev A/B: the run-time-loop form
   const int n = no_unroll ? 0 : p.nc1 + p.nc2;
   if (KSPLIT == 1) {
-    switch (n) {     // K = 512 / 768 / 1024 / 1536 (ResNet layer3 / layer4 1x1 convs and their K-concatenated block exits)
+    switch (n) {     // K = 256 / 384 / 512 / 768 / 1024 / 1536 (ResNet layer2-4 1x1 convs and their K-concatenated block exits)
+      case 4: return cd_launch<KSPLIT, HAS_RES, 4>(p, s);
+      case 6: return cd_launch<KSPLIT, HAS_RES, 6>(p, s);
       case 8: return cd_launch<KSPLIT, HAS_RES, 8>(p, s);
       case 12: return cd_launch<KSPLIT, HAS_RES, 12>(p, s);
       case 16: return cd_launch<KSPLIT, HAS_RES, 16>(p, s);

@@ -89,9 +89,13 @@ class HipModule(nn.Module):
                 prog.run_eager()          # surfaces argument errors before any capture
                 if hip_ops.benchmark:     # cudnn.benchmark counterpart: pick each conv's tile variant in situ (every
                     prog.stream.synchronize()   # pass is a complete, valid forward: the outputs stay those of this input)
-                    prog.tune_tiles(verbose=bool(os.environ.get("FT_CONV_BENCHMARK_VERBOSE")))
+                    verbose = bool(os.environ.get("FT_CONV_BENCHMARK_VERBOSE"))
+                    prog.tune_tiles(verbose=verbose)
+                    prog.tune_choices(verbose=verbose)   # fused / unfused blocks, direct / implicit-GEMM 1x1s: keep the faster
                     prog.run_eager()      # outputs of this call come from the chosen variants (split-K variants sum in
                                           # another order: the first call must be bit-identical to the replays)
+                else:
+                    prog.resolve_choices()    # no benchmark: the recorder's first option of every alternative
                 if self.use_graph:
                     prog.stream.synchronize()
                     prog.capture()

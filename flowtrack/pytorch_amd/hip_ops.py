@@ -117,6 +117,7 @@ class Program:
         # branch of the captured graph): two small independent launches share the GPU instead of queueing
         self._side = False
         self._side_stream: Optional[torch.cuda.Stream] = None
+        self._choice_flops: list = []     # begin_choice() stack: [flops before the group, flops of its first option]
         self._events: list = []
 
     @property
@@ -137,6 +138,142 @@ class Program:
     def join(self) -> None:
         self.calls.append(("__join__", ()))
         self.lanes.append(0)
+
+    # -- alternatives -------------------------------------------------------------------------------------------------
+    # begin_choice(key) / option() ... / option() ... / end_choice(): the same piece of the network recorded in more than
+    # one form (one fused launch or three conv launches; ft_conv_direct_fwd or ft_conv2d_fwd).  Every option writes the
+    # same outputs from the same inputs, so until the choice is resolved ALL of them run, in recording order, and the
+    # result is valid.  tune_choices() times them in situ and keeps the fastest, resolve_choices() keeps the first one
+    # (the recorder's heuristic); both delete the other launches, so a captured plan never holds a choice.  Groups nest.
+    def begin_choice(self, key: str) -> None:
+        self.calls.append(("__choice__", (key,)))
+        self.lanes.append(0)
+        self._choice_flops.append([self.flops, None])
+
+    def option(self) -> None:
+        base = self._choice_flops[-1]
+        if base[1] is None and self.calls[-1][0] != "__choice__":
+            base[1] = self.flops - base[0]          # flops of the first option: all options are the same arithmetic
+        self.flops = base[0]
+        self.calls.append(("__option__", ()))
+        self.lanes.append(0)
+
+    def end_choice(self) -> None:
+        base = self._choice_flops.pop()
+        if base[1] is not None:
+            self.flops = base[0] + base[1]
+        self.calls.append(("__endchoice__", ()))
+        self.lanes.append(0)
+
+    def _innermost_choices(self) -> list:
+        """Unresolved choice groups that contain no other group: dicts {key, marks: [option starts..., end]}."""
+        stack, out = [], []
+        for i, (name, args) in enumerate(self.calls):
+            if name == "__choice__":
+                if stack:
+                    stack[-1]["nested"] = True
+                stack.append({"key": args[0], "start": i, "marks": [], "nested": False})
+            elif name == "__option__":
+                stack[-1]["marks"].append(i)
+            elif name == "__endchoice__":
+                g = stack.pop()
+                g["marks"].append(i)
+                if not g["nested"]:
+                    out.append(g)
+        if stack:
+            raise FlowtrackHipError("begin_choice without end_choice")
+        return out
+
+    def _keep_options(self, groups: list, picks: list) -> None:
+        """Delete the markers of `groups` and every option but picks[k]; re-index the per-launch records."""
+        drop = [False] * len(self.calls)
+        for g, pick in zip(groups, picks):
+            drop[g["start"]] = True
+            marks = g["marks"]
+            for j in range(len(marks) - 1):
+                for i in range(marks[j], marks[j + 1]):
+                    drop[i] = drop[i] or j != pick or i == marks[j]
+            drop[marks[-1]] = True
+        new_index, n = {}, 0
+        for i, d in enumerate(drop):
+            if not d:
+                new_index[i] = n
+                n += 1
+        self.calls = [c for c, d in zip(self.calls, drop) if not d]
+        self.lanes = [l for l, d in zip(self.lanes, drop) if not d]
+        self.conv_records = [(r[0], new_index[r[1]]) + tuple(r[2:]) for r in self.conv_records if r[1] in new_index]
+        self.fused_records = [(r[0], new_index[r[1]]) + tuple(r[2:]) for r in self.fused_records if r[1] in new_index]
+
+    def resolve_choices(self) -> None:
+        """Keep the benchmarked pick of every choice where the cache holds one, otherwise its first option."""
+        if self.graph_exec is not None:
+            return
+        _load_tile_cache()
+        while True:
+            groups = self._innermost_choices()
+            if not groups:
+                return
+            self._keep_options(groups, [min(int(_TILE_CACHE.get("choice|" + g["key"], 0)), len(g["marks"]) - 2) for g in groups])
+
+    def tune_choices(self, reps: int = 3, verbose: bool = False) -> int:
+        """In-situ benchmark of the recorded alternatives, innermost groups first: the whole launch list runs with hipEvents
+        at the boundaries of each option; per key (all instances of one layer shape share a pick, as the tile variants
+        do) the fastest option wins if it beats the recorder's first choice by 3 %.  Returns #groups that changed."""
+        if self.graph_exec is not None:
+            raise FlowtrackHipError("tune_choices must run before the plan is captured into a graph")
+        self._ensure_workspace()
+        _load_tile_cache()
+        lib, sh = self.lib, self.stream_handle
+        changed = 0
+        while True:
+            groups = self._innermost_choices()
+            if not groups:
+                break
+            todo = [g for g in groups if "choice|" + g["key"] not in _TILE_CACHE]
+            if todo:
+                marks = {}
+                for g in todo:
+                    g["ev"] = []
+                    for i in g["marks"]:
+                        e = ctypes.c_void_p()
+                        check(lib.ft_event_create(ctypes.byref(e)), "ft_event_create")
+                        g["ev"].append(e)
+                        marks[i] = e
+                    g["ms"] = [float("inf")] * (len(g["marks"]) - 1)
+                for _ in range(reps):
+                    with torch.cuda.stream(self.stream):
+                        torch.cuda._sleep(4_000_000)
+                    for i, (name, args) in enumerate(self.calls):
+                        if name.startswith("__"):
+                            if i in marks:
+                                check(lib.ft_event_record(marks[i], sh))
+                            continue
+                        check(getattr(lib, name)(*args, sh), name)
+                    check(lib.ft_stream_synchronize(sh), "ft_stream_synchronize")
+                    for g in todo:
+                        for j in range(len(g["ms"])):
+                            ms = ctypes.c_float()
+                            check(lib.ft_event_elapsed_ms(g["ev"][j], g["ev"][j + 1], ctypes.byref(ms)))
+                            g["ms"][j] = min(g["ms"][j], ms.value)
+                total = {}
+                for g in todo:
+                    tot = total.setdefault(g["key"], [0.0] * len(g["ms"]))
+                    for j, v in enumerate(g["ms"]):
+                        tot[j] += v
+                    for e in g["ev"]:
+                        lib.ft_event_destroy(e)
+                for key, tot in total.items():
+                    best = min(range(len(tot)), key=lambda j: tot[j])
+                    if tot[best] > 0.97 * tot[0]:
+                        best = 0
+                    _TILE_CACHE["choice|" + key] = best
+                    changed += best != 0
+                    if verbose:
+                        print(f"[choice benchmark] {key:60s} " + "  ".join(f"{v * 1e3:7.1f} us" for v in tot) + f"  -> option {best}",
+                              file=sys.stderr)
+            self._keep_options(groups, [min(int(_TILE_CACHE.get("choice|" + g["key"], 0)), len(g["marks"]) - 2) for g in groups])
+        _save_tile_cache()
+        return changed
 
     def side(self):
         prog = self
@@ -193,13 +330,14 @@ class Program:
                     ev = self._event(nev); nev += 1
                     check(lib.ft_event_record(ev, side))
                     check(lib.ft_stream_wait_event(sh, ev))
-            else:
+            elif not name.startswith("__"):     # (an unresolved choice runs all of its options: same outputs)
                 check(getattr(lib, name)(*args, side if (lane and side is not None) else sh), name)
 
     def capture(self) -> None:
         """Record the launch sequence into a HIP graph (hipStreamBeginCapture on our side stream)."""
         if self.graph_exec is not None:
             return
+        self.resolve_choices()
         sh = self.stream_handle
         check(self.lib.ft_graph_begin_capture(sh), "ft_graph_begin_capture")
         try:
@@ -296,7 +434,7 @@ class Program:
         if not convs:
             return 0
         _load_tile_cache()
-        keys = [_desc_key(d) for _, d in convs]
+        keys = [("direct|" if self.calls[i][0] == "ft_conv_direct_fwd" else "") + _desc_key(d) for i, d in convs]
         if all(k in _TILE_CACHE for k in keys):          # every layer already benchmarked (this process or the file)
             for (_, d), k in zip(convs, keys):
                 d.tile_hint = _TILE_CACHE[k]
@@ -596,14 +734,25 @@ class FusedConv:
             res_ptr = self._tail.data_ptr()
         w, _, scale, shift = self._packed_for(d)
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
-        prog.flops += flops
-        prog.conv_records.append((self.label, len(prog.calls), flops, d))
         ws = _direct_stream(self, d, w, x.t.device) if (self.k in (1, 3) and isinstance(y, ActView) and not self.tail_cout and not pool) else None
         if ws is not None:
-            prog.add("ft_conv_direct_fwd", ctypes.byref(d), x.t.data_ptr(), ws.data_ptr(),
+            # two forms of the same launch; the in-situ benchmark (Program.tune_choices) keeps the faster one
+            dd = ConvDesc.from_buffer_copy(d)
+            prog.begin_choice("conv|" + _desc_key(d))
+            prog.option()
+            prog.flops += flops
+            prog.conv_records.append((self.label, len(prog.calls), flops, dd))
+            prog.add("ft_conv_direct_fwd", ctypes.byref(dd), x.t.data_ptr(), ws.data_ptr(),
                      scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, res_ptr,
-                     yt.data_ptr(), keep=(d, x.t, yt, ws, scale, shift, residual.t if residual is not None else None))
-            return
+                     yt.data_ptr(), keep=(dd, x.t, yt, ws, scale, shift, residual.t if residual is not None else None))
+            prog.option()
+        self._record_igemm(prog, d, x, w, scale, shift, res_ptr, yt, residual, flops)
+        if ws is not None:
+            prog.end_choice()
+
+    def _record_igemm(self, prog: Program, d: ConvDesc, x: ActView, w, scale, shift, res_ptr, yt, residual, flops: float) -> None:
+        prog.flops += flops
+        prog.conv_records.append((self.label, len(prog.calls), flops, d))
         if prog._side:     # side-branch launches may overlap main-branch ones: they must not share the plan's workspace
             prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
                      scale.data_ptr() if scale is not None else None,
@@ -618,9 +767,11 @@ class FusedConv:
 
 
 #: 1x1 layers with few pixels and a long K run on ft_conv_direct_fwd (weights straight to registers); FT_CONV_DIRECT=0 keeps
-#: them on ft_conv2d_fwd, FT_CONV_DIRECT_MAX_PIXELS moves the pixel bound (default 16384: ResNet layer3 / layer4 at batch 64)
+#: them on ft_conv2d_fwd, FT_CONV_DIRECT_MAX_PIXELS moves the pixel bound (default 65536: ResNet layer2.0's block exit, layer3
+#: and layer4 at batch 64; measured same-box on R50: layer3.0.conv1 34 -> 26 us, layer2.0.conv3+downsample 44 -> 36 us, but
+#: layer2.0.conv1 at 196608 pixels 50 -> 95 us)
 CONV_DIRECT = os.environ.get("FT_CONV_DIRECT", "1") != "0"
-CONV_DIRECT_MAX_PIXELS = int(os.environ.get("FT_CONV_DIRECT_MAX_PIXELS", "16384"))
+CONV_DIRECT_MAX_PIXELS = int(os.environ.get("FT_CONV_DIRECT_MAX_PIXELS", "65536"))
 
 
 def _direct_stream(owner, d: ConvDesc, w: torch.Tensor, device) -> Optional[torch.Tensor]:
@@ -697,15 +848,22 @@ class FusedShortcutConv:
         d.x2_cin, d.x2_hi, d.x2_wi, d.x2_cstride, d.x2_coff, d.x2_stride = self.cin2, x.H, x.W, x.cstride, x.coff, self.stride_d
         w, shift = self._packed_for(d)
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
-        prog.flops += flops
-        prog.conv_records.append((self.label, len(prog.calls), flops, d))
         ws = _direct_stream(self, d, w, t2.t.device)
         if ws is not None:
-            prog.add("ft_conv_direct_fwd", ctypes.byref(d), t2.t.data_ptr(), ws.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
-                     y.t.data_ptr(), keep=(d, t2.t, x.t, y.t, ws, shift))
-            return
+            dd = ConvDesc.from_buffer_copy(d)
+            prog.begin_choice("conv|" + _desc_key(d))
+            prog.option()
+            prog.flops += flops
+            prog.conv_records.append((self.label, len(prog.calls), flops, dd))
+            prog.add("ft_conv_direct_fwd", ctypes.byref(dd), t2.t.data_ptr(), ws.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
+                     y.t.data_ptr(), keep=(dd, t2.t, x.t, y.t, ws, shift))
+            prog.option()
+        prog.flops += flops
+        prog.conv_records.append((self.label, len(prog.calls), flops, d))
         prog.add("ft_conv2d_fwd", ctypes.byref(d), t2.t.data_ptr(), w.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
                  y.t.data_ptr(), keep=(d, t2.t, x.t, y.t, w, shift))
+        if ws is not None:
+            prog.end_choice()
 
 
 def bottleneck_fusable(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView) -> bool:
@@ -727,6 +885,14 @@ def bottleneck_fusable(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: Act
 #: the streamed-weights fused bottleneck (ft_bottleneck_stream_fwd) for the 128- / 256-plane stages; FT_FUSE_BOTTLENECK_STREAM=0
 #: keeps their three conv launches
 FUSE_BOTTLENECK_STREAM = os.environ.get("FT_FUSE_BOTTLENECK_STREAM", "1") != "0"
+
+
+def bottleneck_prefers_fused(x: ActView, planes: int) -> bool:
+    """The recorder's first choice for a fusable identity block (what runs when the first-call benchmark is off): the
+    64-plane kernel always; the streamed-weights kernels only with enough pixels to spread their per-workgroup weight
+    stream over (measured: 256 planes at 3072 px 50 us fused vs 27 us as three launches, at 12288 px 53 vs 82 us)."""
+    px = x.N * x.H * x.W
+    return planes == 64 or (planes == 128 and px >= 16384) or (planes == 256 and px >= 8192)
 
 
 def _bottleneck_desc(x: ActView, y: ActView, planes: int, head_only: bool = False) -> _lib.BottleneckDesc:

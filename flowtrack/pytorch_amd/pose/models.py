@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ..engine import HipModule
 from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable,
-                       bottleneck_head_fusable, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_head,
+                       bottleneck_head_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_head,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -164,8 +164,25 @@ class DeconvResnet(HipModule):
                 c3 = self.fused(name + ".conv3", blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", **mk)
                 out = new_act(B, Ho, Wo, planes * 4, dtype, device)
                 if self.fuse_bottleneck and not len(blk.downsample) and s == 1 and bottleneck_fusable(c1, c2, c3, cur, out):
-                    # the whole block in one launch: t1 / t2 never leave LDS (HBM-bound 256-wide stage)
-                    record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
+                    # the whole block in one launch (t1 / t2 never leave LDS) or as three conv launches: which one is faster
+                    # depends on how many workgroups the stage's pixels make (each streams the block's whole weight set),
+                    # so both are recorded and the first-call benchmark keeps one (Program.tune_choices)
+                    t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
+                    t2 = new_act(B, Ho, Wo, planes, dtype, device)
+
+                    def fused_form():
+                        record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
+
+                    def conv_form():
+                        c1.record(prog, cur, t1)
+                        c2.record(prog, t1, t2)
+                        c3.record(prog, t2, out, residual=cur)
+                    forms = (fused_form, conv_form) if bottleneck_prefers_fused(cur, planes) else (conv_form, fused_form)
+                    prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
+                    for form in forms:
+                        prog.option()
+                        form()
+                    prog.end_choice()
                     cur = out
                     continue
                 t2 = new_act(B, Ho, Wo, planes, dtype, device)

@@ -48,10 +48,12 @@ def test_direct_conv1x1_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
     outs = {}
     for mode in (True, False):
         monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
         monkeypatch.setattr(hip_ops, "CONV_DIRECT_MAX_PIXELS", 1 << 20)
         y = ActView(torch.full((N, H, W, Cout + 64), 3.0, dtype=dtype, device=dev), Cout, 64)
         prog = make_program()
         conv.record(prog, xv, y, residual=rv)
+        prog.resolve_choices()      # recorded as [direct | implicit GEMM]: keep the first form
         assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd_ws"), prog.calls[0][0]
         run_program(prog)
         outs[mode] = view_to_nchw(y)
@@ -88,10 +90,12 @@ def test_direct_shortcut_conv_matches_oracle_and_igemm(hip_lib, case, monkeypatc
     outs = {}
     for mode in (True, False):
         monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
         monkeypatch.setattr(hip_ops, "CONV_DIRECT_MAX_PIXELS", 1 << 20)
         y = ActView(torch.zeros((N, H, W, cout), dtype=dtype, device=dev), cout, 0)
         prog = make_program()
         fused.record(prog, t2v, xv, y)
+        prog.resolve_choices()      # recorded as [direct | implicit GEMM]: keep the first form
         assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd"), prog.calls[0][0]
         run_program(prog)
         outs[mode] = view_to_nchw(y)
@@ -118,9 +122,11 @@ def test_direct_conv3x3_whole_maps_matches_oracle_and_igemm(hip_lib, case, monke
     outs = {}
     for mode in (True, False):
         monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
         y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
         prog = make_program()
         conv.record(prog, xv, y)
+        prog.resolve_choices()      # recorded as [direct | implicit GEMM]: keep the first form
         assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd_ws"), prog.calls[0][0]
         run_program(prog)
         outs[mode] = view_to_nchw(y)

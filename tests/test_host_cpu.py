@@ -270,3 +270,58 @@ def test_flip_test_pairs_follow_the_dataset():
     assert torch.equal(back, torch.flip(hm, dims=[3])[:, perm])
     with pytest.raises(ValueError):
         pose_main._flip_back(hm[:, :14], pose_main.get_flip_pairs("mpii"))
+
+
+def test_program_choice_groups_bookkeeping(hip_lib, monkeypatch):
+    """Program.begin_choice / option / end_choice: every option is recorded, resolve keeps one (the first, or the cached
+    benchmark pick), nested groups resolve inside-out, flops count once and the per-launch records are re-indexed."""
+    from flowtrack.pytorch_amd import hip_ops
+    monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
+    monkeypatch.setattr(hip_ops, "_TILE_CACHE_LOADED", True)
+
+    def build():
+        prog = hip_ops.Program(None)
+        prog.add("a")
+        prog.flops += 1.0
+        prog.begin_choice("blk")
+        prog.option()                                   # option 0: one fused launch
+        prog.flops += 10.0
+        prog.fused_records.append(("blk.fused", len(prog.calls), 10.0))
+        prog.add("fused")
+        prog.option()                                   # option 1: three launches, the middle one itself a choice
+        prog.flops += 3.0
+        prog.conv_records.append(("c1", len(prog.calls), 3.0, None))
+        prog.add("c1")
+        prog.begin_choice("c2")
+        prog.option()
+        prog.flops += 4.0
+        prog.conv_records.append(("c2.direct", len(prog.calls), 4.0, None))
+        prog.add("c2_direct")
+        prog.option()
+        prog.flops += 4.0
+        prog.conv_records.append(("c2.igemm", len(prog.calls), 4.0, None))
+        prog.add("c2_igemm")
+        prog.end_choice()
+        prog.flops += 3.0
+        prog.conv_records.append(("c3", len(prog.calls), 3.0, None))
+        prog.add("c3")
+        prog.end_choice()
+        prog.add("z")
+        return prog
+
+    prog = build()
+    assert prog.flops == 11.0                           # 1 + the block once
+    prog.resolve_choices()
+    assert [c[0] for c in prog.calls] == ["a", "fused", "z"] and prog.lanes == [0, 0, 0]
+    assert prog.fused_records == [("blk.fused", 1, 10.0)] and prog.conv_records == []
+
+    hip_ops._TILE_CACHE.update({"choice|blk": 1, "choice|c2": 1})
+    prog = build()
+    prog.resolve_choices()
+    assert [c[0] for c in prog.calls] == ["a", "c1", "c2_igemm", "c3", "z"]
+    assert [(r[0], r[1]) for r in prog.conv_records] == [("c1", 1), ("c2.igemm", 2), ("c3", 3)] and prog.fused_records == []
+
+    hip_ops._TILE_CACHE.update({"choice|c2": 0})
+    prog = build()
+    prog.resolve_choices()
+    assert [c[0] for c in prog.calls] == ["a", "c1", "c2_direct", "c3", "z"]

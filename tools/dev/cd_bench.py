@@ -22,6 +22,7 @@ for mode in (True, False):
     prog = Program(torch.cuda.Stream())
     for _ in range(8):
         conv.record(prog, x, y, residual=r)
+        prog.resolve_choices()
     torch.cuda.synchronize()
     prog.run_eager(); prog.stream.synchronize()
     t = prog.time_calls(iters=10)
@@ -30,6 +31,7 @@ for mode in (True, False):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     prog1 = Program(torch.cuda.Stream())
     conv.record(prog1, x, y, residual=r)
+    prog1.resolve_choices()
     cold = []
     with torch.cuda.stream(prog1.stream):
         for _ in range(6):

@@ -18,6 +18,7 @@ r = ActView(torch.randn((N, H, W, Cout), device=dev).to(dt), Cout, 0) if with_re
 y = ActView(torch.zeros((N, H, W, Cout), dtype=dt, device=dev), Cout, 0)
 prog = Program(torch.cuda.Stream())
 conv.record(prog, x, y, residual=r)
+prog.resolve_choices()
 torch.cuda.synchronize()
 for _ in range(3):
     prog.run_eager(); prog.stream.synchronize()

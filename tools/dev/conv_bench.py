@@ -86,6 +86,7 @@ def main():
             r = new_act(N, Ho, Wo, Cout, dtype, dev); r.t.normal_()
         prog = Program(torch.cuda.Stream())
         layer.record(prog, x, y, residual=r)
+        prog.resolve_choices()
         name_, args = prog.calls[0]
         sh = prog.stream_handle
         fn = getattr(lib, name_)
