@@ -87,7 +87,7 @@ def conv_roofline(prog, dtype_name, iters=5):
         ms = times[call_idx][1]
         per_layer.append((label, fl, ms))
     return {
-        "bound": "mfma", "kernel": "every conv launch of the step (ft_conv2d_fwd / ft_bottleneck_fwd): conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow), fused-bottleneck, generic and few-output variants", "achieved": round(achieved, 2), "peak": peak,
+        "bound": "mfma", "kernel": "every conv launch of the step (ft_conv2d_fwd / ft_conv_direct_fwd / ft_bottleneck_fwd / ft_bottleneck_stream_fwd): conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow) and few-output variants, conv_direct / conv3x3_direct (weights straight to registers), the fused bottleneck kernels (LDS-resident and streamed weights)", "achieved": round(achieved, 2), "peak": peak,
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
         "launches_per_step": n_conv, "flop_per_launch_avg": flops / max(n_conv, 1),
         "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),

@@ -1093,6 +1093,8 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   p.ws_bytes = (unsigned)ft_bottleneck_stream_weight_bytes(d);
   static const int dbg = getenv("FT_BNS_DBG") ? atoi(getenv("FT_BNS_DBG")) : 0;
   p.dbg = dbg;
+  if (dbg & 64) p.ws_bytes = 0;     // dev: every weight load out of range (returns 0, no L2 access): the kernel's time without its weight stream
+  if (dbg & 128) p.x_bytes = 0;     // dev: likewise the input
   hipStream_t s = as_stream(stream);
   switch (pl.variant) {
     case 0: return bns_launch<128, 4, 3>(p, s);

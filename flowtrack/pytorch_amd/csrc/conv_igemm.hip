@@ -654,7 +654,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
   for (int t = 0; t < NIA; ++t) {
     const int r = (wave + NW * t) * RPI + lrow;
     const int lc = pos ^ ((r / SWZ_DIV) % CH);           // source chunk that lands at LDS position `pos`
-    a_voff[t] = (unsigned)(r * p.Kpad * esz + lc * 16);
+    a_voff[t] = (p.dbg & 256) ? kOOB : (unsigned)(r * p.Kpad * esz + lc * 16);   // (dev probe 256: weight-tile loads fetch nothing)
   }
   int b_base[NIB];
   unsigned b_mask[NIB];

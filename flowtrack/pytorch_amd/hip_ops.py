@@ -204,13 +204,16 @@ class Program:
         self.conv_records = [(r[0], new_index[r[1]]) + tuple(r[2:]) for r in self.conv_records if r[1] in new_index]
         self.fused_records = [(r[0], new_index[r[1]]) + tuple(r[2:]) for r in self.fused_records if r[1] in new_index]
 
-    def resolve_choices(self) -> None:
-        """Keep the benchmarked pick of every choice where the cache holds one, otherwise its first option."""
+    def resolve_choices(self, cached_only: bool = False) -> None:
+        """Keep the benchmarked pick of every choice where the cache holds one, otherwise its first option
+        (cached_only: leave the choices without a cached pick in place, for tune_choices)."""
         if self.graph_exec is not None:
             return
         _load_tile_cache()
         while True:
             groups = self._innermost_choices()
+            if cached_only:
+                groups = [g for g in groups if "choice|" + g["key"] in _TILE_CACHE]
             if not groups:
                 return
             self._keep_options(groups, [min(int(_TILE_CACHE.get("choice|" + g["key"], 0)), len(g["marks"]) - 2) for g in groups])
