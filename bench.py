@@ -288,15 +288,13 @@ def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B):
     x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
     kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
     gather = parallel.RowGatherer(B, (17, 3), torch.float32, device) if world > 1 else None
-    rows = torch.empty((B, 17, 3), dtype=torch.float32, device=device)
     state = {"pending": None}
 
     def consume(h):
         kp_host.copy_(gather.finish(h)[rank * B:(rank + 1) * B], non_blocking=True)   # (the consumer: the rank's own rows back on the host)
 
     def step():
-        _, _, score, coords = model.forward_keypoints(x)
-        torch.cat((coords, score), dim=2, out=rows)         # [B,17,3] keypoint rows, no allocation
+        rows = model.forward_keypoint_rows(x)                # [B,17,3] (x, y, score) rows written by the plan's last launch
         if gather is None:
             kp_host.copy_(rows, non_blocking=True)
             return rows

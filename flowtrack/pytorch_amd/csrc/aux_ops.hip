@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
 // ---- max_preds (+ final_preds nudge): one workgroup per (n,k) map ------------------------------
 __global__ __launch_bounds__(256) void heatmap_max_preds_kernel(const float* __restrict__ hm, int H, int W, int adjust,
                                                                 int32_t* __restrict__ idx_out, float* __restrict__ score_out,
-                                                                float* __restrict__ coords_out) {
+                                                                float* __restrict__ coords_out, int sstride, int cstride) {
   const int map = blockIdx.x;
   const int HW = H * W;
   const float* p = hm + (size_t)map * HW;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void heatmap_max_preds_kernel(const float* __r
       if (s_v[w] > best || (s_v[w] == best && s_i[w] < bidx)) { best = s_v[w]; bidx = s_i[w]; }
     if (bidx == 0x7fffffff) bidx = 0;  // all-NaN / empty map
     idx_out[map] = bidx;
-    score_out[map] = best;
+    score_out[(size_t)map * sstride] = best;
     float cx = 0.f, cy = 0.f;
     if (best > 0.f) {  // coords.mul(mask), evaluation.py:17-19
       const int x = bidx % W, y = bidx / W;
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void heatmap_max_preds_kernel(const float* __r
         cy += dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f);
       }
     }
-    coords_out[2 * map] = cx;
-    coords_out[2 * map + 1] = cy;
+    coords_out[(size_t)map * cstride] = cx;
+    coords_out[(size_t)map * cstride + 1] = cy;
   }
 }
 
@@ -404,7 +404,16 @@ extern "C" int ft_heatmap_max_preds(const float* heatmaps, int N, int K, int H, 
                                     float* score, float* coords, ft_stream_t stream) {
   if (!heatmaps || !idx || !score || !coords || N <= 0 || K <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
   hipLaunchKernelGGL(heatmap_max_preds_kernel, dim3(N * K), dim3(256), 0, as_stream(stream), heatmaps, H, W,
-                     adjust_coords, idx, score, coords);
+                     adjust_coords, idx, score, coords, 1, 2);
+  FT_LAUNCH_CHECK("heatmap_max_preds_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_heatmap_keypoint_rows(const float* heatmaps, int N, int K, int H, int W, int adjust_coords, int32_t* idx,
+                                        float* rows, ft_stream_t stream) {
+  if (!heatmaps || !idx || !rows || N <= 0 || K <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(heatmap_max_preds_kernel, dim3(N * K), dim3(256), 0, as_stream(stream), heatmaps, H, W,
+                     adjust_coords, idx, rows + 2, rows, 3, 3);
   FT_LAUNCH_CHECK("heatmap_max_preds_kernel");
   return FT_OK;
 }

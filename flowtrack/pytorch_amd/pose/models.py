@@ -236,12 +236,12 @@ class DeconvResnet(HipModule):
         if self.keypoints_in_plan is not None:
             # max_preds (+ the 0.25 px nudge of final_preds) as the last launch of the plan: no extra stream work per call
             K, hh, hw = self.num_classes, heatmaps.shape[2], heatmaps.shape[3]
+            # written as (x, y, score) rows — what the tracking glue and the multi-GPU gather consume; scores / coords are views
             plan.kp_idx = torch.empty((B, K), dtype=torch.int32, device=device)
-            plan.kp_score = torch.empty((B, K, 1), dtype=torch.float32, device=device)
-            plan.kp_coords = torch.empty((B, K, 2), dtype=torch.float32, device=device)
-            prog.add("ft_heatmap_max_preds", heatmaps.data_ptr(), B, K, hh, hw, int(bool(self.keypoints_in_plan)),
-                     plan.kp_idx.data_ptr(), plan.kp_score.data_ptr(), plan.kp_coords.data_ptr(),
-                     keep=(plan.kp_idx, plan.kp_score, plan.kp_coords))
+            plan.kp_rows = torch.empty((B, K, 3), dtype=torch.float32, device=device)
+            plan.kp_score, plan.kp_coords = plan.kp_rows[:, :, 2:], plan.kp_rows[:, :, :2]
+            prog.add("ft_heatmap_keypoint_rows", heatmaps.data_ptr(), B, K, hh, hw, int(bool(self.keypoints_in_plan)),
+                     plan.kp_idx.data_ptr(), plan.kp_rows.data_ptr(), keep=(plan.kp_idx, plan.kp_rows))
         return plan
 
     def plan_for(self, B: int, H: int, W: int) -> _PosePlan:
@@ -285,6 +285,13 @@ class DeconvResnet(HipModule):
         hm = self.forward(x, copy_output=False)
         plan = self._last_plan
         return hm, plan.kp_idx, plan.kp_score, plan.kp_coords
+
+    @torch.no_grad()
+    def forward_keypoint_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """forward_keypoints() returning only the plan's [B,K,3] (x, y, score) rows in heatmap pixels (static buffer, valid
+        until the next call): the form `lib/tracking/net_utils.py` concatenates preds and maxvals into."""
+        self.forward_keypoints(x)
+        return self._last_plan.kp_rows
 
 
 def deconv(backbone: str, num_classes: int, pretrained: bool) -> DeconvResnet:

@@ -278,6 +278,13 @@ int ft_bn_batch_stats(const void* x, int N, int H, int W, int C, int x_cstride, 
 int ft_heatmap_max_preds(const float* heatmaps, int N, int K, int H, int W,
                          int adjust_coords, int32_t* idx, float* score,
                          float* coords, ft_stream_t stream);
+/* The same launch with the key points written as rows (x, y, score): rows fp32
+ * [N*K*3] — the layout the tracking glue and the multi-GPU gather consume
+ * (lib/tracking/net_utils.py: `preds` and `maxvals` concatenated), so no
+ * concat launch follows the network. */
+int ft_heatmap_keypoint_rows(const float* heatmaps, int N, int K, int H, int W,
+                             int adjust_coords, int32_t* idx, float* rows,
+                             ft_stream_t stream);
 
 /* ---- F1: FlowNet2* input normalisation ------------------------------------
  * rgb_mean over (pair,H,W) per (b,colour) then (x - mean) / rgb_max

@@ -136,6 +136,8 @@ def test_keypoints_inside_the_plan_match_the_separate_call(hip_lib, adjust):
     for _ in range(2):          # eager first call, then the graph replay
         hm, idx, score, coords = m.forward_keypoints(x)
         assert torch.equal(hm, hm_ref) and torch.equal(idx, idx_r) and torch.equal(score, score_r) and torch.equal(coords, coords_r)
+        rows = m.forward_keypoint_rows(x)        # the same launch, read as (x, y, score) rows
+        assert rows.is_contiguous() and torch.equal(rows, torch.cat((coords_r, score_r), dim=2))
 
 
 @pytest.mark.parametrize("shape", [(2, 224, 160), (1, 288, 224), (3, 256, 192)], ids=str)
