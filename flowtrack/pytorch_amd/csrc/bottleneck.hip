@@ -461,11 +461,7 @@ static int supported(const ft_bottleneck_desc* d) {
 template <int TW, int NCH, bool FULL>
 static int launch(const BnkParams& p, hipStream_t s) {
   auto k = bottleneck_fused_kernel<TW, NCH, FULL>;
-  static thread_local bool attr_done = false;   // per thread = per device in the one-thread-per-GPU callers (as launch_dma_r)
-  if (!attr_done) {
-    FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_done = true;
-  }
+  FT_RAISE_LDS(k, kLdsBytes);
   hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
   FT_LAUNCH_CHECK("bottleneck_fused_kernel");
   return FT_OK;

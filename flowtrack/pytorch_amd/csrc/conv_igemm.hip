@@ -2256,13 +2256,7 @@ static int launch_dma_r(const ConvParams& p, dim3 grid, hipStream_t s) {
   static_assert((size_t)(KS - 1) * BP * BC * 4 <= ring, "K-split partials must fit in the rings");
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = conv_igemm_dma_kernel<T, BP, BC, WGP, WGC, BKB, S, HAS_RES, KS>;
-  if (lds > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      raised = true;
-    }
-  }
+  if (lds > 64 * 1024) FT_RAISE_LDS(k, lds);
   hipLaunchKernelGGL(k, grid, dim3(64 * WGP * WGC * KS), lds, s, p);
   return FT_OK;
 }
@@ -2287,13 +2281,7 @@ constexpr int kHintWideShift = 28;   // tile_hint bits 28-29: wide-K level w, BK
 template <int BC, int TW, int NTAPS, int KW, int S, int CCH>
 static int launch_halo_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
   auto k = conv_halo_kernel<BC, TW, NTAPS, KW, S, CCH>;
-  if (lds > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
-    }
-  }
+  if (lds > 64 * 1024) FT_RAISE_LDS(k, 160 * 1024);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
   return FT_OK;
 }
@@ -2301,13 +2289,7 @@ static int launch_halo_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t
 template <int KH, int STRIDE, int RUNB, int NT>
 static int launch_stem_k(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
   auto k = conv_stem_kernel<KH, STRIDE, RUNB, NT>;
-  if (lds > 64 * 1024) {
-    static thread_local bool raised = false;
-    if (!raised) {
-      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
-    }
-  }
+  if (lds > 64 * 1024) FT_RAISE_LDS(k, 160 * 1024);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
   return FT_OK;
 }

@@ -696,11 +696,7 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
     const size_t stage = ((size_t)(64 + 4 * drad) * C * 2 + 1023) / 1024 * 1024;
     const size_t lds2 = 2 * stage;
     auto k = correlation_mfma_kernel<16>;
-    static thread_local bool raised = false;
-    if (!raised) {
-      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
-    }
+    FT_RAISE_LDS(k, 160 * 1024);
     hipLaunchKernelGGL(k, dim3(ceil_div(W, 64), H, B), dim3(256), lds2, as_stream(stream), static_cast<const half_t*>(f1),
                        static_cast<const half_t*>(f2), static_cast<half_t*>(y), H, W, drad, (unsigned)f_bytes, f_cstride,
                        y_cstride, y_coff, act, slope);

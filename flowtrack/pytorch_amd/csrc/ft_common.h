@@ -23,6 +23,19 @@ int record_hip_error(hipError_t e, const char* what);
     if (_e != hipSuccess) return ::ft::record_hip_error(_e, name);   \
   } while (0)
 
+// More than 64 KiB of dynamic LDS is an opt-in per kernel AND per device: one flag per device id, set on the first launch
+// there (a process that drives several GPUs from one thread must not inherit another device's flag).
+#define FT_RAISE_LDS(kernel, bytes)                                                                              \
+  do {                                                                                                           \
+    static bool _raised[64] = {};                                                                                \
+    int _dev = 0;                                                                                                \
+    FT_HIP_CHECK(hipGetDevice(&_dev));                                                                           \
+    if (_dev < 0 || _dev >= 64 || !_raised[_dev]) {                                                              \
+      FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      if (_dev >= 0 && _dev < 64) _raised[_dev] = true;                                                          \
+    }                                                                                                            \
+  } while (0)
+
 static inline hipStream_t as_stream(ft_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -6,6 +6,7 @@ parameters stay in the reference's layout; plans hold the packed copies.
 """
 from __future__ import annotations
 
+import itertools
 import os
 from typing import Dict, Optional
 
@@ -27,11 +28,17 @@ class HipModule(nn.Module):
         self._plans: Dict[tuple, object] = {}
         self._layers: Dict[tuple, object] = {}   # (label, dtype, device) -> FusedConv: packed weights shared by all plans
         self._stream: Optional[torch.cuda.Stream] = None
+        self._fingerprint: Optional[tuple] = None   # (data_ptr, version) of every parameter / buffer the plans were built from
 
     # -- parameter changes invalidate packed weights ------------------------------------------
     def _invalidate(self):
         self._plans = {}
         self._layers = {}
+
+    def refresh(self) -> None:
+        """Drop every packed weight set and captured plan; the next forward rebuilds them from the current parameters.
+        Needed only after edits the version check of _check_fingerprint() cannot see (writes through `p.data`)."""
+        self._invalidate()
 
     def fused(self, label: str, weight, *, dtype, device, **kw):
         """FusedConv for `label`, built once per (dtype, device) and shared by every plan (input shape) of this
@@ -58,7 +65,20 @@ class HipModule(nn.Module):
         p = next(self.parameters())
         return p.device, p.dtype
 
+    def _check_fingerprint(self) -> None:
+        """Packed weights / captured graphs are copies of the parameters: rebuild them when any parameter or buffer of
+        this module tree changed since they were made — a load_state_dict through a child or a wrapper, in-place edits
+        under no_grad such as nn.init (all bump the tensor's version counter) or a re-assigned `.data` (new address).
+        Writes through `p.data` bump no counter: call refresh() after those.  ~50 us of host time per
+        call for a ResNet-101, hidden behind the asynchronous graph launch."""
+        fp = tuple((t.data_ptr(), t._version) for t in itertools.chain(self.parameters(), self.buffers()))
+        if fp != self._fingerprint:
+            if self._fingerprint is not None and (self._plans or self._layers):
+                self._invalidate()
+            self._fingerprint = fp
+
     def _resolve(self):
+        self._check_fingerprint()
         device, pdtype = self._param_device_dtype()
         require_gpu(device)
         dtype = self.compute_dtype or pdtype

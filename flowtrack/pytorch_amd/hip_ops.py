@@ -11,6 +11,7 @@ reference graphs (lib/flownet/networks/FlowNetS.py:73-88) becomes "write into a 
 from __future__ import annotations
 
 import ctypes
+import functools
 import json
 import os
 import sys
@@ -94,6 +95,19 @@ def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int
 def is_conv_call(name: str) -> bool:
     """Launches whose work is convolution MACs (the roofline's kernels): ft_conv2d_fwd[_ws] and ft_bottleneck_fwd."""
     return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd", "ft_conv_direct_fwd")
+
+
+def _on_plan_device(fn):
+    """Run a Program method with the plan's GPU as the current HIP device: the library launches on the stream it is handed,
+    but hipFuncSetAttribute / hipGetDevice / event creation inside it act on the CURRENT device, which is not the plan's
+    when one process drives several GPUs."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if self.stream is None:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self.stream.device):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 class Program:
@@ -218,6 +232,7 @@ class Program:
                 return
             self._keep_options(groups, [min(int(_TILE_CACHE.get("choice|" + g["key"], 0)), len(g["marks"]) - 2) for g in groups])
 
+    @_on_plan_device
     def tune_choices(self, reps: int = 3, verbose: bool = False) -> int:
         """In-situ benchmark of the recorded alternatives, innermost groups first: the whole launch list runs with hipEvents
         at the boundaries of each option; per key (all instances of one layer shape share a pick, as the tile variants
@@ -311,6 +326,7 @@ class Program:
     #: FT_NO_BRANCHES=1: ignore fork / join (everything in recording order on one stream) — dev A/B switch
     use_branches = os.environ.get("FT_NO_BRANCHES") is None
 
+    @_on_plan_device
     def run_eager(self, branches: bool = True) -> None:
         """Issue the launch list: on the program's stream, with the side-lane calls of each fork/join section on the
         second stream (branches=False: everything in order on the main stream, as the timing passes need it)."""
@@ -336,6 +352,7 @@ class Program:
             elif not name.startswith("__"):     # (an unresolved choice runs all of its options: same outputs)
                 check(getattr(lib, name)(*args, side if (lane and side is not None) else sh), name)
 
+    @_on_plan_device
     def capture(self) -> None:
         """Record the launch sequence into a HIP graph (hipStreamBeginCapture on our side stream)."""
         if self.graph_exec is not None:
@@ -351,6 +368,7 @@ class Program:
         check(st, "ft_graph_end_capture")
         self.graph_exec = exec_
 
+    @_on_plan_device
     def run(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Replay the captured graph on `stream` (default: the program's own stream; a graph may be launched on any
         stream, only the capture needed a private one), or run eagerly on the program's stream if not captured."""
@@ -360,6 +378,7 @@ class Program:
         else:
             self.run_eager()
 
+    @_on_plan_device
     def time_calls(self, iters: int = 5):
         """Per-call hipEvent timing on the program's stream (eager). Returns [(name, ms_avg)]."""
         self._ensure_workspace()
@@ -387,6 +406,7 @@ class Program:
             lib.ft_event_destroy(e)
         return [(self.calls[i][0], acc[i] / iters) for i in range(len(self.calls))]
 
+    @_on_plan_device
     def time_conv_runs(self, iters: int = 5):
         """GPU time of the conv launches of one step, with hipEvents only at the boundaries of each maximal run of
         consecutive `ft_conv2d_fwd` calls (so the kernels run back to back exactly as in the graph and the intervals
@@ -423,6 +443,7 @@ class Program:
             lib.ft_event_destroy(e)
         return conv_ms / iters, other_ms / iters
 
+    @_on_plan_device
     def tune_tiles(self, reps: int = 3, verbose: bool = False) -> int:
         """In-situ benchmark of the conv tile variants (the reference's `cudnn.benchmark = True`): the whole launch
         list runs eagerly `reps` times per candidate round with hipEvents around every conv, so each variant is timed

@@ -35,7 +35,7 @@ def detect(person_dets: np.ndarray, thresh: float = 0.3, prop_dets: np.ndarray =
 
 def boxes_to_center_scale(boxes: np.ndarray, inp_res=(256, 192)):
     """Box -> (center, scale) of the pose crop: aspect-corrected box height (net_utils.py:47-48; the datasets
-    additionally pad by 1.25, lib/pose/datasets/coco.py:110-113 — pass pad=1.25 to crop_boxes for that)."""
+    additionally enlarge the box by 1.25, lib/pose/datasets/coco.py:110-113 — multiply the returned scales by 1.25 for that)."""
     boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
     centers = np.stack((boxes[:, [0, 2]].mean(1), boxes[:, [1, 3]].mean(1)), axis=1)
     scales = np.maximum(boxes[:, 3] - boxes[:, 1], (boxes[:, 2] - boxes[:, 0]) / inp_res[1] * inp_res[0])
@@ -124,13 +124,23 @@ def pose_est_frames(net, frames_dev, boxes_list, inp_res=(256, 192), normalize=T
     return out
 
 
+def pad_pairs_to_64(ims: torch.Tensor) -> torch.Tensor:
+    """[B,3,2,H,W] -> [B,3,2,Hp,Wp] with Hp, Wp the next multiples of 64 (FlowNet's six stride-2 stages), filled by
+    replicating the last row / column.  The reference feeds frames as they are (net_utils.py:73-92) and only works for
+    sizes the net divides; zero padding would add a hard black edge and pull the net's own rgb_mean
+    (lib/flownet/model/models.py:255) towards black, replication keeps both representative."""
+    B, C, P, H, W = ims.shape
+    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
+    if (Hp, Wp) == (H, W):
+        return ims
+    return torch.nn.functional.pad(ims.reshape(B, C * P, H, W), (0, Wp - W, 0, Hp - H), mode="replicate").reshape(B, C, P, Hp, Wp)
+
+
 def flow_est(net, prev_frame: torch.Tensor, cur_frame: torch.Tensor) -> np.ndarray:
     """prev / cur: uint8 [H,W,3] BGR (device or host) -> flow [2,H,W] fp32 numpy (net_utils.py:73-92):
-    BGR -> RGB, pack [1,3,2,H,W] float 0..255, pad to a multiple of 64, crop the flow back."""
+    BGR -> RGB, pack [1,3,2,H,W] float 0..255, edge-replicate to a multiple of 64, crop the flow back."""
     dev = next(net.parameters()).device
     pair = torch.stack((torch.as_tensor(prev_frame).to(dev), torch.as_tensor(cur_frame).to(dev)))   # [2,H,W,3]
     H, W = pair.shape[1:3]
-    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
-    ims = torch.zeros((1, 3, 2, Hp, Wp), dtype=torch.float32, device=dev)
-    ims[0, :, :, :H, :W] = pair.flip(-1).permute(3, 0, 1, 2).float()
+    ims = pad_pairs_to_64(pair.flip(-1).permute(3, 0, 1, 2).float().unsqueeze(0))
     return net(ims)[0, :, :H, :W].cpu().numpy()

@@ -190,3 +190,25 @@ def test_plan_alternatives_are_resolved_and_equivalent(hip_lib, monkeypatch):
     assert na != nb
     rng = (a.max() - a.min()).item()
     assert (a - b).abs().max().item() <= 0.02 * rng
+
+
+def test_in_place_parameter_edits_rebuild_the_packed_weights(hip_lib):
+    """Plans hold packed copies of the parameters: an edit that bypasses load_state_dict (p.data.copy_, a load through a
+    child module) must not keep serving the old weights, and ordinary forwards must not rebuild anything."""
+    m, _ = _model(50, torch.float16)
+    x = synth.pose_crops(SEED + 5, 2).cuda()
+    a = m(x)
+    plan = m._last_plan
+    assert torch.equal(m(x), a) and m._last_plan is plan and plan.runs == 2      # no rebuild between plain forwards
+    with torch.no_grad():
+        m.heatmap.bias.add_(0.5)                       # in place, no load_state_dict (nn.init.* does the same)
+    b = m(x)
+    assert m._last_plan is not plan
+    assert (b - a - 0.5).abs().max().item() <= 2e-3
+    sd = {k: v.clone() for k, v in m.heatmap.state_dict().items()}
+    sd["bias"] -= 0.5
+    m.heatmap.load_state_dict(sd)                      # through a child module
+    assert (m(x) - a).abs().max().item() <= 2e-3
+    m.heatmap.bias.data.add_(0.25)                     # `.data` edits carry no version counter: refresh() is the contract
+    m.refresh()
+    assert (m(x) - a - 0.25).abs().max().item() <= 2e-3

@@ -270,3 +270,17 @@ def test_clip_pipeline_functional_signal_on_gpu(hip_lib):
     b0 = out[0]["boxes"]
     assert np.all(k0[..., 2] > 0.5) and np.all(k0[..., 0] >= b0[:, None, 0] - 16) and np.all(k0[..., 0] <= b0[:, None, 2] + 16)
     assert np.all(k0[..., 1] >= b0[:, None, 1] - 16) and np.all(k0[..., 1] <= b0[:, None, 3] + 16)
+
+
+def test_flow_frames_are_edge_replicated_to_multiples_of_64():
+    """pad_pairs_to_64: the padded area repeats the last row / column (no black border, the net's rgb_mean stays the
+    frame's), frames that already divide are returned untouched."""
+    from flowtrack.pytorch_amd.tracking.net_utils import pad_pairs_to_64
+    x = torch.arange(2 * 3 * 2 * 70 * 100, dtype=torch.float32).reshape(2, 3, 2, 70, 100)
+    y = pad_pairs_to_64(x)
+    assert tuple(y.shape) == (2, 3, 2, 128, 128)
+    assert torch.equal(y[..., :70, :100], x)
+    assert torch.equal(y[..., 70:, :100], x[..., 69:70, :].expand(-1, -1, -1, 58, -1))
+    assert torch.equal(y[..., :70, 100:], x[..., :, 99:100].expand(-1, -1, -1, -1, 28))
+    z = torch.zeros(1, 3, 2, 64, 128)
+    assert pad_pairs_to_64(z) is z

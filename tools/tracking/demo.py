@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 from flowtrack.pytorch_amd import parallel, synth                                  # noqa: E402
 from flowtrack.pytorch_amd.flownet import models as flow_models                     # noqa: E402
 from flowtrack.pytorch_amd.pose import models as pose_models                        # noqa: E402
-from flowtrack.pytorch_amd.tracking import FlowTracker, box_propagation, detect, flow_est, pose_est, pose_est_frames  # noqa: E402
+from flowtrack.pytorch_amd.tracking import FlowTracker, box_propagation, detect, flow_est, net_utils, pose_est, pose_est_frames  # noqa: E402
 
 
 def synthetic_clip(n_frames, H=384, W=512, n_people=5, seed=0):
@@ -143,13 +143,11 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     lo, hi = parallel.shard_range(T - 1, rank, world)
     H, W = frames.shape[1:3]
     local = torch.empty((hi - lo, 2, H, W), dtype=torch.float32, device=dev)
-    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
     for b0 in range(lo, hi, flow_batch):
         b1 = min(hi, b0 + flow_batch)
-        ims = torch.zeros((b1 - b0, 3, 2, Hp, Wp), dtype=torch.float32, device=dev)
-        ims[:, :, 0, :H, :W] = fr[b0:b1].flip(-1).permute(0, 3, 1, 2).float()             # BGR -> RGB (net_utils.py:83-87)
-        ims[:, :, 1, :H, :W] = fr[b0 + 1:b1 + 1].flip(-1).permute(0, 3, 1, 2).float()
-        local[b0 - lo:b1 - lo] = flow_fn(ims)[:, :, :H, :W]
+        ims = torch.stack((fr[b0:b1].flip(-1).permute(0, 3, 1, 2).float(),                # BGR -> RGB (net_utils.py:83-87)
+                           fr[b0 + 1:b1 + 1].flip(-1).permute(0, 3, 1, 2).float()), dim=2)
+        local[b0 - lo:b1 - lo] = flow_fn(net_utils.pad_pairs_to_64(ims))[:, :, :H, :W]    # edge-replicated to multiples of 64
     flows = parallel.all_gather_rows(local, T - 1)
     # the tracker reads the fields on the host: pinned buffer, copy overlapped with phase 2
     flows_host = torch.empty(flows.shape, dtype=flows.dtype, pin_memory=dev.type == "cuda") if rank == 0 else None
