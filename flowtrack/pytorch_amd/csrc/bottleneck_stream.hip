@@ -997,9 +997,16 @@ static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
   int pick;
   if (force == 1 || force == 2) pick = force;
   else {
-    // the big strip halves the weight stream per pixel; the small one doubles the workgroups when the big one leaves CUs idle
-    const long long wg_big = th_big >= 1 ? (long long)d->N * ceil_div(d->H, th_big) : 0;
-    pick = (th_big >= 1 && (wg_big >= 224 || th_small < 1)) ? 1 : 2;
+    // Both variants run one workgroup per CU at the matrix pipe's pace (the FT_BNS_DBG=64/128 ablation: same phase times
+    // with every load out of range), so the cost of a launch is rounds of 256 workgroups x MFMAs per workgroup:
+    // 64 K-steps on MT1 halo tiles + (144 + 64) K-steps on MT2 output tiles, per wave and pair of channel tiles.
+    auto cost = [&](int th, int mt1, int mt2) {
+      const long long wg = (long long)d->N * ceil_div(d->H, th);
+      return ((wg + 255) / 256) * (long long)(64 * mt1 + 208 * mt2);
+    };
+    if (th_big < 1) pick = 2;
+    else if (th_small < 1) pick = 1;
+    else pick = cost(th_big, 4, 3) <= cost(th_small, 3, 2) ? 1 : 2;
   }
   if (pick == 1 && th_big < 1) pick = 2;
   if (pick == 2 && th_small < 1) pick = 1;
