@@ -806,6 +806,17 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     mma2(c0{}, slot{}, std::integral_constant<int, 2>{});
     if (has_next) ldb(c0{}, 0, rbn);
     mma2(c1{}, slot{}, std::integral_constant<int, 3>{});
+    // Issue order of the step: one weight load and the pixel-operand reads after every MT2 MFMAs.  A buffer_load_b128 holds
+    // the wave's issue port for ~40 cycles (tools/dev/ubench/l2_burst.hip: a step costs its compute time + 335 cycles for its
+    // eight loads, whatever the prefetch depth); clustered as hipcc places them, the matrix pipe drains behind them.
+    if (!(p.dbg & 256)) {
+      bns_unroll<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        __builtin_amdgcn_sched_group_barrier(0x008, MT2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (i & 1) ? (MT2 + 1) / 2 : MT2 / 2, 0);
+      });
+    }
   };
 
   // ---- phase 2: nine taps x KC chunks, three taps per loop trip (12 steps: a multiple of the register ring period) -------
