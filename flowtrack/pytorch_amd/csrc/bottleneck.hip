@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       const int oy = qy0 + m / TW, ox = qx0 + m % TW;
       const uint4_t v = *reinterpret_cast<const uint4_t*>(t2 + m * 128 + ((ch ^ (m & 7)) << 4));
       if (oy < p.H && ox < p.W && !(p.dbg & 4))
-        *reinterpret_cast<uint4_t*>(p.y + ((((long long)n * p.H + oy) * p.W + ox) * p.y_cstride + p.y_coff + ch * 8) * 2) = v;
+        store_out16(p.y + ((((long long)n * p.H + oy) * p.W + ox) * p.y_cstride + p.y_coff + ch * 8) * 2, v);
     }
     return;
   }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       const int idx = tid + 256 * i, m = idx >> 3, ch = idx & 7;
       const uint4_t v = *reinterpret_cast<const uint4_t*>(so + m * 128 + ((ch ^ (m & 7)) << 4));
       if (spix[i] >= 0 && !(p.dbg & 4))
-        *reinterpret_cast<uint4_t*>(p.y + (spix[i] * p.y_cstride + p.y_coff + q * 64 + ch * 8) * 2) = v;
+        store_out16(p.y + (spix[i] * p.y_cstride + p.y_coff + q * 64 + ch * 8) * 2, v);
     }
   });
   if (p.dbg & 32) {       // dev: phase timestamps of wave 0 over the tile's first output pixel (output is garbage then)

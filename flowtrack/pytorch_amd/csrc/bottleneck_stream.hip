@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
               const int m = m_out[j];
               *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
             } else if (!(p.dbg & 4)) {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, y_voff[j], (q * P + i * 32 + h * 8) * 2, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, y_voff[j], (q * P + i * 32 + h * 8) * 2, FT_YSTORE_BUF_AUX);
             }
           }
         }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 #pragma unroll
         for (int k = 0; k < NSTG; ++k) {
           const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
-          if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, 0);
+          if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
         }
         if constexpr (P == 256 && q < 3) {
           // the staging tile sat in a weight buffer: hand it back (its refill with step glast + 3 was deferred)
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
       for (int k = 0; k < NSTG; ++k) {
         const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
-        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, 0);
+        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
       }
     });
   }

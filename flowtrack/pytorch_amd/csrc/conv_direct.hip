@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
     const int m = m0 + row;
     const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + row * G::STG_ROWB + ((ch ^ (row & SMASK)) << 4));
     const unsigned voff = (m < p.M && cb * BN + ch * 8 < p.Cout) ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + ch * 8) * 2) : kOOB;
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, FT_YSTORE_BUF_AUX);
   }
   if (p.dbg & 32) {
     ts[4] = __builtin_amdgcn_s_memtime();
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p
     const int m = m0 + row;
     const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + row * STG_ROWB + ((ch ^ (row & 7)) << 4));
     const unsigned voff = (row < npix && m < p.M && cb * BN + ch * 8 < p.Cout) ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + ch * 8) * 2) : kOOB;
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, FT_YSTORE_BUF_AUX);
   }
 #endif
 }

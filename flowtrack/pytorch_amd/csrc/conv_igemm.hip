@@ -307,10 +307,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
         const long long o = s_opix[pl];
         if (o >= 0 && co0 + ch * 8 < p.Cout) {
           const uint4_t v = *reinterpret_cast<const uint4_t*>(s_tile + pl * ROWB + ((ch ^ (pl & (NCH - 1))) << 4));
-#if FT_EPI_NT
+#if FT_EPI_NT && FT_YSTORE_AUX == 0
           __builtin_nontemporal_store(v, reinterpret_cast<uint4_t*>(ybase + o * p.y_cstride + ch * 8));
 #else
-          *reinterpret_cast<uint4_t*>(ybase + o * p.y_cstride + ch * 8) = v;
+          store_out16(ybase + o * p.y_cstride + ch * 8, v);
 #endif
         }
       }
@@ -1842,8 +1842,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
         best = __builtin_elementwise_max(best, __builtin_bit_cast(half8_t, v));
       }
     if (py < Hp && px < Wp)
-      *reinterpret_cast<uint4_t*>(p.y + ((((long long)n * Hp + py) * Wp + px) * p.y_cstride + p.y_coff + ch * 8) * 2) =
-          __builtin_bit_cast(uint4_t, best);
+      store_out16(p.y + ((((long long)n * Hp + py) * Wp + px) * p.y_cstride + p.y_coff + ch * 8) * 2, __builtin_bit_cast(uint4_t, best));
   }
 #endif
 }

@@ -50,4 +50,22 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
+// Activation-output stores.  FT_YSTORE_AUX = 16 (sc1) makes them write-through: nothing is left dirty in the XCD L2s for
+// the end-of-kernel release to write back (the line is dropped from L2; the next launch reads it from the memory side).
+#ifndef FT_YSTORE_AUX
+#define FT_YSTORE_AUX 0
+#endif
+#define FT_YSTORE_BUF_AUX (FT_YSTORE_AUX == 2 ? 2 : ((FT_YSTORE_AUX & 16) ? FT_YSTORE_AUX : 0))   // raw_buffer_store aux: 2 = nt, 16 = sc1, 17 = sc0 sc1
+__device__ __forceinline__ void store_out16(void* ptr, uint4_t v) {
+#if FT_YSTORE_AUX == 16
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+#elif FT_YSTORE_AUX == 17
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+#elif FT_YSTORE_AUX == 2
+  __builtin_nontemporal_store(v, reinterpret_cast<uint4_t*>(ptr));
+#else
+  *reinterpret_cast<uint4_t*>(ptr) = v;
+#endif
+}
+
 }  // namespace ft

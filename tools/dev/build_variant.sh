@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: build_variant.sh <name> <extra hipcc flags...>  -> flowtrack/pytorch_amd/libflowtrack_hip_<name>.so (A/B builds, FT_LIB_PATH selects)
+R=$(cd $(dirname $0)/../.. && pwd); P=$R/flowtrack/pytorch_amd; name=$1; shift
+mkdir -p $P/build_$name
+pids=()
+for s in conv_igemm bottleneck bottleneck_stream conv_direct aux_ops flow_ops crop_ops runtime; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I$R/include -I$P/csrc "$@" -c $P/csrc/$s.hip -o $P/build_$name/$s.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p || exit 1; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $P/build_$name/*.o -o $P/libflowtrack_hip_$name.so && echo built $P/libflowtrack_hip_$name.so
