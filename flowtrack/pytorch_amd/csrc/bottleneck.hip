@@ -44,6 +44,7 @@ struct BnkParams {
   unsigned x_bytes;
   int tx, ty;      // patches per image along x / y
   int total;       // workgroups
+  int w3_pitch;    // bytes per output-channel row of w3: 128 (W3 [256][64]); 256 at a projection block ([256][W3' 64 | Wd' 64])
   int dbg;         // FT_BNK_DBG (dev): 1 no x loads, 4 no stores, 16 x loads from images 0..7 only (L2-resident), 32 phase timestamps
 };
 
@@ -70,11 +71,16 @@ __device__ __forceinline__ constexpr int ring_slot(int i) { return i == 0 ? 6553
 // NCH = 64-channel chunks of the block input (4: the 256-wide identity blocks, 1: the stage's entry block, 64 in).
 // FULL = false stops after phase 2 and writes t2 (the entry block's conv3 is K-concatenated with its projection shortcut
 // in ft_conv2d_fwd's x2_* path; here only its conv1 + conv2 pair is fused).
-template <int TW, int NCH, bool FULL>
+// PROJ = the entry block WHOLE (64 -> 64 -> 64 -> 256 with its projection shortcut, blocks.py:104-119): phase 3 is the GEMM
+// over K = [t2 | x] of FusedShortcutConv (both BatchNorms folded into the weights, the shifts added): W3' quarters come through
+// the ring as before, the x fragments of the patch's own pixels are picked out of the phase-1 stage in the B-operand layout
+// and the shortcut weights Wd' (32 KiB per workgroup, L2-resident) go straight to registers at kernel start.
+template <int TW, int NCH, bool FULL, bool PROJ = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
   static_assert(NPIX <= 192, "halo patch");
+  static_assert(!PROJ || (FULL && NCH == 1), "projection form: 64-channel input, whole block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, kP * NCH * 128, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, kP * 9 * kP * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, FULL ? kC * kP * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, FULL ? kC * kP * (PROJ ? 4 : 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, FULL ? 3072 : 1024, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     const unsigned lc = (unsigned)((lpos ^ (wr & 7)) << 4);
     w1_voff[t] = (unsigned)(wr * NCH * 128) + lc;        // W1 [64][64 * NCH]
     w2_voff[t] = (unsigned)(wr * 9 * kP * 2) + lc;       // W2 [64][576]
-    w3_voff[t] = (unsigned)(wr * kP * 2) + lc;           // W3 [256][64], + quarter * 64 rows
+    w3_voff[t] = (unsigned)(wr * p.w3_pitch) + lc;       // W3 [256][64] (or the first half of [256][128]), + quarter * 64 rows
   }
 
   auto load_stage1 = [&](int slot, int c) {              // chunk c: channels 64c .. 64c+63 of the halo patch + W1's K-slice
@@ -147,12 +153,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       if (item < 9)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w2_voff[t], item * 128, 0, 0);
       else    // !FULL: rsrc_w3 is empty, every lane is out of range -> zero fill, no traffic, same load count for the waits
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w3_voff[t], (item - 9) * 64 * kP * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, w3_voff[t], (item - 9) * 64 * p.w3_pitch, 0, 0);
     }
   };
 
   // oldest loads of every wave: the folded-BN table (3 KiB, waves 0..2) and W2's first tap (its ring slot lies outside the
   // phase-1 stages) — both land long before they are needed and sit in front of every counted wait below
+  // projection form: the shortcut weights of this wave's channel tile, all four quarters x four 16-channel K slices, straight
+  // to registers (the oldest loads of the wave: every counted wait below covers them)
+  uint4_t fad[PROJ ? 4 : 1][4];
+  if constexpr (PROJ) {
+    const int wc2_ = wave >> 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        fad[q][k4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w3, (unsigned)((q * 64 + wc2_ * 32 + l31) * 256 + 128 + (k4 * 2 + lhi) * 16), 0, 0);
+  }
   if (wave < (FULL ? 3 : 1))
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_tab, (lds_ptr)(smem + kOffTab + wave * 1024), 16, (unsigned)(lane * 16), wave * 1024, 0, 0);
   load_item(0);
@@ -189,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     const int rc = (m / TW + 1) * PW + (m % TW + 1);
     rc_off[j] = rc * 128 + lhi * 8 + (((wc2 * 4) ^ (rc & 7)) << 4);    // 16-byte chunk wc2*4 + g sits at (.. ^ g) << 4
   }
-  half4_t res[FULL ? 4 : 1][2][4];
+  half4_t res[FULL && !PROJ ? 4 : 1][2][4];
+  uint4_t fbx[PROJ ? 2 : 1][2][2];      // projection form: the block input at the patch's own pixels as phase 3's pixel operand
 
   // two 32-KiB stages: chunk c+1 streams while chunk c is multiplied; a stage is refilled (chunk c+2) once every wave is
   // past its reads — a second barrier per chunk, four chunks
@@ -208,11 +226,24 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
       for (int j = 0; j < 3; ++j) fb[k16][j] = *reinterpret_cast<const uint4_t*>(st + (b1_off[j] ^ (k16 << 5)));
     }
-    if constexpr (FULL) {
+    if constexpr (FULL && !PROJ) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) res[c][j][g] = *reinterpret_cast<const half4_t*>(st + (rc_off[j] ^ (g << 4)));
+    }
+    if constexpr (PROJ) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = wp2 * 64 + j * 32 + l31;
+        const int rc = (m / TW + 1) * PW + (m % TW + 1);
+        const int lsw = lhi ^ (rc & 7);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+            fbx[sl][kk][j] = *reinterpret_cast<const uint4_t*>(st + rc * 128 + ((lsw ^ (sl * 4 + kk * 2)) << 4));
+      }
     }
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16)
@@ -400,6 +431,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
           acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa),
                                                            __builtin_bit_cast(half8_t, fb3[sl][kk][j]), acc3[j], 0, 0, 0);
       }
+    if constexpr (PROJ) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fad[q][sl * 2 + kk]),
+                                                             __builtin_bit_cast(half8_t, fbx[sl][kk][j]), acc3[j], 0, 0, 0);
+    }
     char* so = smem + ((q & 1) ? kOffOutB : kOffOutA);
     float4_t sc[4], sh[4];
 #pragma unroll
@@ -417,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
         half4_t h;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          h[e] = (half_t)__builtin_fmaxf(acc3[j][g * 4 + e] * sc[g][e] + sh[g][e] + (float)res[q][j][g][e], 0.f);
+          h[e] = (half_t)__builtin_fmaxf(acc3[j][g * 4 + e] * sc[g][e] + sh[g][e] + (PROJ ? 0.f : (float)res[PROJ ? 0 : q][j][g][e]), 0.f);
         *reinterpret_cast<half4_t*>(rowp + (((wc2 * 4 + g) << 4) ^ msw)) = h;
       }
     }
@@ -449,18 +490,18 @@ static int supported(const ft_bottleneck_desc* d) {
   if (!d) return FT_ERR_INVALID_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
   if (d->dtype != FT_F16 || d->P != kP) return FT_ERR_UNSUPPORTED;
-  if (d->head_only ? (d->C != 64 && d->C != kC) : d->C != kC) return FT_ERR_UNSUPPORTED;
-  if (d->head_only && d->C != 64) return FT_ERR_UNSUPPORTED;     // (256-wide head-only: no caller, not instantiated)
-  const int yc = d->head_only ? d->P : d->C;
+  if (d->head_only && d->projection) return FT_ERR_INVALID_ARG;
+  if (d->head_only || d->projection ? d->C != 64 : d->C != kC) return FT_ERR_UNSUPPORTED;   // (256-wide head-only: no caller, not instantiated)
+  const int yc = d->head_only ? d->P : kC;
   if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
   if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + yc) return FT_ERR_INVALID_ARG;
   if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
   return FT_OK;
 }
 
-template <int TW, int NCH, bool FULL>
+template <int TW, int NCH, bool FULL, bool PROJ = false>
 static int launch(const BnkParams& p, hipStream_t s) {
-  auto k = bottleneck_fused_kernel<TW, NCH, FULL>;
+  auto k = bottleneck_fused_kernel<TW, NCH, FULL, PROJ>;
   FT_RAISE_LDS(k, kLdsBytes);
   hipLaunchKernelGGL(k, dim3(p.total), dim3(256), kLdsBytes, s, p);
   FT_LAUNCH_CHECK("bottleneck_fused_kernel");
@@ -474,7 +515,9 @@ extern "C" int ft_bottleneck_supported(const ft_bottleneck_desc* d) { return ft:
 
 extern "C" double ft_bottleneck_flops(const ft_bottleneck_desc* d) {
   if (!d) return 0.0;
-  return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (d->head_only ? 0.0 : (double)d->P * d->C));
+  const double cout = 4.0 * d->P;
+  return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (d->head_only ? 0.0 : (double)d->P * cout) +
+                                     (d->projection ? (double)d->C * cout : 0.0));
 }
 
 extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, const void* w1, const void* w2, const void* w3,
@@ -493,6 +536,7 @@ extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, con
   p.N = d->N; p.H = d->H; p.W = d->W;
   p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
   p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->x_cstride * 2);
+  p.w3_pitch = d->projection ? 256 : 128;
   // 8 rows x 16 columns unless the width only divides by 8 (R101 at 384x288: 96x72 maps -> 16 rows x 8 columns)
   const bool tall = d->W % 16 != 0 && d->W % 8 == 0;
   const int tw = tall ? 8 : 16, th = 128 / tw;
@@ -503,6 +547,7 @@ extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, con
   p.dbg = dbg;
   hipStream_t s = as_stream(stream);
   if (d->head_only) return tall ? launch<8, 1, false>(p, s) : launch<16, 1, false>(p, s);
+  if (d->projection) return tall ? launch<8, 1, true, true>(p, s) : launch<16, 1, true, true>(p, s);
   return tall ? launch<8, 4, true>(p, s) : launch<16, 4, true>(p, s);
 }
 

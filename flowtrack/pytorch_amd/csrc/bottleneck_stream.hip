@@ -621,6 +621,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + 2 * wcol + i) * 1024, 0);
   };
 
+  auto load_a_half = [&](auto slotc, int g, auto halfc) {   // K16 slices {0, 1} or {2, 3} of the step
+    constexpr int SL = decltype(slotc)::value, HF = decltype(halfc)::value;
+#pragma unroll
+    for (int kk = 2 * HF; kk < 2 * HF + 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + 2 * wcol + i) * 1024, 0);
+  };
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BNSD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
   BNSD_TS(0);
@@ -679,10 +687,29 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       constexpr int c = decltype(cc)::value;
       constexpr int buf = c % 3;
       using slot = std::integral_constant<int, c % 3>;
-      load_a(std::integral_constant<int, (c + 2) % 3>{}, c + 2);
+      // The wave-uniform branch below (residual pick-up) splits the chunk into two scheduling regions; each gets half of the
+      // step's weight loads and a pinned issue order (see dstep): one vector-memory load and the LDS reads behind every two
+      // MFMAs instead of hipcc's clusters of 6-8 loads with the matrix pipe drained behind them.
+      load_a_half(std::integral_constant<int, (c + 2) % 3>{}, c + 2, c0{});
       ldx(c1{}, buf, 1);
       mma1(c0{}, slot{}, std::integral_constant<int, 0>{});
       ldx(c0{}, buf, 2);
+      if (!(p.dbg & 256)) {
+        // region: [x chunk c+2 DMA, slice-0 reads of this chunk, slice 3 of chunk c-1] (behind the last barrier) + the above
+        __builtin_amdgcn_sched_group_barrier(0x020, LX, 0);
+        bns_unroll<3>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, (2 * MT1 + 2) / 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (MT1 + 2) / 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        bns_unroll<MT1 - 1>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, (MT1 + 2) / 3, 0);
+        });
+      }
       if (c % 4 == wcol) {           // this chunk holds the channels of this wave column for quarter c / 4
         constexpr int q = c / 4;
         const char* xb = smem + buf * G::XSTRIDE;
@@ -698,8 +725,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         }
       }
       mma1(c1{}, slot{}, std::integral_constant<int, 1>{});
+      load_a_half(std::integral_constant<int, (c + 2) % 3>{}, c + 2, c1{});
       ldx(c1{}, buf, 3);
       mma1(c0{}, slot{}, std::integral_constant<int, 2>{});
+      if (!(p.dbg & 256)) {
+        bns_unroll<MT1>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 4 - MT1 > 0 ? 4 - MT1 : 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT1 - 2 * MT1 - 2, 0);
+      }
       if constexpr (c + 1 < NC1) {
         // x chunk c+1 has landed and every read of chunk c's buffer is complete: refill it with chunk c+3.  Younger than x
         // chunk c+1 are the weights of step c+1 (needed next anyway), x chunk c+2 and the weights of step c+2.
@@ -983,7 +1021,7 @@ struct BnsPlan {
 static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
   if (!d) return FT_ERR_INVALID_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
-  if (d->dtype != FT_F16 || d->head_only || (d->P != 128 && d->P != 256) || d->C != 4 * d->P) return FT_ERR_UNSUPPORTED;
+  if (d->dtype != FT_F16 || d->head_only || d->projection || (d->P != 128 && d->P != 256) || d->C != 4 * d->P) return FT_ERR_UNSUPPORTED;
   if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
   if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + d->C) return FT_ERR_INVALID_ARG;
   if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->H * d->W * d->y_cstride * 2 >= (1LL << 31))

@@ -53,7 +53,7 @@ typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 // Activation-output stores.  FT_YSTORE_AUX = 16 (sc1) makes them write-through: nothing is left dirty in the XCD L2s for
 // the end-of-kernel release to write back (the line is dropped from L2; the next launch reads it from the memory side).
 #ifndef FT_YSTORE_AUX
-#define FT_YSTORE_AUX 0
+#define FT_YSTORE_AUX 16
 #endif
 #define FT_YSTORE_BUF_AUX (FT_YSTORE_AUX == 2 ? 2 : ((FT_YSTORE_AUX & 16) ? FT_YSTORE_AUX : 0))   // raw_buffer_store aux: 2 = nt, 16 = sc1, 17 = sc0 sc1
 __device__ __forceinline__ void store_out16(void* ptr, uint4_t v) {

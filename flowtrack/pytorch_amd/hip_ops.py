@@ -973,6 +973,55 @@ def record_bottleneck_head(prog: Program, c1: "FusedConv", c2: "FusedConv", x: A
              t2.t.data_ptr(), keep=(d, x.t, t2.t, w1, w2, table))
 
 
+def bottleneck_entry_fusable(c1: "FusedConv", c2: "FusedConv", sc: "FusedShortcutConv", x: ActView, y: ActView) -> bool:
+    """True when ft_bottleneck_fwd(projection) covers a stage's WHOLE entry block (fp16, 64 -> 64 -> 64 -> 256, stride 1,
+    projection shortcut K-concatenated with conv3)."""
+    if x.t.dtype != torch.float16 or x.rowpacked or (x.N, x.H, x.W) != (y.N, y.H, y.W):
+        return False
+    if (c1.k, c2.k) != (1, 3) or (c1.stride, c2.stride, c2.pad, sc.stride_d) != (1, 1, 1, 1):
+        return False
+    if (c1.cin, c1.cout, c2.cin, c2.cout, sc.cin, sc.cin2, sc.cout, y.C) != (x.C, c2.cin, c2.cin, c2.cin, c2.cin, x.C, 4 * c2.cin, 4 * c2.cin):
+        return False
+    if any(c.transposed or c.tail_cout or c.act != ACT_CODES["relu"] or c._bn is None for c in (c1, c2)) or sc.act != ACT_CODES["relu"]:
+        return False
+    d = _bottleneck_desc(x, y, c2.cin)
+    d.projection = 1
+    return _lib.load().ft_bottleneck_supported(ctypes.byref(d)) == 0
+
+
+def record_bottleneck_entry(prog: Program, c1: "FusedConv", c2: "FusedConv", sc: "FusedShortcutConv", x: ActView, y: ActView,
+                            label: str) -> None:
+    """A stage's entry block as ONE launch (ft_bottleneck_fwd, projection = 1): conv1 + bn1 + relu -> conv2 + bn2 + relu ->
+    relu(bn3(conv3) + bn_d(conv_d(x))); t1 / t2 stay in LDS, the last step is FusedShortcutConv's K-concatenated GEMM with
+    the very weights that class packs."""
+    lib = _lib.load()
+    planes = c2.cin
+    w1, s1, b1 = _bottleneck_packed(c1, x, (planes, x.C, 1), label)
+    w2, s2, b2 = _bottleneck_packed(c2, x, (planes, 9 * planes, 1), label)
+    dc = ConvDesc()
+    dc.dtype = sc.code
+    dc.N, dc.Hi, dc.Wi, dc.Ho, dc.Wo = x.N, x.H, x.W, x.H, x.W
+    dc.Cin, dc.x_cstride, dc.x_coff = sc.cin, act_stride(sc.cin), 0
+    dc.Cout, dc.kh, dc.kw, dc.stride, dc.pad, dc.transposed = sc.cout, 1, 1, 1, 0, 0
+    dc.y_cstride, dc.y_coff, dc.out_layout = y.cstride, y.coff, FT_LAYOUT_NHWC
+    dc.act = sc.act
+    dc.x2_cin, dc.x2_hi, dc.x2_wi, dc.x2_cstride, dc.x2_coff, dc.x2_stride = sc.cin2, x.H, x.W, x.cstride, x.coff, 1
+    g = conv_geometry(dc)
+    if (g.cout_pad, g.kpad, g.cin_pad, g.nphases) != (4 * planes, planes + x.C, planes, 1):
+        raise FlowtrackHipError(f"{label}: unexpected K-concatenated layout {(g.cout_pad, g.kpad, g.cin_pad)} for the fused entry block")
+    w3, shift3 = sc._packed_for(dc)
+    d = _bottleneck_desc(x, y, planes)
+    d.projection = 1
+    check(lib.ft_bottleneck_supported(ctypes.byref(d)), "ft_bottleneck_supported")
+    flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
+    prog.flops += flops
+    prog.fused_records.append((label, len(prog.calls), flops))
+    table = torch.cat([t.flatten()[:planes].float() for t in (s1, b1, s2, b2)] +
+                      [torch.ones(4 * planes, dtype=torch.float32, device=x.t.device), shift3.flatten()[:4 * planes].float()]).contiguous()
+    prog.add("ft_bottleneck_fwd", ctypes.byref(d), x.t.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), table.data_ptr(),
+             y.t.data_ptr(), keep=(d, x.t, y.t, w1, w2, w3, table))
+
+
 def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
                       label: str) -> None:
     """conv1 + bn1 + relu -> conv2 + bn2 + relu -> conv3 + bn3 + residual(x) + relu as ONE launch (ft_bottleneck_fwd);

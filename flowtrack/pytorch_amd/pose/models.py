@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ..engine import HipModule
 from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable,
-                       bottleneck_head_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_head,
+                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -186,21 +186,31 @@ class DeconvResnet(HipModule):
                     cur = out
                     continue
                 t2 = new_act(B, Ho, Wo, planes, dtype, device)
-                if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
-                    record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
-                else:
-                    t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
-                    c1.record(prog, cur, t1)
-                    c2.record(prog, t1, t2)
+                fused = None
                 if len(blk.downsample) and self.fuse_shortcut:
-                    # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
-                    # the shortcut tensor never exists in HBM
                     key = (name + ".conv3+downsample", dtype, str(device))
                     fused = self._layers.get(key)
                     if fused is None:
                         fused = self._layers[key] = FusedShortcutConv(
                             blk.conv3.weight, blk.bn3.as_dict(), blk.downsample[0].weight, blk.downsample[1].as_dict(), s,
                             dtype=dtype, device=device, act="relu", label=name + ".conv3+downsample")
+                whole = self.fuse_bottleneck and fused is not None and bottleneck_entry_fusable(c1, c2, fused, cur, out)
+                if whole:
+                    # the 64-wide entry block whole (t1, t2 and the shortcut never leave the CU) or as head + K-concatenated
+                    # conv3: both recorded, the first-call benchmark keeps one
+                    prog.begin_choice(f"entry|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
+                    prog.option()
+                    record_bottleneck_entry(prog, c1, c2, fused, cur, out, name + ".fused")
+                    prog.option()
+                if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
+                    record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
+                else:
+                    t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
+                    c1.record(prog, cur, t1)
+                    c2.record(prog, t1, t2)
+                if fused is not None:
+                    # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
+                    # the shortcut tensor never exists in HBM
                     fused.record(prog, t2, cur, out)
                 elif len(blk.downsample):
                     ds = self.fused(name + ".downsample", blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(),
@@ -210,6 +220,8 @@ class DeconvResnet(HipModule):
                     c3.record(prog, t2, out, residual=res)
                 else:
                     c3.record(prog, t2, out, residual=cur)  # relu(bn3(conv3) + residual), blocks.py:114-119
+                if whole:
+                    prog.end_choice()
                 cur = out
 
         # head: 3 x (ConvTranspose 4/2/1 + bn + relu), then the 1x1 heatmap conv (pose_deconv.py:43-45) — fused behind

@@ -222,6 +222,10 @@ typedef struct ft_bottleneck_desc {
   int head_only;          /* 1: conv1 + conv2 only, y = t2 [N,H,W,P] (C = 64: the stage's entry block, whose conv3 is
                              K-concatenated with its projection shortcut by ft_conv2d_fwd); w3 = NULL,
                              scale_shift = float[4P] */
+  int projection;         /* 1: the stage's entry block WHOLE (blocks.py:104-119 with `downsample`): C = 64 input channels,
+                             y = relu(bn3(conv3(t2)) + bn_d(conv_d(x))) [N,H,W,4P]; w3 = [4P][P | C] fp16, the two 1x1
+                             convs K-concatenated with their BatchNorm scales folded in (the layout ft_conv2d_fwd's x2_*
+                             path takes), scale_shift = float[4P + 8P]: {s1 b1 s2 b2} then scale3 = 1, shift3 = b3 + b_d */
 } ft_bottleneck_desc;
 int ft_bottleneck_supported(const ft_bottleneck_desc* d);   /* FT_OK or FT_ERR_UNSUPPORTED / FT_ERR_INVALID_ARG */
 int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,

@@ -146,6 +146,56 @@ def test_fused_bottleneck_head_matches_oracle_and_the_two_launches(hip_lib, case
     assert torch.equal(view_to_nchw(t2f), got)
 
 
+@pytest.mark.parametrize("case", HEAD_CASES + [("view_out", 2, 16, 16)], ids=[c[0] for c in HEAD_CASES] + ["view_out"])
+def test_fused_entry_block_matches_oracle_and_the_two_launches(hip_lib, case):
+    """The stage's WHOLE entry block (64 -> 64 -> 64 -> 256, projection shortcut K-concatenated with conv3, blocks.py:104-119)
+    as one launch (projection = 1) vs the torch-CPU functional form and vs head + FusedShortcutConv."""
+    from flowtrack.pytorch_amd.hip_ops import (FusedShortcutConv, bottleneck_entry_fusable, record_bottleneck_entry,
+                                               record_bottleneck_head)
+    name, N, H, W = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 29
+    C = P = 64
+    CO = 4 * P
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (CO, P, 1, 1), std=(2.0 / P) ** 0.5)
+    wd = synth.normal(seed, name + ".wd", (CO, C, 1, 1), std=(2.0 / C) ** 0.5)
+    bn1, bn2, bn3, bnd = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", CO), _bn(seed, name + ".bnd", CO)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t2 = F.relu(_bnf(F.conv2d(F.relu(_bnf(F.conv2d(x, w1), bn1)), w2, padding=1), bn2))
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + _bnf(F.conv2d(x, wd), bnd))
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    sc = FusedShortcutConv(w3, bn3, wd, bnd, 1, dtype=dtype, device=dev, act="relu", label="conv3+downsample")
+    xv = nchw_to_view(x, dtype, dev)
+    off = 32 if name == "view_out" else 0
+    yf = ActView(torch.full((N, H, W, CO + off), 3.0, dtype=dtype, device=dev), CO, off)
+    assert bottleneck_entry_fusable(c1, c2, sc, xv, yf)
+    prog = make_program()
+    record_bottleneck_entry(prog, c1, c2, sc, xv, yf, name)
+    run_program(prog)
+    got = view_to_nchw(yf)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: fused entry block vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    if off:
+        assert torch.all(yf.t[..., :off] == 3.0), "channels outside the output slice were written"
+    t2v = ActView(torch.zeros((N, H, W, P), dtype=dtype, device=dev), P, 0)
+    y2 = ActView(torch.zeros((N, H, W, CO), dtype=dtype, device=dev), CO, 0)
+    prog2 = make_program()
+    record_bottleneck_head(prog2, c1, c2, xv, t2v, name)
+    sc.record(prog2, t2v, xv, y2)
+    prog2.resolve_choices()
+    run_program(prog2)
+    diff = (got - view_to_nchw(y2)).abs()
+    assert diff.max().item() <= 1e-2 * scale, f"{name}: fused vs head + shortcut launches max abs diff {diff.max().item():.3e}"
+    assert (diff > 0).float().mean().item() < 0.05, "fused and separate launches should agree bit for bit almost everywhere"
+    yf.t.fill_(5.0)
+    run_program(prog)
+    assert torch.equal(view_to_nchw(yf), got)
+
+
 def test_fused_bottleneck_rejects_other_blocks(hip_lib):
     from flowtrack.pytorch_amd import _lib
     import ctypes
