@@ -55,6 +55,12 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 }
 
 #define BNS_BARRIER() asm volatile("s_barrier" ::: "memory")
+#ifndef FT_BNS_OVL
+#define FT_BNS_OVL 0    // dev A/B: phase 3 of the direct kernel hides a quarter's epilogue inside the next quarter's weight steps
+#endif
+#ifndef FT_BNS_PIN
+#define FT_BNS_PIN 3    // dev A/B: bit 0 = pinned issue order in phase 1 of the direct kernel, bit 1 = in its weight steps (dstep)
+#endif
 
 // MFMA row r of an A fragment holds output channel sigma(r) of its 32-channel tile, so that accumulator register k of
 // lane (pixel, half) is channel 16 * half + k: 16 consecutive channels per lane.
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       ldx(c1{}, buf, 1);
       mma1(c0{}, slot{}, std::integral_constant<int, 0>{});
       ldx(c0{}, buf, 2);
-      if (!(p.dbg & 256)) {
+      if constexpr (FT_BNS_PIN & 1) {
         // region: [x chunk c+2 DMA, slice-0 reads of this chunk, slice 3 of chunk c-1] (behind the last barrier) + the above
         __builtin_amdgcn_sched_group_barrier(0x020, LX, 0);
         bns_unroll<3>([&](auto) {
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       load_a_half(std::integral_constant<int, (c + 2) % 3>{}, c + 2, c1{});
       ldx(c1{}, buf, 3);
       mma1(c0{}, slot{}, std::integral_constant<int, 2>{});
-      if (!(p.dbg & 256)) {
+      if constexpr (FT_BNS_PIN & 1) {
         bns_unroll<MT1>([&](auto) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -821,41 +827,51 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
     for (int j = 0; j < MT2; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (kk << 5)));
   };
-  auto mma2 = [&](auto setc, auto slotc, auto kkc) {
+  auto mma2 = [&](auto setc, auto slotc, auto kkc, float16_t (&A)[2][MT2]) {
     constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]),
-                                                           __builtin_bit_cast(half8_t, fb[S][j]), acc[i][j], 0, 0, 0);
+        A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]),
+                                                         __builtin_bit_cast(half8_t, fb[S][j]), A[i][j], 0, 0, 0);
   };
   // one weight step g (ring slot SL = g % 3): slice 0 of the pixel operand already sits in register set 0; `rbn` = row
-  // bases of the next step
-  auto dstep = [&](auto slotc, int g, const int (&rb)[MT2], bool has_next, const int (&rbn)[MT2]) {
-    constexpr int SL = decltype(slotc)::value;
+  // bases of the next step; `extra` = independent vector work that rides along (phase 3: a piece of the previous
+  // quarter's epilogue), NX = how many of its VALU instructions each of the eight issue groups takes
+  auto dstep = [&](auto slotc, int g, const int (&rb)[MT2], bool has_next, const int (&rbn)[MT2], float16_t (&A)[2][MT2], auto nxc,
+                   auto&& extra) {
+    constexpr int SL = decltype(slotc)::value, NX = decltype(nxc)::value;
     using slot = std::integral_constant<int, SL>;
     load_a(std::integral_constant<int, (SL + 2) % 3>{}, g + 2);
     ldb(c1{}, 1, rb);
-    mma2(c0{}, slot{}, std::integral_constant<int, 0>{});
+    mma2(c0{}, slot{}, std::integral_constant<int, 0>{}, A);
+    extra();
     ldb(c0{}, 2, rb);
-    mma2(c1{}, slot{}, std::integral_constant<int, 1>{});
+    mma2(c1{}, slot{}, std::integral_constant<int, 1>{}, A);
     ldb(c1{}, 3, rb);
-    mma2(c0{}, slot{}, std::integral_constant<int, 2>{});
+    mma2(c0{}, slot{}, std::integral_constant<int, 2>{}, A);
     if (has_next) ldb(c0{}, 0, rbn);
-    mma2(c1{}, slot{}, std::integral_constant<int, 3>{});
+    mma2(c1{}, slot{}, std::integral_constant<int, 3>{}, A);
     // Issue order of the step: one weight load and the pixel-operand reads after every MT2 MFMAs.  A buffer_load_b128 holds
     // the wave's issue port for ~40 cycles (tools/dev/ubench/l2_burst.hip: a step costs its compute time + 335 cycles for its
     // eight loads, whatever the prefetch depth); clustered as hipcc places them, the matrix pipe drains behind them.
-    if (!(p.dbg & 256)) {
+    if constexpr (FT_BNS_PIN & 1) {
       bns_unroll<8>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         __builtin_amdgcn_sched_group_barrier(0x008, MT2, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, (i & 1) ? (MT2 + 1) / 2 : MT2 / 2, 0);
+        if constexpr (NX > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x002, NX, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the folded-BN table reads of the piece
+          __builtin_amdgcn_sched_group_barrier(0x200, (i & 3) == 3 ? 1 : 0, 0);
+        }
       });
     }
   };
+  using nx0 = std::integral_constant<int, 0>;
+  auto no_extra = [] {};
 
   // ---- phase 2: nine taps x KC chunks, three taps per loop trip (12 steps: a multiple of the register ring period) -------
   {
@@ -870,7 +886,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         constexpr int nkc = (kc + 1) % KC, nkx = kc + 1 == KC ? (kx + 1) % 3 : kx;
         const int nky = (kc + 1 == KC && kx == 2) ? ky + 1 : ky;
         row_bases(nky * W + nkx - 1, nkc, nkx == 0 ? 1 : (nkx == 2 ? 2 : 0), rbn);
-        dstep(std::integral_constant<int, (G::G2 + s) % 3>{}, G::G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn);
+        dstep(std::integral_constant<int, (G::G2 + s) % 3>{}, G::G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn, acc, nx0{}, no_extra);
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
@@ -923,53 +939,110 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     int rb[MT2], rbn[MT2];
     row_bases(0, 0, 0, rb);
     ldb(c0{}, 0, rb);
+    // epilogue of quarter q, tile (i, j): folded BN + residual + ReLU -> fp16 -> staging tile q & 1
+    auto epi_piece = [&](auto qc, int i, int j, float16_t (&A)[2][MT2]) {
+      constexpr int q = decltype(qc)::value;
+      char* stg = smem + STG + (q & 1) * STGB;
+      const float* tb = reinterpret_cast<const float*>(smem + TABS + (2 + q) * G::TABB);
+      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+      }
+      const int m = m_out[j];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = h * 8 + e;
+          o[e] = (half_t)__builtin_fmaxf(A[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
+        }
+        *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
+      }
+    };
+    auto readout = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const char* stg = smem + STG + (q & 1) * STGB;
+#pragma unroll
+      for (int k = 0; k < NSTG; ++k) {
+        const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
+        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
+      }
+    };
+    auto zero_set = [&](float16_t (&A)[2][MT2]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MT2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) A[i][j][r] = 0.f;
+    };
+#if FT_BNS_OVL
+    // Overlapped form: two accumulator sets alternate between the quarters; the epilogue of quarter q-1 (VALU + LDS writes,
+    // ~3.4 k cycles when it ran alone behind its quarter) rides inside the weight steps of quarter q, one (i, j) tile per
+    // step, pinned between the MFMAs by dstep's issue groups.  The staging tiles alternate as before: tile (q-1) & 1 is
+    // written during quarter q, read out behind quarter q's barrier; its previous readers (quarter q-3) are two barriers back.
+    static_assert(2 * MT2 == KC, "one epilogue tile per weight step");
+    float16_t acc_b[2][MT2];
+    zero_set(acc_b);
+    bns_unroll<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      float16_t (&A)[2][MT2] = (q & 1) ? acc_b : acc;
+      float16_t (&Aprev)[2][MT2] = (q & 1) ? acc : acc_b;
+      bns_unroll<KC>([&](auto kcc) {
+        constexpr int kc = decltype(kcc)::value;
+        constexpr int g = G::G3 + q * KC + kc;
+        row_bases(0, (kc + 1) % KC, 0, rbn);
+        if constexpr (q > 0) {
+          dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn, A, std::integral_constant<int, 12>{},
+                [&] { epi_piece(std::integral_constant<int, q - 1>{}, kc / MT2, kc % MT2, Aprev); });
+        } else {
+          dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn, A, nx0{}, no_extra);
+        }
+#pragma unroll
+        for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
+      });
+      if constexpr (q > 0) {
+        zero_set(Aprev);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BNS_BARRIER();
+        readout(std::integral_constant<int, q - 1>{});
+      }
+    });
+    // quarter 3 has no successor to hide behind
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT2; ++j) epi_piece(std::integral_constant<int, 3>{}, i, j, acc_b);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BNS_BARRIER();
+    readout(std::integral_constant<int, 3>{});
+#else
     bns_unroll<4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       bns_unroll<KC>([&](auto kcc) {
         constexpr int kc = decltype(kcc)::value;
         constexpr int g = G::G3 + q * KC + kc;
         row_bases(0, (kc + 1) % KC, 0, rbn);
-        dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn);
+        dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn, acc, nx0{}, no_extra);
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
-      char* stg = smem + STG + (q & 1) * STGB;
-      const float* tb = reinterpret_cast<const float*>(smem + TABS + (2 + q) * G::TABB);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ch = (2 * wcol + i) * 32 + 16 * lhi;
-        float4_t sc[4], sh[4];
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < MT2; ++j) {
-          const int m = m_out[j];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
-            half8_t o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int r = h * 8 + e;
-              o[e] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
-            }
-            *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
-          }
-        }
-      }
+        for (int j = 0; j < MT2; ++j) epi_piece(qc, i, j, acc);
       zero_acc();
       // the two staging tiles alternate: a tile's previous readers (quarter q-2) are two barriers behind
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       BNS_BARRIER();
-#pragma unroll
-      for (int k = 0; k < NSTG; ++k) {
-        const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
-        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
-      }
+      readout(qc);
     });
+#endif
   }
   if (p.dbg & 32) {
     ts[5] = __builtin_amdgcn_s_memtime();

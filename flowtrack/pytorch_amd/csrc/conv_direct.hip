@@ -41,6 +41,7 @@ struct CdParams {
   float slope;
   int npt, ncb;                // pixel tiles, output-channel blocks
   unsigned x_bytes, x2_bytes, y_bytes, res_bytes, ws_bytes;
+  int cpt, kw, Hi, Wi, stride, pad;   // TAPS form (kh x kw, any stride): chunks per tap, kernel width, input map, geometry
   int dbg;                     // FT_CD_DBG (dev): 32 = phase timestamps of wave 0 into the tile's first output row
 };
 
@@ -76,7 +77,10 @@ struct CdGeom {
 // a run-time trip count hipcc joins its wait-count states at the loop header and drains the whole queue, vmcnt(0), at the
 // first use of a prefetched weight fragment: the look-ahead is lost, 22 instead of 12 us on layer4's conv3.)  NCH = 0 is
 // the run-time-loop fallback for K sizes without an instantiation.
-template <int KSPLIT, bool HAS_RES, int NCH>
+// TAPS: a kh x kw convolution (3x3 / stride 2 of the stages' entry blocks, blocks.py:92-95 with stride on conv2): chunk c of
+// the K walk is channel chunk c % cpt of tap c / cpt; the pixel operand of a tap is a gather (input pixel oy*s - pad + ky,
+// ox*s - pad + kx: one base offset per ring row + a scalar tap offset, taps that leave the image read out of range = zeros).
+template <int KSPLIT, bool HAS_RES, int NCH, bool TAPS = false>
 __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = CdGeom<KSPLIT>;
@@ -113,13 +117,30 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   // ring row = pixel, ROWB bytes; a 1-KiB wave load covers 1024 / ROWB rows; XOR swizzle on the SOURCE 16-byte position
   constexpr int CPR = ROWB / 16;                  // 16-byte positions per row: 8 or 32
   constexpr int RPL = 64 / CPR;                   // rows per wave load: 8 or 2
-  unsigned x_voff[LX], x2_voff[LX];
+  unsigned x_voff[LX], x2_voff[TAPS ? 1 : LX];
+  int x_tmask[TAPS ? LX : 1];      // TAPS: bit t = tap t of this row's pixel lies inside the input map
 #pragma unroll
   for (int t = 0; t < LX; ++t) {
     const int row = (t * 4 + wave) * RPL + lane / CPR, pos = lane % CPR;
     const int m = m0 + row;
     const unsigned swz = (unsigned)((pos ^ (row & (CPR < 16 ? CPR - 1 : 15))) << 4);
     unsigned v = kOOB, v2 = kOOB;
+    if constexpr (TAPS) {
+      int mk = 0;
+      if (m < p.M) {
+        const int n = m / p.HqWq, rem = m - n * p.HqWq, oy = rem / p.Wq, ox = rem - oy * p.Wq;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        v = (unsigned)((((n * p.Hi + iy0) * p.Wi + ix0) * p.x_cstride + p.x_coff) * 2) + swz;    // tap (0, 0); may wrap, only used when valid
+        const int ntap = p.nc1 / p.cpt;
+        for (int tp = 0; tp < ntap; ++tp) {
+          const int ky = tp / p.kw, kx = tp - ky * p.kw;
+          if ((unsigned)(iy0 + ky) < (unsigned)p.Hi && (unsigned)(ix0 + kx) < (unsigned)p.Wi) mk |= 1 << tp;
+        }
+      }
+      x_tmask[t] = mk;
+      x_voff[t] = v;
+      continue;
+    }
     if (m < p.M) {
       v = (unsigned)((m * p.x_cstride + p.x_coff) * 2) + swz;
       if (p.nc2) {
@@ -128,11 +149,19 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
       }
     }
     x_voff[t] = v;
-    x2_voff[t] = v2;
+    x2_voff[TAPS ? 0 : t] = v2;
   }
   auto issue_x = [&](int c, int buf) {            // chunk c of the K walk: x's chunks, then x2's
     char* dst = smem + buf * XB;
-    if (c < p.nc1) {
+    if constexpr (TAPS) {
+      const int tap = c / p.cpt, cc = c - tap * p.cpt;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const unsigned delta = (unsigned)(((ky * p.Wi + kx) * p.x_cstride) * 2 + cc * ROWB);
+#pragma unroll
+      for (int t = 0; t < LX; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16,
+                                                 ((x_tmask[t] >> tap) & 1) ? x_voff[t] + delta : kOOB, 0, 0, 0);
+    } else if (c < p.nc1) {
 #pragma unroll
       for (int t = 0; t < LX; ++t)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x_voff[t], c * ROWB, 0, 0);
@@ -700,9 +729,14 @@ struct CdPlan {
 
 static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
   if (!d) return FT_ERR_INVALID_ARG;
-  if (d->dtype != FT_F16 || d->transposed || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return FT_ERR_UNSUPPORTED;
+  if (d->dtype != FT_F16 || d->transposed) return FT_ERR_UNSUPPORTED;
+  const bool taps = d->kh != 1 || d->kw != 1;
+  if (taps) {        // the gather form: 3x3, stride 1 or 2, pad 1, no second input, no residual
+    if (d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->x2_cin || d->has_residual) return FT_ERR_UNSUPPORTED;
+    if (d->Ho != (d->Hi + 2 - 3) / d->stride + 1 || d->Wo != (d->Wi + 2 - 3) / d->stride + 1) return FT_ERR_INVALID_ARG;
+  } else if (d->stride != 1 || d->pad != 0) return FT_ERR_UNSUPPORTED;
   if (d->tail_cout || d->pool || d->x_wpitch || d->out_layout != FT_LAYOUT_NHWC) return FT_ERR_UNSUPPORTED;
-  if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
+  if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || (!taps && (d->Ho != d->Hi || d->Wo != d->Wi))) return FT_ERR_UNSUPPORTED;
   if (d->x_coff % 8 || d->x_cstride % 8 || d->y_coff % 8 || d->y_cstride % 8 || d->Cout % 64) return FT_ERR_UNSUPPORTED;
   if (d->x_cstride < d->x_coff + d->Cin || d->y_cstride < d->y_coff + d->Cout) return FT_ERR_INVALID_ARG;
   if (d->has_residual && (d->x2_cin || d->res_coff % 8 || d->res_cstride % 8)) return FT_ERR_UNSUPPORTED;
@@ -710,7 +744,7 @@ static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
                     d->Wo != (d->x2_wi - 1) / d->x2_stride + 1)) return FT_ERR_UNSUPPORTED;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const long long lim = 1LL << 31;
-  if (M * d->x_cstride * 2 >= lim || M * d->y_cstride * 2 >= lim || (d->has_residual && M * d->res_cstride * 2 >= lim) ||
+  if ((long long)d->N * d->Hi * d->Wi * d->x_cstride * 2 >= lim || M * d->y_cstride * 2 >= lim || (d->has_residual && M * d->res_cstride * 2 >= lim) ||
       (d->x2_cin && (long long)d->N * d->x2_hi * d->x2_wi * d->x2_cstride * 2 >= lim)) return FT_ERR_UNSUPPORTED;
   const int npt = (int)((M + 95) / 96);
   static const int force = getenv("FT_CD_KSPLIT") ? atoi(getenv("FT_CD_KSPLIT")) : 0;
@@ -725,13 +759,13 @@ static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
   if (force == 1 && a_ok) ks = 1;
   if (force == 4 && b_ok) ks = 4;
   const int ck = ks == 1 ? 64 : 256;
-  *out = CdPlan{ks, d->Cin / ck, d->x2_cin / ck, npt, d->Cout / (ks == 1 ? 256 : 64)};
+  *out = CdPlan{ks, d->kh * d->kw * (d->Cin / ck), d->x2_cin / ck, npt, d->Cout / (ks == 1 ? 256 : 64)};
   return FT_OK;
 }
 
-template <int KSPLIT, bool HAS_RES, int NCH>
+template <int KSPLIT, bool HAS_RES, int NCH, bool TAPS = false>
 static int cd_launch(const CdParams& p, hipStream_t s) {
-  auto k = conv_direct_kernel<KSPLIT, HAS_RES, NCH>;
+  auto k = conv_direct_kernel<KSPLIT, HAS_RES, NCH, TAPS>;
   constexpr int lds = CdGeom<KSPLIT>::LDS_BYTES;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -743,6 +777,21 @@ static int cd_launch(const CdParams& p, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3(p.npt * p.ncb), dim3(256), lds, s, p);
   FT_LAUNCH_CHECK("conv_direct_kernel");
   return FT_OK;
+}
+
+template <int KSPLIT>
+static int cd_dispatch_taps(const CdParams& p, hipStream_t s) {
+  if (KSPLIT == 1) {
+    switch (p.nc1) {   // 3x3 on 256 channels in 64-channel chunks; longer walks take the run-time loop
+      case 36: return cd_launch<KSPLIT, false, 36, true>(p, s);
+      default: return cd_launch<KSPLIT, false, 0, true>(p, s);
+    }
+  }
+  switch (p.nc1) {     // 3x3 on 256 / 512 channels in 256-channel chunks (ResNet layer3.0 / layer4.0 conv2, FlowNet conv4 .. conv5_1)
+    case 9: return cd_launch<KSPLIT, false, 9, true>(p, s);
+    case 18: return cd_launch<KSPLIT, false, 18, true>(p, s);
+    default: return cd_launch<KSPLIT, false, 0, true>(p, s);
+  }
 }
 
 template <int KSPLIT, bool HAS_RES>
@@ -773,27 +822,22 @@ static int cd_dispatch(const CdParams& p, hipStream_t s) {
 extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;
-  if (d && d->kh == 3) return ft::c3_plan(d, &p3);
+  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return FT_OK;     // whole small maps; other 3x3s: the gather form
   return ft::cd_plan(d, &pl);
 }
 
 extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
   ft::CdPlan pl;
-  if (d && d->kh == 3) {
-    ft::C3Plan p3;
-    if (ft::c3_plan(d, &p3) != FT_OK) return 0;
-    return (long long)p3.ncb * 4 * 9 * p3.spt * 8192;
-  }
+  ft::C3Plan p3;
+  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return (long long)p3.ncb * 4 * 9 * p3.spt * 8192;
   if (ft::cd_plan(d, &pl) != FT_OK) return 0;
   return (long long)pl.ncb * (pl.nc1 + pl.nc2) * 32768;
 }
 
 extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, int kpad, int cout_pad, void* wstream, ft_stream_t stream) {
   using namespace ft;
-  if (d && d->kh == 3) {
-    C3Plan p3;
-    const int st3 = c3_plan(d, &p3);
-    if (st3 != FT_OK) return st3;
+  C3Plan p3;
+  if (d && d->kh == 3 && c3_plan(d, &p3) == FT_OK) {
     if (!w_packed || !wstream || kpad < 9 * d->Cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
     const int total = p3.ncb * 4 * 9 * p3.spt * 512;
     hipLaunchKernelGGL(c3_pack_kernel<2>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const half_t*>(w_packed),
@@ -804,7 +848,7 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
   CdPlan pl;
   const int st = cd_plan(d, &pl);
   if (st != FT_OK) return st;
-  if (!w_packed || !wstream || kpad < d->Cin + d->x2_cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
+  if (!w_packed || !wstream || kpad < d->kh * d->kw * d->Cin + d->x2_cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
   const int nchunk = pl.nc1 + pl.nc2;
   const int total = pl.ncb * nchunk * 2048;
   hipStream_t s = as_stream(stream);
@@ -821,10 +865,8 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
 extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const void* wstream, const float* scale, const float* shift,
                                   const void* residual, void* y, ft_stream_t stream) {
   using namespace ft;
-  if (d && d->kh == 3) {
-    C3Plan p3;
-    const int st3 = c3_plan(d, &p3);
-    if (st3 != FT_OK) return st3;
+  C3Plan p3;
+  if (d && d->kh == 3 && c3_plan(d, &p3) == FT_OK) {
     if (!x || !wstream || !y) return FT_ERR_INVALID_ARG;
     C3Params q{};
     q.x = static_cast<const char*>(x);
@@ -858,9 +900,11 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
   p.HqWq = d->Ho * d->Wo; p.Wq = d->Wo;
   p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
   p.Cout = d->Cout; p.act = d->act; p.slope = d->slope;
-  p.x_bytes = (unsigned)((size_t)p.M * d->x_cstride * 2);
+  p.x_bytes = (unsigned)((size_t)d->N * d->Hi * d->Wi * d->x_cstride * 2);
   p.y_bytes = (unsigned)((size_t)p.M * d->y_cstride * 2);
   p.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+  const bool taps = d->kh != 1;
+  p.cpt = d->Cin / (pl.ksplit == 1 ? 64 : 256); p.kw = d->kw; p.Hi = d->Hi; p.Wi = d->Wi; p.stride = d->stride; p.pad = d->pad;
   if (d->x2_cin) {
     p.x2 = static_cast<const char*>(residual);
     p.x2_hi = d->x2_hi; p.x2_wi = d->x2_wi; p.x2_cstride = d->x2_cstride; p.x2_coff = d->x2_coff; p.x2_stride = d->x2_stride;
@@ -874,6 +918,7 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
   static const int dbg = getenv("FT_CD_DBG") ? atoi(getenv("FT_CD_DBG")) : 0;
   p.dbg = dbg;
   hipStream_t s = as_stream(stream);
+  if (taps) return pl.ksplit == 1 ? cd_dispatch_taps<1>(p, s) : cd_dispatch_taps<4>(p, s);
   if (pl.ksplit == 1) return d->has_residual ? cd_dispatch<1, true>(p, s) : cd_dispatch<1, false>(p, s);
   return d->has_residual ? cd_dispatch<4, true>(p, s) : cd_dispatch<4, false>(p, s);
 }

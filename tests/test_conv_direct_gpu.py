@@ -136,3 +136,53 @@ def test_direct_conv3x3_whole_maps_matches_oracle_and_igemm(hip_lib, case, monke
     assert err <= 2e-2 * scale, f"{name}: direct 3x3 vs oracle max abs err {err:.3e} (scale {scale:.2f})"
     diff = (outs[True] - outs[False]).abs()
     assert diff.max().item() <= 1e-2 * scale and (diff > 0).float().mean().item() < 0.05
+
+
+# name, N, H, W, Cin, Cout, stride, act, input channel offset
+GATHER_CASES = [
+    ("l3_entry_conv2", 64, 32, 24, 256, 256, 2, "relu", 0),      # layer3.0.conv2: K-split form, 9 chunks, 512 workgroups
+    ("l4_entry_conv2", 64, 16, 12, 512, 512, 2, "relu", 0),      # layer4.0.conv2: 18 chunks
+    ("flownet_conv4", 4, 48, 64, 256, 512, 2, "leaky", 32),      # N-tile 256 form, 36 chunks of 64 channels, LeakyReLU, input slice
+    ("stride1_big_map", 2, 20, 14, 256, 256, 1, "relu", 0),      # 3x3 / s1 on a map the whole-map kernel does not take
+    ("odd_map_s2", 3, 13, 9, 256, 256, 2, "relu", 0),            # odd sizes: Ho = 7, Wo = 5, ragged pixel tile
+    ("long_walk", 2, 8, 6, 1024, 256, 2, "relu", 0),             # 36 chunks of 256 channels: the run-time loop
+]
+
+
+@pytest.mark.parametrize("case", GATHER_CASES, ids=[c[0] for c in GATHER_CASES])
+def test_direct_conv3x3_gather_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
+    """3x3 convs (stride 1 or 2, pad 1; the entry blocks' conv2 with the stride on the 3x3, blocks.py:92-95, and FlowNetS's
+    conv4 .. conv6, FlowNetS.py:24-31) on the weight-streaming kernel: the pixel operand of a tap is a gather."""
+    name, N, H, W, Cin, Cout, stride, act, xoff = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 37
+    w = synth.normal(seed, name + ".w", (Cout, Cin, 3, 3), std=(2.0 / (9 * Cin)) ** 0.5)
+    bn = _bn(seed, name + ".bn", Cout)
+    x = synth.normal(seed, name + ".x", (N, Cin, H, W)).half().float()
+    pre = _bnf(F.conv2d(x, w, stride=stride, padding=1), bn)
+    want = F.relu(pre) if act == "relu" else F.leaky_relu(pre, 0.1)
+    Ho, Wo = want.shape[2], want.shape[3]
+    conv = FusedConv(w, stride=stride, pad=1, bn=bn, act=act, slope=0.1, dtype=dtype, device=dev, label=name)
+    xv = nchw_to_view(x, dtype, dev, cstride=Cin + xoff, coff=xoff)
+    if xoff:
+        xv.t[..., :xoff] = 7.0
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
+        y = ActView(torch.full((N, Ho, Wo, Cout + 32), 3.0, dtype=dtype, device=dev), Cout, 32)
+        prog = make_program()
+        conv.record(prog, xv, y)
+        prog.resolve_choices()      # recorded as [direct | implicit GEMM]: keep the first form
+        assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd_ws"), prog.calls[0][0]
+        run_program(prog)
+        outs[mode] = view_to_nchw(y)
+        assert torch.all(y.t[..., :32] == 3.0)
+        if mode:
+            y.t.fill_(5.0)
+            run_program(prog)
+            assert torch.equal(view_to_nchw(y), outs[True])
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[True] - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: direct 3x3 gather vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    diff = (outs[True] - outs[False]).abs()
+    assert diff.max().item() <= 1e-2 * scale and (diff > 0).float().mean().item() < 0.05

@@ -8,15 +8,17 @@ from flowtrack.pytorch_amd import hip_ops, synth
 from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv, Program
 N, H, W, Cin, Cout = (int(v) for v in sys.argv[1:6])
 with_res = len(sys.argv) > 6
+KK, SS = int(os.environ.get("K", "1")), int(os.environ.get("S", "1"))     # K=3 S=2: the gather form
 dev, dt = torch.device("cuda:0"), torch.float16
 hip_ops.CONV_DIRECT_MAX_PIXELS = 1 << 22
 bn = {"weight": torch.ones(Cout), "bias": torch.zeros(Cout), "running_mean": torch.zeros(Cout), "running_var": torch.ones(Cout), "eps": 1e-5}
-conv = FusedConv(synth.normal(1, "w", (Cout, Cin, 1, 1), std=(2.0 / Cin) ** 0.5), bn=bn, act="relu", dtype=dt, device=dev, label="l")
+conv = FusedConv(synth.normal(1, "w", (Cout, Cin, KK, KK), std=(2.0 / Cin) ** 0.5), stride=SS, pad=KK // 2, bn=bn, act="relu", dtype=dt, device=dev, label="l")
+Ho, Wo = conv.out_hw(H, W)
 x = ActView(torch.randn((N, H, W, Cin), device=dev).to(dt), Cin, 0)
-r = ActView(torch.randn((N, H, W, Cout), device=dev).to(dt), Cout, 0) if with_res else None
-y = ActView(torch.zeros((N, H, W, Cout), dtype=dt, device=dev), Cout, 0)
+r = ActView(torch.randn((N, Ho, Wo, Cout), device=dev).to(dt), Cout, 0) if with_res else None
+y = ActView(torch.zeros((N, Ho, Wo, Cout), dtype=dt, device=dev), Cout, 0)
 big_a = torch.empty(128 << 20, dtype=torch.uint8, device=dev); big_b = torch.empty_like(big_a)
-fl = 2.0 * N * H * W * Cin * Cout
+fl = 2.0 * N * Ho * Wo * Cin * Cout * KK * KK
 for mode in (True, False):
     hip_ops.CONV_DIRECT = mode
     prog = Program(torch.cuda.Stream())
