@@ -55,6 +55,12 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 }
 
 #define BNS_BARRIER() asm volatile("s_barrier" ::: "memory")
+#ifndef FT_BNS_STG
+#define FT_BNS_STG 1    // dev A/B: 0 = phase 3 of the direct kernel stores straight from the accumulator layout (no LDS staging tile)
+#endif
+#ifndef FT_BNS_DIRECT_AUX
+#define FT_BNS_DIRECT_AUX 0   // cache policy of those stores (plain: the L2 merges the 16-byte pieces of a line)
+#endif
 #ifndef FT_BNS_OVL
 #define FT_BNS_OVL 0    // dev A/B: phase 3 of the direct kernel hides a quarter's epilogue inside the next quarter's weight steps
 #endif
@@ -961,19 +967,28 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
           const int r = h * 8 + e;
           o[e] = (half_t)__builtin_fmaxf(A[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
         }
+#if FT_BNS_STG
         *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
+#else
+        // straight from the accumulator layout: the lane's 16 consecutive channels = two adjacent 16-byte stores
+        const unsigned vo = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + ch + 8 * h) * 2) : kOOB;
+        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo, q * P * 2, FT_BNS_DIRECT_AUX);
+#endif
       }
     };
     auto readout = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       const char* stg = smem + STG + (q & 1) * STGB;
+#if !FT_BNS_STG
+      return;
+#endif
 #pragma unroll
       for (int k = 0; k < NSTG; ++k) {
         const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
         if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
       }
     };
-    auto zero_set = [&](float16_t (&A)[2][MT2]) {
+    [[maybe_unused]] auto zero_set = [&](float16_t (&A)[2][MT2]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1037,10 +1052,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
         for (int j = 0; j < MT2; ++j) epi_piece(qc, i, j, acc);
       zero_acc();
+#if FT_BNS_STG
       // the two staging tiles alternate: a tile's previous readers (quarter q-2) are two barriers behind
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       BNS_BARRIER();
       readout(qc);
+#endif
     });
 #endif
   }
