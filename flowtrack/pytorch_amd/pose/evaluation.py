@@ -1,7 +1,8 @@
 """Heatmaps -> keypoints and the OKS metrics, host side.
 
 Mirrors lib/pose/utils/evaluation.py (max_preds :11-20, final_preds :22-35, compute_oks :61-82,
-nms_oks :84-101, eval_mAP :190-211) and the point transform of lib/pose/utils/transforms.py
+nms_oks :84-101, eval_mAP :190-211; nms_heatmap :37-59, calc_dists / dist_acc / accuracy :104-159 and compute_pck :164-175
+at the end of the file) and the point transform of lib/pose/utils/transforms.py
 (:173-226, rot = 0).  The per-map arg-max and the +/-0.25 px nudge — a Python double loop that
 indexes a GPU tensor element by element in the reference — run as one HIP launch
 (ft_heatmap_max_preds); the 3x3 inverse affine stays numpy float64 as in the reference.
@@ -98,3 +99,79 @@ def eval_mAP(pred, anno, ref_scale, delta):
     """Fraction of samples with OKS above each of the 10 COCO thresholds (evaluation.py:190-211)."""
     all_oks = np.concatenate([compute_oks(pred[i], anno[i], ref_scale[i], delta) for i in range(len(pred))])
     return [float(np.sum(all_oks > thr) / np.float32(all_oks.size)) for thr in np.linspace(0.5, 0.95, 10)]
+
+
+# ---- the remaining host-side helpers of lib/pose/utils/evaluation.py (training-time PCK read-out, peak NMS) -----------
+# Not on the inference hot path: they run as plain torch / numpy on whatever device the maps live on, as in the reference.
+def _argmax_xy(heatmap: torch.Tensor):
+    """Per-map arg-max -> (x, y, score) with torch-0.4 integer semantics (y = idx // W, first occurrence wins)."""
+    n, c, h, w = heatmap.shape
+    scores, idx = torch.max(heatmap.reshape(n, c, -1), -1)
+    x = torch.remainder(idx, w).float()
+    y = torch.div(idx, w, rounding_mode="floor").float()
+    return x, y, scores
+
+
+def nms_heatmap(heatmap: torch.Tensor, threshold: float = 0, window_size: int = 3) -> np.ndarray:
+    """Strongest local maximum of every map -> [N, K, 3] (x, y, score) (evaluation.py:37-59): a pixel survives when it
+    equals the max of its window (and is >= threshold when threshold > 0); the rest are zeroed before the arg-max."""
+    pad = (window_size - 1) // 2
+    max_map = torch.nn.functional.max_pool2d(heatmap, kernel_size=window_size, stride=1, padding=pad)
+    mask = torch.eq(heatmap, max_map)
+    if threshold > 0:
+        mask = mask & heatmap.ge(threshold)
+    x, y, scores = _argmax_xy(heatmap * mask.to(heatmap.dtype))
+    return torch.stack((x, y, scores), dim=2).cpu().numpy()
+
+
+def calc_dists(preds: np.ndarray, target: np.ndarray, normalize: np.ndarray) -> np.ndarray:
+    """[K, N] normalised distances, -1 where the target joint is not annotated (x or y < 1) (evaluation.py:104-116)."""
+    preds = np.asarray(preds, dtype=np.float32)
+    target = np.asarray(target, dtype=np.float32)
+    norm = np.asarray(normalize)[:, None, :]
+    d = np.linalg.norm(preds / norm - target / norm, axis=2).astype(np.float64)
+    annotated = (target[..., 0] >= 1) & (target[..., 1] >= 1)
+    return np.where(annotated, d, -1.0).T
+
+
+def dist_acc(dists: np.ndarray, thr: float = 0.5) -> float:
+    """Fraction of the counted distances (!= -1) below thr, or -1 when none is counted (evaluation.py:119-126)."""
+    counted = np.not_equal(dists, -1)
+    num = counted.sum()
+    return float(np.less(dists[counted], thr).sum() * 1.0 / num) if num > 0 else -1
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, hm_type: str = "gaussian", thr: float = 0.5):
+    """PCK between the arg-max of predicted and ground-truth heat maps (evaluation.py:130-159):
+    (acc [K + 1] with the mean in slot 0, mean accuracy, joints counted, predicted coords [N, K, 2])."""
+    n, c, h, w = output.shape
+    if hm_type != "gaussian":
+        raise ValueError("only hm_type='gaussian' is defined by the reference")
+
+    def coords_of(hm):
+        x, y, s = _argmax_xy(hm)
+        return (torch.stack((x, y), dim=2) * s.gt(0).float().unsqueeze(-1)).cpu().numpy()      # max_preds' threshold-0 mask
+    pred, tgt = coords_of(output), coords_of(target)
+    norm = np.ones((n, 2)) * np.array([h, w]) / 10
+    dists = calc_dists(pred, tgt, norm)
+    acc = np.zeros(c + 1)
+    total, cnt = 0.0, 0
+    for i in range(c):
+        acc[i + 1] = dist_acc(dists[i], thr)
+        if acc[i + 1] >= 0:
+            total += acc[i + 1]
+            cnt += 1
+    avg = total / cnt if cnt else 0
+    if cnt:
+        acc[0] = avg
+    return acc, avg, cnt, pred
+
+
+def compute_pck(pred: np.ndarray, anno: np.ndarray, ref_scale, threshold: float) -> np.ndarray:
+    """Per-joint PCK(h) (evaluation.py:164-175; the reference's +1 on the predicted joints — MATLAB-indexed annotations —
+    is kept)."""
+    pred, anno = np.asarray(pred), np.asarray(anno)
+    counted = anno[:, :, 2] > 0
+    dists = np.linalg.norm(pred[:, :, :2] + 1 - anno[:, :, :2], axis=2) / ref_scale
+    match = (dists <= threshold) * counted
+    return match.sum(0).astype(np.float32) / counted.sum(0)

@@ -193,3 +193,23 @@ def test_flownet2_css_oracle_wiring(oracle_lib):
     assert torch.allclose(c3[:, 7:8], torch.norm(c3[:, 3:5], dim=1, keepdim=True), atol=1e-6)
     assert torch.allclose(c3[:, 8:9], torch.norm(c3[:, 5:7], dim=1, keepdim=True), atol=1e-6)
     assert out.shape == (1, 2, 64, 64) and torch.isfinite(out).all()
+
+
+def test_remaining_evaluation_helpers_match_reference_golden():
+    """nms_heatmap / calc_dists / dist_acc / accuracy / compute_pck of lib/pose/utils/evaluation.py:37-59,104-175 against
+    outputs of the imported reference (tests/golden/make_eval_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_extra_golden.npz"))
+    # pose/evaluation.py imports the HIP arg-max from hip_ops at module level; these helpers do not use it
+    from flowtrack.pytorch_amd.pose import evaluation as ev
+    hm = torch.from_numpy(g["nms_heatmap"])
+    for thr, win in ((0, 3), (0.5, 3), (0, 5)):
+        got = ev.nms_heatmap(hm, threshold=thr, window_size=win)
+        assert np.array_equal(got, g[f"nms_thr{thr}_win{win}"]), (thr, win)
+    dists = ev.calc_dists(g["cd_preds"], g["cd_target"], g["cd_norm"])
+    assert np.allclose(dists, g["cd_dists"], rtol=0, atol=1e-6) and np.array_equal(dists == -1, g["cd_dists"] == -1)
+    assert np.allclose([ev.dist_acc(dists[c]) for c in range(dists.shape[0])], g["cd_acc"])
+    assert ev.dist_acc(np.full((5,), -1.0)) == float(g["cd_acc_all_skipped"]) == -1
+    assert np.allclose(ev.compute_pck(g["pck_pred"], g["pck_anno"], g["pck_scale"], 0.5), g["pck"])
+    acc, avg, cnt, pred = ev.accuracy(torch.from_numpy(g["acc_out"]), torch.from_numpy(g["acc_tgt"]))
+    assert np.allclose(acc, g["acc"]) and abs(avg - float(g["acc_avg"])) < 1e-12 and cnt == int(g["acc_cnt"])
