@@ -8,6 +8,8 @@
 // bounds test, and the in-network form reads the NHWC activations the conv stack already produces.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ft_common.h"
 
 namespace ft {
@@ -416,6 +418,239 @@ __global__ __launch_bounds__(256, 1) void correlation_mfma_rows_kernel(const hal
 #endif
 }
 
+// ---- the rows kernel for maps up to 64 pixels wide ---------------------------------------------------------------------
+// Shipped form (STAGED = false, NRS = 2): 64-column ring slots, EIGHT waves — R = 4 output rows per workgroup, the upper
+// two owned by waves 4..7 with their own f1 fragments on the same ring — and the rows kernel's 2-byte band stores:
+// 61.9-63.5 us at [16,256,48,64] against 65.6-67.3 for the 104-column, four-wave rows kernel (same box).
+// The STAGED form below was the attempt to get rid of the 1008 two-byte stores per lane; it is correct and slower:
+// At W <= 64 (FlowNetC at 512x384: 48 x 64) only 64 of the 104 window columns of an f2 row exist, so a ring slot shrinks
+// from 52 to 32 KiB (window columns outside the image read one shared zero row) and the 64 KiB that frees hold a TRANSPOSE
+// tile per output row: the band products of GD = 8 consecutive dy displacements are written (ds_write_b16, band lanes
+// only) into [64 pixels][8 x 21] fp16 = 336 contiguous, 16-byte-aligned bytes of each pixel's 441-channel run, and leave
+// as whole 16-byte pieces (21 per pixel) when the group is complete: ~50 b128 stores per thread instead of 1008 two-byte
+// stores per lane, at the price of one extra barrier per flush (9 per workgroup).  The last group holds 5 x 21 values =
+// 210 bytes: thirteen pieces and one 2-byte store.  Same MFMA order and fp32 -> fp16 step as the rows kernel.
+// Every step waits with vmcnt(NL): loads return in order among loads, so "at most NL vector-memory operations in flight"
+// means row jj has landed whatever the stores of the previous flush are doing.
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void corr_unroll(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    corr_unroll<N, I + 1>(f);
+  }
+}
+
+// STAGED = false keeps the rows kernel's 2-byte band stores (and its store-counting waits) on the narrow ring: measured at
+// [16,256,48,64], the transpose costs more in ds_write_b16 issue than it saves in stores (75 us staged; 86 us with a branch
+// per band register instead of the scratch-slot select; 63.5 us unstaged with four waves, 62 us with eight).  Pulling the f2
+// window straight into registers instead of through the ring (each wave uses its own 32 window pixels) was also tried with
+// the staged band: 87 us.
+// NRS = 2: eight waves, the second four take the upper half of the R output rows with their own f1 fragments and read the
+// same ring: two waves per SIMD, one's band stores issue while the other's products run on the matrix pipe.
+template <int KS, int R, int DRAD, bool STAGED, int NRS>
+__global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
+                                                                          half_t* __restrict__ y, int H, int W, unsigned f2_bytes,
+                                                                          unsigned y_bytes, int f_cstride, int y_cstride, int y_coff,
+                                                                          int act, float slope, int ngy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = KS * 16, ROWB = C * 2;
+  constexpr int D = 2 * DRAD + 1, WROWS = 64 + 4 * DRAD;
+  constexpr int NJ = R + 2 * DRAD;          // f2 rows of the class this workgroup walks
+  constexpr int RW = R / NRS;               // output rows per wave
+  constexpr int SLOT = 64 * ROWB, NL = SLOT / 1024 / (4 * NRS);
+  static_assert(R % NRS == 0 && (NRS == 1 || !STAGED), "row sets");
+  constexpr int ZROW = 3 * SLOT, STG = ZROW + ROWB;
+  constexpr int GD = 8;
+  constexpr int PROW = GD * D * 2;          // bytes of a pixel's run per group
+  constexpr int TILE = 64 * PROW;           // the transpose tile of one output row
+  constexpr int DUMMY = STG + R * TILE;     // 128 bytes: where the lanes outside the band write
+  static_assert(PROW % 16 == 0 && (!STAGED || DUMMY + 128 <= 160 * 1024) && ROWB == 512 && NL * 4 * NRS * 1024 == SLOT, "shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = wave & 1, jt = (wave >> 1) & 1, rs = wave >> 2;
+  const int c = lane & 31, h = lane >> 5;
+  int n, q, i0;
+  {
+    const int total = gridDim.x, b = blockIdx.x;
+    const int qq = total >> 3, rr = total & 7, xcd = b & 7, loc = b >> 3;
+    const int logical = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+    const int gy = logical % ngy;
+    n = logical / ngy;
+    q = gy & 1;
+    i0 = (gy >> 1) * R;
+  }
+  const int Hq = (H - q + 1) >> 1;          // rows of this parity class
+  const float inv_c = 1.0f / (float)C;
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // f1 fragments of the R rows (operand A: row = f1 pixel of this column parity, k = channel)
+  uint4_t a[RW][KS];
+  {
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(f1), 0, f2_bytes, 0x00020000);
+    const int x = 2 * c + par;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int yy = 2 * (i0 + rs * RW + r) + q;
+      const unsigned voff = (x < W && yy < H) ? (unsigned)((((n * H + yy) * W + x) * f_cstride + h * 8) * 2) : kOOB;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a[r][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, voff, s * 32, 0);
+    }
+  }
+  // operand B: column = window pixel 64*jt + 2*c + par = image column x2 (ring row x2), the zero row outside the image
+  int wr = 64 * jt + 2 * c + par;
+  wr = wr < WROWS ? wr : WROWS - 1;
+  const int x2 = wr - 2 * DRAD;
+  const bool in_img = (unsigned)x2 < (unsigned)W;
+  const int b_base = in_img ? x2 * ROWB : ZROW - 0;      // slot-relative for image columns; ZROW is absolute (see b_abs)
+  const int b_key = in_img ? (x2 >> 1) & 15 : 0;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(f2), 0, f2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
+  // loader lanes: wave-load i = t*4 + wave covers ring rows 2i, 2i+1; XOR swizzle on the source chunk
+  unsigned l_voff[NL];
+#pragma unroll
+  for (int t = 0; t < NL; ++t) {
+    const int i = t * 4 * NRS + wave;
+    const int row = i * 2 + (lane >> 5), pos = lane & 31;
+    const int lc = pos ^ ((row >> 1) & 15);
+    l_voff[t] = row < W ? (unsigned)(((n * H) * W + row) * f_cstride * 2 + lc * 16) : kOOB;
+  }
+  const int row_bytes = W * f_cstride * 2;
+  auto issue = [&](int jj, int slot) {       // always NL loads per wave: rows outside the image / past the walk are out of range
+    const int j = i0 - DRAD + jj;
+    const bool row_ok = jj < NJ && (unsigned)j < (unsigned)Hq;
+    const int soff = row_ok ? (2 * j + q) * row_bytes : 0;
+#pragma unroll
+    for (int t = 0; t < NL; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + slot * SLOT + (t * 4 * NRS + wave) * 1024), 16,
+                                               row_ok ? l_voff[t] : kOOB, soff, 0, 0);
+  };
+  // band lanes: accumulator register g of lane (c, h) = f1 pixel rr = G(g) + 4h (of this column parity) x window column c
+  // -> displacement index dxi = c + 32*jt - rr, kept when 0 <= dxi < D and the pixel lies inside the image
+  const int dxi0 = c + 32 * jt - 4 * h;
+  const int lane_base = STG + (8 * h + par) * PROW + dxi0 * 2;     // byte of (pixel 2*(4h) + par, dxi0) of tile 0
+  int vmask = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int G = (g & 3) + 8 * (g >> 2);
+    if ((unsigned)(dxi0 - G) < (unsigned)D && 2 * (G + 4 * h) + par < W) vmask |= 1 << g;
+  }
+  // act(v) = max(v, s*v) for s in [0, 1] (relu: 0, leaky: slope, none: 1); the 1/C of the correlation rides along
+  const float k_pos = inv_c, k_neg = inv_c * (act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f));
+  const int yrow_bytes = W * y_cstride * 2;
+  unsigned s_voff[STAGED ? 1 : 16];              // !STAGED: the band leaves as 2-byte stores in the accumulator layout
+  if constexpr (!STAGED) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int G = (g & 3) + 8 * (g >> 2);
+      const int x = 2 * (G + 4 * h) + par;
+      s_voff[g] = ((vmask >> g) & 1) ? (unsigned)(((n * H) * W + x) * y_cstride + y_coff + dxi0 - G) * 2u : kOOB;
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting
+  if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
+  issue(0, 0);
+  issue(1, 1);
+  corr_unroll<NJ>([&](auto jc) {
+    constexpr int jj = decltype(jc)::value;
+    constexpr int slot = jj % 3;
+    // row jj has landed (this wave's share).  !STAGED: behind it row jj+1 and the 16*R band stores of the previous step may fly
+    if constexpr (STAGED || jj == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL + 16 * RW) : "memory");
+    asm volatile("s_barrier" ::: "memory");               // everyone's has; everyone is done reading the slot refilled now
+    issue(jj + 2, (jj + 2) % 3);
+    const int j = i0 - DRAD + jj;
+    const bool row_ok = (unsigned)j < (unsigned)Hq;
+    uint4_t b[KS];
+    if (row_ok) {
+      const char* st = smem + (in_img ? slot * SLOT : 0) + b_base;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const uint4_t*>(st + (((2 * s + h) ^ b_key) << 4));
+    }
+    corr_unroll<RW>([&](auto rc) {
+      constexpr int rw = decltype(rc)::value;
+      constexpr int r = rw;                              // STAGED (NRS = 1): the row itself
+      constexpr int dyi = jj - r;                        // f2 row j is displacement dyi - DRAD of output row i0 + r
+      if constexpr (!STAGED) {
+        // the rows kernel's form: always 16 stores per (step, row) so that the waits can count them
+        const int r = rs * RW + rw;                      // wave-uniform
+        const int dyi = jj - r;
+        const bool live = dyi >= 0 && dyi < D && i0 + r < Hq;
+        if (live) {
+          float16_t acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          if (row_ok) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[rw][s]), __builtin_bit_cast(half8_t, b[s]), acc, 0, 0, 0);
+          }
+          const int soff = (2 * (i0 + r) + q) * yrow_bytes + dyi * D * 2;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const half_t hv = (half_t)__builtin_fmaxf(acc[g] * k_pos, acc[g] * k_neg);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rsrc_y, s_voff[g], soff, 0);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rsrc_y, kOOB, 0, 0);
+        }
+      } else if constexpr (dyi >= 0 && dyi < D) {
+        if (i0 + r < Hq) {                               // workgroup-uniform
+          constexpr int gg = dyi / GD, dslot = dyi % GD;
+          float16_t acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          if (row_ok) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[r][s]), __builtin_bit_cast(half8_t, b[s]), acc, 0, 0, 0);
+          }
+          char* tile = smem + r * TILE + dslot * D * 2 + lane_base;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int G = (g & 3) + 8 * (g >> 2);
+            const float v = __builtin_fmaxf(acc[g] * k_pos, acc[g] * k_neg);   // act(v / C), slopes in [0, 1]
+            // lanes outside the band write a scratch slot behind the tiles: straight-line code (a branch per register would
+            // fence the next product's MFMAs off from these writes)
+            char* dst = ((vmask >> g) & 1) ? tile + G * (2 * PROW - 2) : smem + DUMMY + lane * 2;
+            *reinterpret_cast<half_t*>(dst) = (half_t)v;
+          }
+          constexpr bool last_of_group = dslot == GD - 1 || dyi == D - 1;
+          if constexpr (last_of_group) {
+            constexpr int gbytes = (dyi == D - 1 ? D - gg * GD : GD) * D * 2;   // bytes of the group per pixel
+            constexpr int npc = gbytes / 16, tail = gbytes % 16;                 // whole 16-byte pieces, bytes behind them
+            static_assert(tail == 0 || tail == 2, "tail");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");         // every wave's band writes of this group sit in the tile
+            const char* src = smem + STG + r * TILE;
+            const int soff = (2 * (i0 + r) + q) * yrow_bytes + (y_coff + gg * GD * D) * 2;
+#pragma unroll
+            for (int k = 0; k < (64 * npc + 255) / 256; ++k) {
+              const int idx = tid + 256 * k;
+              const int px = idx / npc, pc = idx - px * npc;
+              const uint4_t v = *reinterpret_cast<const uint4_t*>(src + (px < 64 ? px : 63) * PROW + pc * 16);
+              const unsigned vo = (px < 64 && px < W) ? (unsigned)((((n * H) * W + px) * y_cstride) * 2 + pc * 16) : kOOB;
+              __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, soff, FT_YSTORE_BUF_AUX);
+            }
+            if constexpr (tail == 2) {
+              const int px = tid;
+              const unsigned short v = px < 64 ? *reinterpret_cast<const unsigned short*>(src + px * PROW + npc * 16) : (unsigned short)0;
+              const unsigned vo = (px < 64 && px < W) ? (unsigned)((((n * H) * W + px) * y_cstride) * 2 + npc * 16) : kOOB;
+              __builtin_amdgcn_raw_buffer_store_b16(v, rsrc_y, vo, soff, 0);
+            }
+          }
+        }
+      }
+    });
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the (all out-of-range) look-ahead rows of the last steps
+#endif
+}
+
 // Workgroup b of a 1-D grid runs on XCD b % 8 and every XCD has its own L2.  The gather kernels below read a 2 x 2
 // neighbourhood around a displaced position: with the plain blockIdx order the rows one workgroup touches are also touched
 // by its neighbours on seven other XCDs and every L2 fetches them again (PMC: 2.7-2.9 x the algorithmic read bytes).  This
@@ -674,6 +909,29 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
     const int drad = max_displacement / 2;
     const unsigned long long y_bytes = (unsigned long long)B * H * W * y_cstride * 2;
     static const bool no_rows = getenv("FT_CORR_ROWS") && atoi(getenv("FT_CORR_ROWS")) == 0;   // dev A/B: one row per workgroup
+    static const bool no_t = getenv("FT_CORR_NARROW") && atoi(getenv("FT_CORR_NARROW")) == 0;   // dev A/B: the 104-column ring
+    if (drad == 10 && y_bytes < (1ull << 31) && !no_rows && !no_t && W <= 64 && y_coff % 8 == 0 && y_cstride % 8 == 0) {
+      // FlowNetC's shape on maps up to 64 wide: 64-column ring slots (FT_CORR_STAGED=1: band transposed through LDS)
+      static const bool stg = getenv("FT_CORR_STAGED") && atoi(getenv("FT_CORR_STAGED")) == 1;   // dev A/B: band through LDS
+      static const bool w8 = !(getenv("FT_CORR_WAVES") && atoi(getenv("FT_CORR_WAVES")) == 4);     // dev A/B: four waves, R = 3
+      const int R = (stg || !w8) ? 3 : 4;
+      auto k = stg ? correlation_mfma_rows64_kernel<16, 3, 10, true, 1>
+                   : (w8 ? correlation_mfma_rows64_kernel<16, 4, 10, false, 2> : correlation_mfma_rows64_kernel<16, 3, 10, false, 1>);
+      constexpr size_t ldst = 3 * 64 * 512 + 512 + 3 * 64 * (8 * 21 * 2) + 128;
+      static bool raised[64] = {};
+      int dev = 0;
+      FT_HIP_CHECK(hipGetDevice(&dev));
+      if (dev < 0 || dev >= 64 || !raised[dev]) {
+        FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+        if (dev >= 0 && dev < 64) raised[dev] = true;
+      }
+      const int ngy = 2 * ceil_div((H + 1) / 2, R);
+      hipLaunchKernelGGL(k, dim3(ngy * B), dim3((!stg && w8) ? 512 : 256), ldst, as_stream(stream), static_cast<const half_t*>(f1),
+                         static_cast<const half_t*>(f2), static_cast<half_t*>(y), H, W, (unsigned)f_bytes, (unsigned)y_bytes,
+                         f_cstride, y_cstride, y_coff, act, slope, ngy);
+      FT_LAUNCH_CHECK("correlation_mfma_rows64_kernel");
+      return FT_OK;
+    }
     if (drad == 10 && y_bytes < (1ull << 31) && !no_rows) {     // FlowNetC's shape: 3 output rows per workgroup
       constexpr int R = 3;
       auto k = correlation_mfma_rows_kernel<16, R, 10>;

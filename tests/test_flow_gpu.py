@@ -57,8 +57,8 @@ def test_correlation_nchw(hip_lib, oracle_lib, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
-@pytest.mark.parametrize("shape", [(1, 256, 12, 16), (2, 64, 9, 37), (2, 256, 24, 64), (1, 256, 5, 83)],
-                         ids=["c256", "ragged", "c256_w64", "c256_w83"])
+@pytest.mark.parametrize("shape", [(1, 256, 12, 16), (2, 64, 9, 37), (2, 256, 24, 64), (1, 256, 5, 83), (2, 256, 7, 40), (3, 256, 48, 64)],
+                         ids=["c256", "ragged", "c256_w64", "c256_w83", "c256_w40_hodd", "c256_flownetc_map"])
 def test_correlation_nhwc_fused(hip_lib, oracle_lib, dtype, shape):
     """in-network form: NHWC features -> LeakyReLU'd cost volume in a channel slice of the concat buffer."""
     B, C, H, W = shape
