@@ -722,8 +722,159 @@ __global__ __launch_bounds__(256) void cd_pack_kernel(const half_t* __restrict__
   out[idx] = v;
 }
 
+
+// ---- 1x1, K = 256, MANY pixels (layer2.0.conv1: 256 -> 128 on 196 k pixels at batch 64): weight-stationary, persistent -----
+// That layer is HBM-bound (150 MB) and ran at 3.1 TB/s on the tiled kernels: a tile's life there is load -> 4 K-steps ->
+// store, and the per-tile ramps do not overlap well.  Here one workgroup per CU keeps its 128 x 256 weight block in
+// REGISTERS for the whole launch (each wave: 2 channel tiles x 16 K16 slices = 128 VGPRs, fragment-ordered stream) and
+// walks pixel tiles of 128: the next tile's 64 KiB stream into the other half of LDS (whole 512-byte pixel rows, DMA) while
+// the current one is multiplied; the results leave straight from the accumulator layout (a lane owns 16 consecutive
+// channels: two adjacent 16-byte stores; the L2 merges the four pieces of a line, so these are plain, not write-through).
+struct CsParams {
+  const char* x;
+  char* y;
+  const char* ws;
+  const float* scale;
+  const float* shift;
+  int M, ntiles;
+  int x_cstride, x_coff, y_cstride, y_coff;
+  int Cout, act;
+  float slope;
+  unsigned x_bytes, y_bytes, ws_bytes;
+};
+
+__global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const CsParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BP = 128, ROWB = 512, SLOTB = BP * ROWB, LX = SLOTB / 1024 / 4, NS = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wp = wave >> 1;          // channel half (2 tiles of 32) x pixel half (2 tiles of 32)
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb = blockIdx.y;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // the weight block of this wave: fragment (channel tile 2*wc + i, slice s) = 1 KiB at ((cb*4 + 2*wc + i) * 16 + s) KiB
+  uint4_t a[2][NS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      a[i][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, ((cb * 4 + 2 * wc + i) * NS + s) * 1024, 0);
+  // folded BN of the lane's 16 consecutive channels of each tile
+  float4_t sc[2][4], sh[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int ch = cb * 128 + (2 * wc + i) * 32 + 16 * lhi + 4 * g4;
+      const float4_t one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+      sc[i][g4] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + ch) : one;
+      sh[i][g4] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + ch) : zero;
+    }
+  const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
+
+  // loader lanes: wave load (t*4 + wave) covers tile rows 2*(t*4 + wave), +1; XOR swizzle of the low 4 chunk bits on the source
+  int l_row[LX];
+  unsigned l_off[LX];
+#pragma unroll
+  for (int t = 0; t < LX; ++t) {
+    const int row = (t * 4 + wave) * 2 + (lane >> 5), pos = lane & 31;
+    l_row[t] = row;
+    l_off[t] = (unsigned)((row * p.x_cstride + p.x_coff) * 2 + ((pos ^ (row & 15)) << 4));
+  }
+  auto issue = [&](int tile, int slot) {            // always LX loads: tiles past the end / rows past M read out of range
+    const int m0 = tile * BP;
+    const bool tile_ok = tile < p.ntiles;
+    const int soff = tile_ok ? m0 * p.x_cstride * 2 : 0;
+#pragma unroll
+    for (int t = 0; t < LX; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + slot * SLOTB + (t * 4 + wave) * 1024), 16,
+                                               (tile_ok && m0 + l_row[t] < p.M) ? l_off[t] : kOOB, soff, 0, 0);
+  };
+  int b_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wp * 64 + j * 32 + l31;
+    b_off[j] = row * ROWB + ((lhi ^ (row & 15)) << 4);
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights and tables sit in registers before the tile loads are counted
+  int tile = blockIdx.x;
+  issue(tile, 0);
+  for (int k = 0; tile < p.ntiles; ++k, tile += gridDim.x) {
+    const int slot = k & 1;
+    // this tile has landed (this wave's share): behind it only the 8 stores of the previous tile may fly
+    if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");          // everyone's share has; everyone is done reading the other half
+    issue(tile + gridDim.x, slot ^ 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const char* xb = smem + slot * SLOTB;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      uint4_t fx[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fx[j] = *reinterpret_cast<const uint4_t*>(xb + (b_off[j] ^ (s << 5)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[i][s]), __builtin_bit_cast(half8_t, fx[j]),
+                                                             acc[i][j], 0, 0, 0);
+    }
+    // the loads of the next tile were issued before these stores: at the next wait they are the older operations
+    const int m0 = tile * BP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wp * 64 + j * 32 + l31;
+        const unsigned vo = m < p.M ? (unsigned)((m * p.y_cstride + p.y_coff + cb * 128 + (2 * wc + i) * 32 + 16 * lhi) * 2) : kOOB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = h * 8 + e;
+            const float v = acc[i][j][r] * sc[i][r >> 2][r & 3] + sh[i][r >> 2][r & 3];
+            o[e] = (half_t)__builtin_fmaxf(v, v * act_k);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo, h * 16, 0);
+        }
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of the last trip must not outlive the workgroup's LDS
+#endif
+}
+
+// fragment-ordered weight block for conv1x1_stream_kernel: [channel block 128][tile 4][slice 16][lane] x 16 bytes
+__global__ __launch_bounds__(256) void cs_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int ncb, int kpad, int cout_pad) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncb * 4 * 16 * 64) return;
+  const int lane = idx & 63;
+  int f = idx >> 6;
+  const int sl = f & 15; f >>= 4;
+  const int tl = f & 3;
+  const int cb = f >> 2;
+  const int co = cb * 128 + tl * 32 + cd_sigma(lane & 31), k = sl * 16 + 8 * (lane >> 5);
+  uint4_t v = {0u, 0u, 0u, 0u};
+  if (co < cout_pad && k < kpad) v = *reinterpret_cast<const uint4_t*>(w + (size_t)co * kpad + k);
+  out[idx] = v;
+}
+
 struct CdPlan {
-  int ksplit;          // 1 or 4
+  int ksplit;          // 1 or 4; 0 = the persistent weight-stationary form (conv1x1_stream_kernel)
   int nc1, nc2, npt, ncb;
 };
 
@@ -746,6 +897,11 @@ static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
   const long long lim = 1LL << 31;
   if ((long long)d->N * d->Hi * d->Wi * d->x_cstride * 2 >= lim || M * d->y_cstride * 2 >= lim || (d->has_residual && M * d->res_cstride * 2 >= lim) ||
       (d->x2_cin && (long long)d->N * d->x2_hi * d->x2_wi * d->x2_cstride * 2 >= lim)) return FT_ERR_UNSUPPORTED;
+  if (!taps && M > 65536) {       // many pixels: only the weight-stationary form (K = 256, 128-channel blocks, plain epilogue)
+    if (d->Cin != 256 || d->Cout % 128 || d->x2_cin || d->has_residual) return FT_ERR_UNSUPPORTED;
+    *out = CdPlan{0, 4, 0, (int)((M + 127) / 128), d->Cout / 128};
+    return FT_OK;
+  }
   const int npt = (int)((M + 95) / 96);
   static const int force = getenv("FT_CD_KSPLIT") ? atoi(getenv("FT_CD_KSPLIT")) : 0;
   const bool a_ok = d->Cout % 256 == 0 && d->Cin % 64 == 0 && d->x2_cin % 64 == 0;
@@ -831,6 +987,7 @@ extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
   ft::C3Plan p3;
   if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return (long long)p3.ncb * 4 * 9 * p3.spt * 8192;
   if (ft::cd_plan(d, &pl) != FT_OK) return 0;
+  if (pl.ksplit == 0) return (long long)pl.ncb * 65536;
   return (long long)pl.ncb * (pl.nc1 + pl.nc2) * 32768;
 }
 
@@ -852,6 +1009,12 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
   const int nchunk = pl.nc1 + pl.nc2;
   const int total = pl.ncb * nchunk * 2048;
   hipStream_t s = as_stream(stream);
+  if (pl.ksplit == 0) {
+    hipLaunchKernelGGL(cs_pack_kernel, dim3(ceil_div(pl.ncb * 4096, 256)), dim3(256), 0, s, static_cast<const half_t*>(w_packed),
+                       static_cast<uint4_t*>(wstream), pl.ncb, kpad, cout_pad);
+    FT_LAUNCH_CHECK("cs_pack_kernel");
+    return FT_OK;
+  }
   if (pl.ksplit == 1)
     hipLaunchKernelGGL(cd_pack_kernel<1>, dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const half_t*>(w_packed),
                        static_cast<uint4_t*>(wstream), nchunk, pl.ncb, kpad, cout_pad);
@@ -888,6 +1051,29 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
   const int st = cd_plan(d, &pl);
   if (st != FT_OK) return st;
   if (!x || !wstream || !y || ((d->has_residual || d->x2_cin) && !residual)) return FT_ERR_INVALID_ARG;
+  if (pl.ksplit == 0) {
+    CsParams q{};
+    q.x = static_cast<const char*>(x);
+    q.y = static_cast<char*>(y);
+    q.ws = static_cast<const char*>(wstream);
+    q.scale = scale;
+    q.shift = shift;
+    q.M = d->N * d->Ho * d->Wo;
+    q.ntiles = pl.npt;
+    q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.y_cstride = d->y_cstride; q.y_coff = d->y_coff;
+    q.Cout = d->Cout; q.act = d->act; q.slope = d->slope;
+    q.x_bytes = (unsigned)((size_t)q.M * d->x_cstride * 2);
+    q.y_bytes = (unsigned)((size_t)q.M * d->y_cstride * 2);
+    q.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+    auto k = conv1x1_stream_kernel;
+    constexpr int lds = 2 * 128 * 512;
+    FT_RAISE_LDS(k, lds);
+    int gx = 256 / pl.ncb;
+    gx = gx < 1 ? 1 : (gx > pl.npt ? pl.npt : gx);
+    hipLaunchKernelGGL(k, dim3(gx, pl.ncb), dim3(256), lds, as_stream(stream), q);
+    FT_LAUNCH_CHECK("conv1x1_stream_kernel");
+    return FT_OK;
+  }
   CdParams p{};
   p.x = static_cast<const char*>(x);
   p.y = static_cast<char*>(y);

@@ -19,6 +19,8 @@ CASES = [
     ("ragged_pixels", 3, 7, 5, 256, 256, True, 4),           # 105 pixels: a ragged second pixel tile
     ("ragged_pixels_wide", 5, 9, 7, 320, 512, False, 1),     # K = 5 chunks (not a multiple of the ring), 315 pixels
     ("many_tiles", 64, 16, 12, 256, 1024, True, 1),          # 128 x 4 workgroups: two rounds on 256 CUs
+    ("l2_entry_conv1", 24, 64, 48, 256, 128, False, 0),      # > 65536 pixels, K = 256: the persistent weight-stationary form
+    ("stationary_ragged", 7, 97, 101, 256, 256, False, 0),   # 68579 pixels (ragged last tile), two channel blocks
 ]
 
 
@@ -60,7 +62,8 @@ def test_direct_conv1x1_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
         assert torch.all(y.t[..., :64] == 3.0), "channels outside the output slice were written"
         if mode:
             d = prog.conv_records[0][3]
-            assert hip_lib.ft_conv_direct_weight_bytes(d) == (Cout // (256 if ksplit == 1 else 64)) * (Cin // (64 if ksplit == 1 else 256)) * 32768
+            want_bytes = (Cout // 128) * 65536 if ksplit == 0 else (Cout // (256 if ksplit == 1 else 64)) * (Cin // (64 if ksplit == 1 else 256)) * 32768
+            assert hip_lib.ft_conv_direct_weight_bytes(d) == want_bytes
             y.t.fill_(5.0)
             run_program(prog)                      # determinism
             assert torch.equal(view_to_nchw(y), outs[True])
