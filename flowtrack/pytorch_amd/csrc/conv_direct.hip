@@ -743,14 +743,21 @@ struct CsParams {
   unsigned x_bytes, y_bytes, ws_bytes;
 };
 
-__global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const CsParams p) {
+// NS = K / 16 slices; WC x WP waves, wave (wc, wp) owns CT channel tiles x PT pixel tiles:
+//   K = 256: 4 waves = 2 x 2, CT = PT = 2: 128 channels x 128 pixels per workgroup (blockIdx.y = channel block)
+//   K = 512: 8 waves = 8 x 1, CT = 1, PT = 2: 256 channels x 64 pixels — half of the CU's register file holds the weights
+template <int NS, int WC, int WP, int CT, int PT>
+__global__ __launch_bounds__(64 * WC * WP, 1) void conv1x1_stream_kernel(const CsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BP = 128, ROWB = 512, SLOTB = BP * ROWB, LX = SLOTB / 1024 / 4, NS = 16;
+  constexpr int NW = WC * WP, BP = WP * PT * 32, BN = WC * CT * 32, ROWB = NS * 32, SLOTB = BP * ROWB, LX = SLOTB / 1024 / NW;
+  constexpr int RPL = 1024 / ROWB, CPR = ROWB / 16;          // rows per 1-KiB wave load (2 or 1), 16-byte chunks per row
+  constexpr int NST = CT * PT * 2;                           // stores per lane per tile
+  static_assert(LX * NW * 1024 == SLOTB && 2 * SLOTB <= 160 * 1024 && RPL >= 1, "shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wp = wave >> 1;          // channel half (2 tiles of 32) x pixel half (2 tiles of 32)
+  const int wc = wave % WC, wp = wave / WC;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int cb = blockIdx.y;
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -758,34 +765,36 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const CsParams p
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
-  // the weight block of this wave: fragment (channel tile 2*wc + i, slice s) = 1 KiB at ((cb*4 + 2*wc + i) * 16 + s) KiB
-  uint4_t a[2][NS];
+  // the weight block of this wave: fragment (channel tile wc*CT + i of the block, slice s) = 1 KiB, tile-major
+  uint4_t a[CT][NS];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < CT; ++i)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      a[i][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, ((cb * 4 + 2 * wc + i) * NS + s) * 1024, 0);
+      a[i][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, ((cb * (BN / 32) + wc * CT + i) * NS + s) * 1024, 0);
   // folded BN of the lane's 16 consecutive channels of each tile
-  float4_t sc[2][4], sh[2][4];
+  float4_t sc[CT][4], sh[CT][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < CT; ++i)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const int ch = cb * 128 + (2 * wc + i) * 32 + 16 * lhi + 4 * g4;
+      const int ch = cb * BN + (wc * CT + i) * 32 + 16 * lhi + 4 * g4;
       const float4_t one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
       sc[i][g4] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + ch) : one;
       sh[i][g4] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + ch) : zero;
     }
   const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
 
-  // loader lanes: wave load (t*4 + wave) covers tile rows 2*(t*4 + wave), +1; XOR swizzle of the low 4 chunk bits on the source
+  // loader lanes: wave load (t*NW + wave) covers RPL tile rows; XOR swizzle of the low 4 chunk bits on the source
   int l_row[LX];
   unsigned l_off[LX];
 #pragma unroll
   for (int t = 0; t < LX; ++t) {
-    const int row = (t * 4 + wave) * 2 + (lane >> 5), pos = lane & 31;
+    const int piece = t * NW + wave;
+    const int row = RPL == 2 ? piece * 2 + (lane >> 5) : piece / (ROWB / 1024);
+    const int pos = RPL == 2 ? (lane & 31) : (piece % (ROWB / 1024)) * 64 + lane;
     l_row[t] = row;
-    l_off[t] = (unsigned)((row * p.x_cstride + p.x_coff) * 2 + ((pos ^ (row & 15)) << 4));
+    l_off[t] = (unsigned)((row * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4));
   }
   auto issue = [&](int tile, int slot) {            // always LX loads: tiles past the end / rows past M read out of range
     const int m0 = tile * BP;
@@ -793,54 +802,55 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const CsParams p
     const int soff = tile_ok ? m0 * p.x_cstride * 2 : 0;
 #pragma unroll
     for (int t = 0; t < LX; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + slot * SLOTB + (t * 4 + wave) * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + slot * SLOTB + (t * NW + wave) * 1024), 16,
                                                (tile_ok && m0 + l_row[t] < p.M) ? l_off[t] : kOOB, soff, 0, 0);
   };
-  int b_off[2];
+  int b_off[PT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = wp * 64 + j * 32 + l31;
+  for (int j = 0; j < PT; ++j) {
+    const int row = (wp * PT + j) * 32 + l31;
     b_off[j] = row * ROWB + ((lhi ^ (row & 15)) << 4);
   }
+  static_assert(CPR >= 32, "chunk index bits");
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights and tables sit in registers before the tile loads are counted
   int tile = blockIdx.x;
   issue(tile, 0);
   for (int k = 0; tile < p.ntiles; ++k, tile += gridDim.x) {
     const int slot = k & 1;
-    // this tile has landed (this wave's share): behind it only the 8 stores of the previous tile may fly
+    // this tile has landed (this wave's share): behind it only the NST stores of the previous tile may fly
     if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     asm volatile("s_barrier" ::: "memory");          // everyone's share has; everyone is done reading the other half
     issue(tile + gridDim.x, slot ^ 1);
-    float16_t acc[2][2];
+    float16_t acc[CT][PT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CT; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < PT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const char* xb = smem + slot * SLOTB;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      uint4_t fx[2];
+      uint4_t fx[PT];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fx[j] = *reinterpret_cast<const uint4_t*>(xb + (b_off[j] ^ (s << 5)));
+      for (int j = 0; j < PT; ++j) fx[j] = *reinterpret_cast<const uint4_t*>(xb + (b_off[j] ^ (s << 5)));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[i][s]), __builtin_bit_cast(half8_t, fx[j]),
                                                              acc[i][j], 0, 0, 0);
     }
     // the loads of the next tile were issued before these stores: at the next wait they are the older operations
     const int m0 = tile * BP;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CT; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wp * 64 + j * 32 + l31;
-        const unsigned vo = m < p.M ? (unsigned)((m * p.y_cstride + p.y_coff + cb * 128 + (2 * wc + i) * 32 + 16 * lhi) * 2) : kOOB;
+      for (int j = 0; j < PT; ++j) {
+        const int m = m0 + (wp * PT + j) * 32 + l31;
+        const unsigned vo = m < p.M ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + (wc * CT + i) * 32 + 16 * lhi) * 2) : kOOB;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           half8_t o;
@@ -858,16 +868,15 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const CsParams p
 #endif
 }
 
-// fragment-ordered weight block for conv1x1_stream_kernel: [channel block 128][tile 4][slice 16][lane] x 16 bytes
-__global__ __launch_bounds__(256) void cs_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int ncb, int kpad, int cout_pad) {
+// fragment-ordered weights for conv1x1_stream_kernel: [channel tile Cout / 32][slice ns][lane] x 16 bytes
+__global__ __launch_bounds__(256) void cs_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int ntile, int ns, int kpad,
+                                                      int cout_pad) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= ncb * 4 * 16 * 64) return;
+  if (idx >= ntile * ns * 64) return;
   const int lane = idx & 63;
-  int f = idx >> 6;
-  const int sl = f & 15; f >>= 4;
-  const int tl = f & 3;
-  const int cb = f >> 2;
-  const int co = cb * 128 + tl * 32 + cd_sigma(lane & 31), k = sl * 16 + 8 * (lane >> 5);
+  const int f = idx >> 6;
+  const int sl = f % ns, tl = f / ns;
+  const int co = tl * 32 + cd_sigma(lane & 31), k = sl * 16 + 8 * (lane >> 5);
   uint4_t v = {0u, 0u, 0u, 0u};
   if (co < cout_pad && k < kpad) v = *reinterpret_cast<const uint4_t*>(w + (size_t)co * kpad + k);
   out[idx] = v;
@@ -897,11 +906,17 @@ static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
   const long long lim = 1LL << 31;
   if ((long long)d->N * d->Hi * d->Wi * d->x_cstride * 2 >= lim || M * d->y_cstride * 2 >= lim || (d->has_residual && M * d->res_cstride * 2 >= lim) ||
       (d->x2_cin && (long long)d->N * d->x2_hi * d->x2_wi * d->x2_cstride * 2 >= lim)) return FT_ERR_UNSUPPORTED;
-  if (!taps && M > 65536) {       // many pixels: only the weight-stationary form (K = 256, 128-channel blocks, plain epilogue)
-    if (d->Cin != 256 || d->Cout % 128 || d->x2_cin || d->has_residual) return FT_ERR_UNSUPPORTED;
-    *out = CdPlan{0, 4, 0, (int)((M + 127) / 128), d->Cout / 128};
+  // many pixels, short K, plain epilogue: the weight-stationary persistent form (the HBM-bound ResNet layer2.0.conv1: K = 256
+  // in 128-channel blocks).  FT_CD_STATIONARY=2 (dev) also sends K = 512 -> 256 layers with >= 32768 pixels (layer3.0.conv1)
+  // to the 8-wave form: measured 24.7 us against 22.3 us for the K-split kernel, and 1.8 % slower over the whole pose step.
+  static const int cs_mode = getenv("FT_CD_STATIONARY") ? atoi(getenv("FT_CD_STATIONARY")) : 1;
+  const bool cs256 = d->Cin == 256 && d->Cout % 128 == 0 && M > 65536, cs512 = cs_mode == 2 && d->Cin == 512 && d->Cout == 256 && M >= 32768;
+  if (!taps && cs_mode != 0 && !d->x2_cin && !d->has_residual && (cs256 || cs512)) {
+    const int bp = cs256 ? 128 : 64;
+    *out = CdPlan{0, d->Cin / 64, 0, (int)((M + bp - 1) / bp), cs256 ? d->Cout / 128 : 1};
     return FT_OK;
   }
+  if (!taps && M > 65536) return FT_ERR_UNSUPPORTED;
   const int npt = (int)((M + 95) / 96);
   static const int force = getenv("FT_CD_KSPLIT") ? atoi(getenv("FT_CD_KSPLIT")) : 0;
   const bool a_ok = d->Cout % 256 == 0 && d->Cin % 64 == 0 && d->x2_cin % 64 == 0;
@@ -987,7 +1002,7 @@ extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
   ft::C3Plan p3;
   if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return (long long)p3.ncb * 4 * 9 * p3.spt * 8192;
   if (ft::cd_plan(d, &pl) != FT_OK) return 0;
-  if (pl.ksplit == 0) return (long long)pl.ncb * 65536;
+  if (pl.ksplit == 0) return (long long)d->Cout * d->Cin * 2;
   return (long long)pl.ncb * (pl.nc1 + pl.nc2) * 32768;
 }
 
@@ -1010,8 +1025,9 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
   const int total = pl.ncb * nchunk * 2048;
   hipStream_t s = as_stream(stream);
   if (pl.ksplit == 0) {
-    hipLaunchKernelGGL(cs_pack_kernel, dim3(ceil_div(pl.ncb * 4096, 256)), dim3(256), 0, s, static_cast<const half_t*>(w_packed),
-                       static_cast<uint4_t*>(wstream), pl.ncb, kpad, cout_pad);
+    const int ntile = d->Cout / 32, ns = d->Cin / 16;
+    hipLaunchKernelGGL(cs_pack_kernel, dim3(ceil_div(ntile * ns * 64, 256)), dim3(256), 0, s, static_cast<const half_t*>(w_packed),
+                       static_cast<uint4_t*>(wstream), ntile, ns, kpad, cout_pad);
     FT_LAUNCH_CHECK("cs_pack_kernel");
     return FT_OK;
   }
@@ -1065,12 +1081,18 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
     q.x_bytes = (unsigned)((size_t)q.M * d->x_cstride * 2);
     q.y_bytes = (unsigned)((size_t)q.M * d->y_cstride * 2);
     q.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
-    auto k = conv1x1_stream_kernel;
-    constexpr int lds = 2 * 128 * 512;
-    FT_RAISE_LDS(k, lds);
+    constexpr int lds = 2 * 65536;
     int gx = 256 / pl.ncb;
     gx = gx < 1 ? 1 : (gx > pl.npt ? pl.npt : gx);
-    hipLaunchKernelGGL(k, dim3(gx, pl.ncb), dim3(256), lds, as_stream(stream), q);
+    if (d->Cin == 256) {
+      auto k = conv1x1_stream_kernel<16, 2, 2, 2, 2>;
+      FT_RAISE_LDS(k, lds);
+      hipLaunchKernelGGL(k, dim3(gx, pl.ncb), dim3(256), lds, as_stream(stream), q);
+    } else {
+      auto k = conv1x1_stream_kernel<32, 8, 1, 1, 2>;
+      FT_RAISE_LDS(k, lds);
+      hipLaunchKernelGGL(k, dim3(gx, 1), dim3(512), lds, as_stream(stream), q);
+    }
     FT_LAUNCH_CHECK("conv1x1_stream_kernel");
     return FT_OK;
   }

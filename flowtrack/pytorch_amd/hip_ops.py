@@ -804,9 +804,9 @@ def _direct_stream(owner, d: ConvDesc, w: torch.Tensor, device) -> Optional[torc
     lib = _lib.load()
     if not CONV_DIRECT or d.dtype != _lib.FT_F16 or d.Cin + d.x2_cin < 256:
         return None
-    if d.N * d.Ho * d.Wo > CONV_DIRECT_MAX_PIXELS and not (CONV_DIRECT_MAX_PIXELS >= 65536 and d.kh == 1 and d.Cin == 256 and not d.x2_cin
-                                                          and not d.has_residual):
-        return None     # (beyond the bound only the weight-stationary K = 256 form exists: ResNet layer2.0.conv1)
+    if d.N * d.Ho * d.Wo > CONV_DIRECT_MAX_PIXELS and not (CONV_DIRECT_MAX_PIXELS >= 65536 and d.kh == 1 and d.Cin in (256, 512)
+                                                          and not d.x2_cin and not d.has_residual):
+        return None     # (beyond the bound only the weight-stationary short-K forms exist: ResNet layer2.0 / layer3.0 conv1)
     if lib.ft_conv_direct_supported(ctypes.byref(d)) != 0:
         return None
     key = ("direct", int(lib.ft_conv_direct_weight_bytes(ctypes.byref(d))), d.N * d.Ho * d.Wo <= 0, w.data_ptr())

@@ -62,7 +62,7 @@ def test_direct_conv1x1_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
         assert torch.all(y.t[..., :64] == 3.0), "channels outside the output slice were written"
         if mode:
             d = prog.conv_records[0][3]
-            want_bytes = (Cout // 128) * 65536 if ksplit == 0 else (Cout // (256 if ksplit == 1 else 64)) * (Cin // (64 if ksplit == 1 else 256)) * 32768
+            want_bytes = Cout * Cin * 2 if ksplit == 0 else (Cout // (256 if ksplit == 1 else 64)) * (Cin // (64 if ksplit == 1 else 256)) * 32768
             assert hip_lib.ft_conv_direct_weight_bytes(d) == want_bytes
             y.t.fill_(5.0)
             run_program(prog)                      # determinism
@@ -189,3 +189,37 @@ def test_direct_conv3x3_gather_matches_oracle_and_igemm(hip_lib, case, monkeypat
     assert err <= 2e-2 * scale, f"{name}: direct 3x3 gather vs oracle max abs err {err:.3e} (scale {scale:.2f})"
     diff = (outs[True] - outs[False]).abs()
     assert diff.max().item() <= 1e-2 * scale and (diff > 0).float().mean().item() < 0.05
+
+
+def test_stationary_k512_dev_form(hip_lib):
+    """The 8-wave K = 512 weight-stationary form is a dev alternative (FT_CD_STATIONARY=2, read once per process): checked in
+    a subprocess against the torch-CPU functional form."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, "tests")
+from flowtrack.pytorch_amd import hip_ops, synth
+from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv
+from util import make_program, nchw_to_view, run_program, view_to_nchw
+for name, N, H, W in (("a", 64, 32, 24), ("b", 3, 111, 101)):
+    w = synth.normal(41, name + ".w", (256, 512, 1, 1), std=(2.0 / 512) ** 0.5)
+    x = synth.normal(41, name + ".x", (N, 512, H, W)).half().float()
+    want = F.relu(F.conv2d(x, w))
+    conv = FusedConv(w, act="relu", dtype=torch.float16, device=torch.device("cuda:0"), label=name)
+    xv = nchw_to_view(x, torch.float16, torch.device("cuda:0"))
+    y = ActView(torch.zeros((N, H, W, 256), dtype=torch.float16, device="cuda:0"), 256, 0)
+    prog = make_program(); conv.record(prog, xv, y); prog.resolve_choices()
+    assert prog.calls[0][0] == "ft_conv_direct_fwd", prog.calls[0][0]
+    d = prog.conv_records[0][3]
+    assert hip_ops._lib.load().ft_conv_direct_weight_bytes(d) == 256 * 512 * 2      # the stationary form's stream, not the K-split one's
+    run_program(prog)
+    err = (view_to_nchw(y) - want).abs().max().item()
+    assert err <= 2e-2 * max(1.0, want.abs().max().item()), err
+print("ok")
+'''
+    env = dict(os.environ, FT_CD_STATIONARY="2", FT_CONV_DIRECT_MAX_PIXELS="1048576")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
