@@ -18,7 +18,7 @@ for k in busy:
     short = k.replace("(anonymous namespace)::", "").split("(")[0][:110]
     frac = busy[k] / (act[k] / 8.0 * 1024.0)
     res[short] = {"launches": calls[k], "gpu_cycles_total": act[k] / 8.0, "mfma_busy_frac": round(frac, 4)}
-    if any(t in k for t in ("conv_", "conv3x3_direct", "bottleneck_fused", "bottleneck_stream")) and "ft" in k:
+    if any(t in k for t in ("conv_", "conv3x3_direct", "conv1x1_stream", "bottleneck_fused", "bottleneck_stream")) and "ft" in k:
         tb += busy[k]; ta += act[k]
 top = dict(sorted(res.items(), key=lambda kv: -kv[1]["gpu_cycles_total"])[:12])
 summary = {"conv_kernels_mfma_busy_frac": round(tb / (ta / 8.0 * 1024.0), 4) if ta else None, "top_kernels_by_gpu_time": top}

@@ -21,7 +21,7 @@ for k in sorted(set(fetch) | set(write)):
     w = write.get(k, 0.0) * 1024.0 / nforward
     short = k.replace("(anonymous namespace)::", "").split("(")[0][:100]
     res["kernels"][short] = {"launches_per_forward": fc.get(k, wc.get(k, 0)) / nforward, "read_MB_per_forward": round(r / 1e6, 2), "write_MB_per_forward": round(w / 1e6, 2)}
-    if any(t in k for t in ("conv_igemm", "conv_fewout", "conv_halo", "conv_stem", "conv_pflow", "conv_splitk", "bottleneck_fused", "bottleneck_stream", "conv_direct", "conv3x3_direct")):
+    if any(t in k for t in ("conv_igemm", "conv_fewout", "conv_halo", "conv_stem", "conv_pflow", "conv_splitk", "bottleneck_fused", "bottleneck_stream", "conv_direct", "conv3x3_direct", "conv1x1_stream")):
         conv_r += r; conv_w += w
         if "conv_splitk" not in k:      # the reduce launch belongs to the ft_conv2d_fwd call of its split-K conv
             n_conv += fc.get(k, 0) / nforward
