@@ -58,6 +58,13 @@ __device__ __forceinline__ void unroll_for(F&& f) {
 
 // s_barrier with a memory clobber: the builtin is IntrNoMem, LDS reads may be hoisted above it (see conv_igemm.hip)
 #define BNK_BARRIER() asm volatile("s_barrier" ::: "memory")
+// XOR key of the 16-byte chunk position inside a 128-byte LDS row.  A 256-byte bank row holds TWO such rows, so the sixteen
+// consecutive rows a ds_read_b128 services together hit sixteen distinct 16-byte slots only if the key changes every second
+// row: with `row & 7` rows r and r + 8 collided (PMC: bank-conflict cycles 43-47 % of the LDS-active cycles of this kernel).
+#ifndef FT_BNK_KEY_SHIFT
+#define FT_BNK_KEY_SHIFT 1
+#endif
+#define BNK_KEY(r) (((r) >> FT_BNK_KEY_SHIFT) & 7)
 
 constexpr int kC = 256, kP = 64;                 // block width / planes this kernel is written for
 // LDS map (bytes).  Phase 1: two 32-KiB stages (64-channel x chunk 24 KiB + W1 K-slice 8 KiB) at 0 .. 64 Ki.
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   // every LDS tile here has 128-byte rows (64 fp16): a 1-KiB wave load covers 8 rows, lane -> (row = lane / 8, 16-byte
   // position = lane % 8) — whole 128-byte lines per row for the texture path (64-byte rows cost twice the requests per
   // byte: the phase-1 stream was request-bound with them).  The LDS image is lane-linear, so the XOR swizzle
-  // (position ^= row & 7) is applied to the SOURCE position.
+  // (position ^= BNK_KEY(row)) is applied to the SOURCE position.
   const int lrow = lane >> 3, lpos = lane & 7;
   unsigned x_voff[6];
 #pragma unroll
@@ -122,14 +129,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
     unsigned v = kOOB;
     if (pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 1))
-      v = (unsigned)(((((p.dbg & 16 ? (n & 7) : n) * p.H + iy) * p.W + ix) * p.x_cstride + p.x_coff) * 2 + ((lpos ^ (pp & 7)) << 4));
+      v = (unsigned)(((((p.dbg & 16 ? (n & 7) : n) * p.H + iy) * p.W + ix) * p.x_cstride + p.x_coff) * 2 + ((lpos ^ BNK_KEY(pp)) << 4));
     x_voff[t] = v;
   }
   unsigned w1_voff[2], w2_voff[2], w3_voff[2];           // rows (t * 4 + wave) * 8 + lrow of a 64-row weight block
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int wr = (t * 4 + wave) * 8 + lrow;
-    const unsigned lc = (unsigned)((lpos ^ (wr & 7)) << 4);
+    const unsigned lc = (unsigned)((lpos ^ BNK_KEY(wr)) << 4);
     w1_voff[t] = (unsigned)(wr * NCH * 128) + lc;        // W1 [64][64 * NCH]
     w2_voff[t] = (unsigned)(wr * 9 * kP * 2) + lc;       // W2 [64][576]
     w3_voff[t] = (unsigned)(wr * p.w3_pitch) + lc;       // W3 [256][64] (or the first half of [256][128]), + quarter * 64 rows
@@ -182,12 +189,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   // wave -> output-channel tile (wave & 1) x three 32-pixel tiles (wave >> 1)
   const int wc1 = wave & 1, wp1 = wave >> 1;
   const int a1_row = wc1 * 32 + l31;
-  const int a1_off = a1_row * 128 + ((lhi ^ (a1_row & 7)) << 4);       // + (k16 * 2) << 4 by XOR: 16-channel slice k16
+  const int a1_off = a1_row * 128 + ((lhi ^ BNK_KEY(a1_row)) << 4);       // + (k16 * 2) << 4 by XOR: 16-channel slice k16
   int b1_off[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int r = (wp1 * 3 + j) * 32 + l31;
-    b1_off[j] = r * 128 + ((lhi ^ (r & 7)) << 4);
+    b1_off[j] = r * 128 + ((lhi ^ BNK_KEY(r)) << 4);
   }
   float16_t acc1[3];
 #pragma unroll
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   for (int j = 0; j < 2; ++j) {
     const int m = wp2 * 64 + j * 32 + l31;
     const int rc = (m / TW + 1) * PW + (m % TW + 1);
-    rc_off[j] = rc * 128 + lhi * 8 + (((wc2 * 4) ^ (rc & 7)) << 4);    // 16-byte chunk wc2*4 + g sits at (.. ^ g) << 4
+    rc_off[j] = rc * 128 + lhi * 8 + (((wc2 * 4) ^ BNK_KEY(rc)) << 4);    // 16-byte chunk wc2*4 + g sits at (.. ^ g) << 4
   }
   half4_t res[FULL && !PROJ ? 4 : 1][2][4];
   uint4_t fbx[PROJ ? 2 : 1][2][2];      // projection form: the block input at the patch's own pixels as phase 3's pixel operand
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       for (int j = 0; j < 2; ++j) {
         const int m = wp2 * 64 + j * 32 + l31;
         const int rc = (m / TW + 1) * PW + (m % TW + 1);
-        const int lsw = lhi ^ (rc & 7);
+        const int lsw = lhi ^ BNK_KEY(rc);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
       const bool inside = r < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       char* rowp = t1 + r * 128 + lhi * 8;
-      const int rsw = (r & 7) << 4;
+      const int rsw = BNK_KEY(r) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         half4_t h;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   // ================= phase 2: t2 = relu(bn2(W2 * t1)), pixel operand from T1 ======================================
   // wave -> output-channel tile wc2 = wave >> 1 x two 32-pixel tiles (wp2 = wave & 1)
   const int a2_row = wc2 * 32 + l31;
-  const int a2_off = a2_row * 128 + ((lhi ^ (a2_row & 7)) << 4);
+  const int a2_off = a2_row * 128 + ((lhi ^ BNK_KEY(a2_row)) << 4);
   int r0[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = r0[j] + ky * PW + kx;
-      const int lsw = lhi ^ (r & 7);
+      const int lsw = lhi ^ BNK_KEY(r);
       const char* rowp = t1 + r * 128;
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     for (int j = 0; j < 2; ++j) {
       const int m = wp2 * 64 + j * 32 + l31;
       char* rowp = t2 + m * 128 + lhi * 8;
-      const int msw = (m & 7) << 4;
+      const int msw = BNK_KEY(m) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         half4_t h;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i, m = idx >> 3, ch = idx & 7;
       const int oy = qy0 + m / TW, ox = qx0 + m % TW;
-      const uint4_t v = *reinterpret_cast<const uint4_t*>(t2 + m * 128 + ((ch ^ (m & 7)) << 4));
+      const uint4_t v = *reinterpret_cast<const uint4_t*>(t2 + m * 128 + ((ch ^ BNK_KEY(m)) << 4));
       if (oy < p.H && ox < p.W && !(p.dbg & 4))
         store_out16(p.y + ((((long long)n * p.H + oy) * p.W + ox) * p.y_cstride + p.y_coff + ch * 8) * 2, v);
     }
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = wp2 * 64 + j * 32 + l31;
-      const int lsw = lhi ^ (m & 7);
+      const int lsw = lhi ^ BNK_KEY(m);
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
     for (int j = 0; j < 2; ++j) {
       const int m = wp2 * 64 + j * 32 + l31;
       char* rowp = so + m * 128 + lhi * 8;
-      const int msw = (m & 7) << 4;
+      const int msw = BNK_KEY(m) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         half4_t h;
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i, m = idx >> 3, ch = idx & 7;
-      const uint4_t v = *reinterpret_cast<const uint4_t*>(so + m * 128 + ((ch ^ (m & 7)) << 4));
+      const uint4_t v = *reinterpret_cast<const uint4_t*>(so + m * 128 + ((ch ^ BNK_KEY(m)) << 4));
       if (spix[i] >= 0 && !(p.dbg & 4))
         store_out16(p.y + (spix[i] * p.y_cstride + p.y_coff + q * 64 + ch * 8) * 2, v);
     }
