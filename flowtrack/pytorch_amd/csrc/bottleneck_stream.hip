@@ -55,6 +55,11 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 }
 
 #define BNS_BARRIER() asm volatile("s_barrier" ::: "memory")
+// XOR key of the x-chunk buffers' 128-byte rows: two rows share a 256-byte bank row (see bottleneck.hip: BNK_KEY)
+#ifndef FT_BNS_XKEY_SHIFT
+#define FT_BNS_XKEY_SHIFT 1
+#endif
+#define BNS_XKEY(hp) (((hp) >> FT_BNS_XKEY_SHIFT) & 7)
 #ifndef FT_BNS_STG
 #define FT_BNS_STG 1    // dev A/B: 0 = phase 3 of the direct kernel stores straight from the accumulator layout (no LDS staging tile)
 #endif
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
     const int iy = y0 - 1 + hr;
     unsigned v = kOOB;
     if (hp < npix_halo && (unsigned)iy < (unsigned)p.H)
-      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ (hp & 7)) << 4));
+      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ BNS_XKEY(hp)) << 4));
     x_voff[t] = v;
   }
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -202,11 +207,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
     for (int j = 0; j < MT1; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
-  int b1_off[MT1];      // x-chunk fragment offsets (buffer-relative): row hp, 16-byte position (kk*2 + lhi) ^ (hp & 7)
+  int b1_off[MT1];      // x-chunk fragment offsets (buffer-relative): row hp, 16-byte position (kk*2 + lhi) ^ BNS_XKEY(hp)
 #pragma unroll
   for (int j = 0; j < MT1; ++j) {
     const int hp = (pg * MT1 + j) * 32 + l31;
-    b1_off[j] = hp * 128 + ((lhi ^ (hp & 7)) << 4);
+    b1_off[j] = hp * 128 + ((lhi ^ BNS_XKEY(hp)) << 4);
   }
   {
     uint4_t fx[2][MT1];
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ (hp & 7)) << 4));
+              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ BNS_XKEY(hp)) << 4));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     const int iy = y0 - 1 + hr;
     unsigned v = kOOB;
     if (hp < npix_halo && (unsigned)iy < (unsigned)p.H)
-      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ (hp & 7)) << 4));
+      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ BNS_XKEY(hp)) << 4));
     x_voff[t] = v;
   }
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
   for (int j = 0; j < MT1; ++j) {
     const int hp = j * 32 + l31;
-    b1_off[j] = hp * 128 + ((lhi ^ (hp & 7)) << 4);
+    b1_off[j] = hp * 128 + ((lhi ^ BNS_XKEY(hp)) << 4);
   }
   {
     uint4_t fx[2][MT1];
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ (hp & 7)) << 4));
+              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ BNS_XKEY(hp)) << 4));
         }
       }
       mma1(c1{}, slot{}, std::integral_constant<int, 1>{});

@@ -57,6 +57,14 @@ __device__ __forceinline__ void cd_unroll(F&& f) {
 
 __host__ __device__ constexpr int cd_sigma(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }   // as bns_sigma
 
+// XOR key of a ring row's 16-byte chunk position.  128-byte rows (CPR = 8): two rows share a 256-byte bank row, so the key
+// changes every second row (`row & 7` made rows r and r + 8 collide: 27-44 % bank-conflict cycles in the PMC); 512-byte rows: row & 15.
+#ifndef FT_CD_KEY_SHIFT
+#define FT_CD_KEY_SHIFT 1
+#endif
+template <int CPR>
+__device__ __forceinline__ int cd_key(int row) { return CPR < 16 ? ((row >> FT_CD_KEY_SHIFT) & (CPR - 1)) : (row & 15); }
+
 template <int KSPLIT>
 struct CdGeom {
   static constexpr int MT = 3, BP = 96;                       // pixel tiles per wave, pixels per workgroup
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   for (int t = 0; t < LX; ++t) {
     const int row = (t * 4 + wave) * RPL + lane / CPR, pos = lane % CPR;
     const int m = m0 + row;
-    const unsigned swz = (unsigned)((pos ^ (row & (CPR < 16 ? CPR - 1 : 15))) << 4);
+    const unsigned swz = (unsigned)((pos ^ cd_key<CPR>(row)) << 4);
     unsigned v = kOOB, v2 = kOOB;
     if constexpr (TAPS) {
       int mk = 0;
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   for (int j = 0; j < MT; ++j) {
     const int row = j * 32 + l31;
     const int s0 = KSPLIT == 1 ? 0 : 4 * wave;
-    b_off[j] = row * ROWB + ((((s0 * 2 + lhi) ^ (row & (CPR < 16 ? CPR - 1 : 15)))) << 4);
+    b_off[j] = row * ROWB + ((((s0 * 2 + lhi) ^ cd_key<CPR>(row))) << 4);
   }
   uint4_t fx[2][MT];
   auto ldx = [&](auto setc, int buf, int kk) {
