@@ -563,6 +563,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // hoisted ABOVE it (measured: the stem kernel read patch rows other waves' LDS-DMA had not landed yet, ~0.1 % of the
 // tiles wrong once workgroups are recycled on a CU).  The inline-asm form with a memory clobber pins the order.
 #define FT_LDS_BARRIER() asm volatile("s_barrier" ::: "memory")
+#ifndef FT_HALO_KEY_SHIFT
+#define FT_HALO_KEY_SHIFT 1    // dev A/B: 0 = the old `r & 7` patch key of conv_halo_kernel's 128-byte rows
+#endif
 #ifndef FT_EPI_NT
 #define FT_EPI_NT 0     // non-temporal stores in the fp16 epilogue (dev A/B)
 #endif
@@ -1343,7 +1346,14 @@ __global__ __launch_bounds__(256, (CCH == 32 ? 3 : 2)) void conv_halo_kernel(con
   }
   // patch swizzle: the 16-byte chunk q of patch pixel r sits at position q ^ pswz(r) of its row (bank-conflict-free
   // fragment reads: 16 consecutive pixels of a tile row hit 16 different bank groups)
-  auto pswz = [](int r) { return CCH == 64 ? (r & 7) : ((r >> 2) & 3); };
+  // 128-byte rows (CCH == 64): two rows share a 256-byte bank row, so the key changes every second row — with `r & 7` rows r
+  // and r + 8 share a 16-byte slot (PMC: 33-40 % bank-conflict cycles on the <*,16,4,2,4,64> instantiations; the reasoning is
+  // bottleneck.hip's BNK_KEY).  MEASURED EFFECT HERE: none — FlowNet2S 15.8-16.0 k pairs/s with this key against 16.0-16.1 k
+  // with `r & 7` (same box, interleaved), deconv2..5 within 0.5 us of each other: these launches rarely WAIT on LDS
+  // (SQ_WAIT_INST_LDS 4-8 % of wave cycles), so removing conflict cycles does not show.  Kept because it is the consistent key;
+  // it is not a speed-up.  64-byte rows (CCH == 32) keep (r >> 2) & 3: their conflicts (40-56 %) come from the jump of PW - TW
+  // rows between tile rows inside one 16-lane group, which no per-row key addresses.
+  auto pswz = [](int r) { return CCH == 64 ? ((r >> FT_HALO_KEY_SHIFT) & 7) : ((r >> 2) & 3); };
   unsigned p_voff[NPWW_MAX];      // patch pixel rows of ROWB bytes: LPP lanes per pixel
   {
     const int ppl = lane / LPP, pos = lane % LPP;
