@@ -60,7 +60,11 @@ __device__ __forceinline__ void unroll_for(F&& f) {
 #define BNK_BARRIER() asm volatile("s_barrier" ::: "memory")
 // XOR key of the 16-byte chunk position inside a 128-byte LDS row.  A 256-byte bank row holds TWO such rows, so the sixteen
 // consecutive rows a ds_read_b128 services together hit sixteen distinct 16-byte slots only if the key changes every second
-// row: with `row & 7` rows r and r + 8 collided (PMC: bank-conflict cycles 43-47 % of the LDS-active cycles of this kernel).
+// row: with `row & 7` rows r and r + 8 collided.  PMC (profiles/r02_lds_wait_counters.txt): bank-conflict cycles were 43-47 % of
+// this kernel's LDS-active cycles before and are 30-33 % after — the fragment reads this key governs are fixed (the same change
+// takes conv_direct's ring reads from 27-44 % to 0), but a third of the LDS time here is STILL conflicts.  Not tracked down;
+// candidates are the 8-byte accesses (T1 / T2 / staging epilogue writes, the residual pick-up), where the two lanes of a pixel
+// write the halves of one 16-byte chunk.  60.4 -> 57.3 us per block came from the part that is fixed.
 #ifndef FT_BNK_KEY_SHIFT
 #define FT_BNK_KEY_SHIFT 1
 #endif
