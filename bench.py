@@ -60,7 +60,7 @@ def build_flow(device, dtype, seed=1234, name="FlowNet2S"):
 def pmc_traffic(workload):
     """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE; tools/dev/prof_traffic.sh + pmc_traffic.py on this same command). None if not measured."""
-    for tag in ("r02", "r01"):       # the latest committed round
+    for tag in ("r03", "r02", "r01"):       # the latest committed round
         path = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic_pmc.json")
         try:
             with open(path) as f:
@@ -76,7 +76,14 @@ def conv_roofline(prog, dtype_name, iters=5):
     launch, ~1 us of overhead each) only feeds the --layers table and the cross-check field."""
     times = prog.time_calls(iters=iters)
     per_launch_conv_ms = sum(ms for name, ms in times if is_conv_call(name))
-    conv_ms, other_ms = prog.time_conv_runs(iters=iters)
+    # the conv-run pass is the one `achieved` comes from: >= 50 passes (>= 0.25 s) right after a spin-up of the same plan,
+    # so it runs at the clocks of the timed region and conv_ms_per_step <= ms_per_step holds for every record of the line
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        for _ in range(5):
+            prog.run()
+        prog.stream.synchronize()
+    conv_ms, other_ms = prog.time_conv_runs(iters=max(iters, 50))
     total_ms = conv_ms + other_ms
     n_conv = sum(1 for name, _ in times if is_conv_call(name))
     flops = prog.flops
@@ -349,12 +356,24 @@ def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sam
     return model, x, step
 
 
-def measure(step, steps, warmup, device, fixed_warmup=False):
+def measure(step, steps, warmup, device, fixed_warmup=False, min_total_s=1.0, max_repeats=400):
+    """W untimed warm-up steps, then BLOCKS of exactly `steps` steps, each bracketed by barrier + synchronize on both sides
+    (timed_region).  One block is what the contract asks for; with a small `steps` it is a few tens of milliseconds, one
+    preempted step away from a 5 % error, so the block is repeated until >= min_total_s has been timed and the MEDIAN block
+    is reported.  The repeat count follows from the first block's (max-over-ranks) time, so every rank runs the same number
+    of blocks.  Returns (median block seconds, repeats, total timed seconds)."""
     for _ in range(max(warmup, 2)):   # >= 2: first run is eager (+ tile benchmark) + graph capture, second replays the graph
         step()
-    if not fixed_warmup:
-        spin_up(step, device)
-    return timed_region(step, steps, device)
+    if fixed_warmup:                  # profiling runs that count launches: exactly one block
+        t = timed_region(step, steps, device)
+        return t, 1, t
+    spin_up(step, device)
+    blocks = [timed_region(step, steps, device)]
+    repeats = min(max_repeats, max(1, int(min_total_s / max(blocks[0], 1e-6)) + 1))
+    for _ in range(repeats - 1):
+        blocks.append(timed_region(step, steps, device))
+    blocks.sort()
+    return blocks[len(blocks) // 2], len(blocks), sum(blocks)
 
 
 def main():
@@ -405,13 +424,15 @@ def main():
         workload = (f"{args.flow_model} {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU "
                     f"(BASELINE.json configs[3]{'' if default_cfg else ' shape, other stack'})")
 
-    elapsed = measure(step, args.steps, args.warmup, device, args.fixed_warmup)
+    elapsed, repeats, total_s = measure(step, args.steps, args.warmup, device, args.fixed_warmup)
     value = B * world * args.steps / elapsed
     out = {
         "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic (counter-hash crops ~N(0,1) / translated-texture frame pairs, He-scaled random weights)",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "repeats": repeats, "timed_region_s": round(total_s, 4),
+        "timing": f"median of {repeats} blocks of exactly {args.steps} steps, each bracketed by barrier + synchronize (max over ranks)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (counter-hash crops ~N(0,1) / translated-texture frame pairs, He-scaled random weights); "
+                                     "the same HBM-resident batch is processed every step",
         "config": {"workload": workload, "per_gpu_batch": B,
                    "parallelism": f"dp{world}: batch sharded, one process per GPU" +
                                   (", RCCL all-gather of the output rows on a comm stream, one step behind" if world > 1 else "")},
@@ -440,12 +461,12 @@ def main():
         # (1) FlowNet2S fp16 on configs[3]'s pairs, every rank, same protocol; sized for >= ~1 s like the headline
         fsteps = max(20, min(args.steps, 1200))
         fmodel, fx, fstep = make_flow_runner(args, device, torch.float16, rank, world, "FlowNet2S", 16, args.gather)
-        fel = measure(fstep, fsteps, args.warmup, device)
+        fel, frep, ftot = measure(fstep, fsteps, args.warmup, device)
         if rank == 0:
             fplan = next(iter(fmodel._plans.values()))
             fval = 16 * world * fsteps / fel
             rec = {"metric": "flow frame-pairs/sec (FlowNet2S, 512x384)", "value": round(fval, 2), "unit": "pairs/s", "steps": fsteps,
-                   "ms_per_step": round(1e3 * fel / fsteps, 4), "timed_region_s": round(fel, 4), "dtype": "fp16",
+                   "ms_per_step": round(1e3 * fel / fsteps, 4), "repeats": frep, "timed_region_s": round(ftot, 4), "dtype": "fp16",
                    "config": {"workload": "FlowNet2S fp16, batch 16 x 512x384 synthetic frame pairs per GPU (BASELINE.json configs[3])",
                               "per_gpu_batch": 16},
                    "gflop_per_unit": round(fplan.prog.flops / 16 / 1e9, 3)}
@@ -462,16 +483,17 @@ def main():
         # (2) the pose step in fp32 parity mode (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, peak 157.3 TFLOP/s)
         psteps = max(10, min(args.steps // 10, 80))
         pmodel, px, pstep = make_pose_runner(args, device, torch.float32, rank, world, "resnet50", 256, 192, 64)
-        pel = measure(pstep, psteps, 3, device)
+        pel, prep, ptot = measure(pstep, psteps, 3, device)
         if rank == 0:
             pplan = next(iter(pmodel._plans.values()))
             pval = 64 * world * psteps / pel
             rec = {"value": round(pval, 2), "unit": "crops/s", "steps": psteps, "ms_per_step": round(1e3 * pel / psteps, 4),
-                   "timed_region_s": round(pel, 4), "dtype": "fp32",
+                   "repeats": prep, "timed_region_s": round(ptot, 4), "dtype": "fp32",
                    "note": "same workload in the parity arithmetic: heat maps <= 1e-3 and arg-max identical vs the CPU reference"}
             if not args.no_roofline:
                 proof, _ = conv_roofline(pplan.prog, "fp32")
-                rec["roofline"] = {k: proof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us")}
+                rec["roofline"] = {k: proof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
+                                                         "conv_ms_per_step")}
             out["fp32_parity_mode"] = rec
             # (3) parity of both modes on the benchmarked batch vs the CPU oracle (checker role only, outside timed regions)
             if world == 1:

@@ -84,6 +84,7 @@ _PROTOTYPES = {
                               c_void_p, c_void_p]),
     "ft_conv_flops": (c_double, [POINTER(ConvDesc)]),
     "ft_conv_direct_supported": (c_int, [POINTER(ConvDesc)]),
+    "ft_conv_direct_stream_id": (c_int, [POINTER(ConvDesc)]),
     "ft_conv_direct_weight_bytes": (ctypes.c_longlong, [POINTER(ConvDesc)]),
     "ft_conv_direct_pack": (c_int, [POINTER(ConvDesc), c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ft_conv_direct_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

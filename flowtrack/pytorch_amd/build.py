@@ -19,8 +19,8 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libflowtrack_hip.so")
 STAMP_PATH = os.path.join(HERE, ".libflowtrack_hip.stamp")
 
-SOURCES = ["conv_igemm.hip", "bottleneck.hip", "bottleneck_stream.hip", "conv_direct.hip", "aux_ops.hip", "flow_ops.hip", "crop_ops.hip", "runtime.hip"]
-HEADERS = [os.path.join(CSRC, "ft_common.h"), os.path.join(INCLUDE, "flowtrack_hip.h")]
+SOURCES = ["conv_igemm.hip", "conv_igemm8.hip", "bottleneck.hip", "bottleneck_stream.hip", "conv_direct.hip", "aux_ops.hip", "flow_ops.hip", "crop_ops.hip", "runtime.hip"]
+HEADERS = [os.path.join(CSRC, "ft_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(INCLUDE, "flowtrack_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -60,23 +60,35 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
+    fingerprint = _fingerprint()          # taken BEFORE compiling: an edit made while hipcc runs must not look built
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
+        # per-object stamp: one translation unit is recompiled only when it, a header or the flags changed
+        h = hashlib.sha256()
+        for path in [os.path.join(CSRC, src)] + HEADERS:
+            with open(path, "rb") as f:
+                h.update(f.read())
+        h.update(" ".join(FLAGS + [ARCH]).encode())
+        want, stamp = h.hexdigest(), obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            continue
         cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+        procs.append((src, subprocess.Popen(cmd), stamp, want))
+    for src, p, stamp, want in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+        with open(stamp, "w") as f:
+            f.write(want)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(STAMP_PATH, "w") as f:
-        f.write(_fingerprint())
+        f.write(fingerprint)
     return LIB_PATH
 
 

@@ -1005,6 +1005,17 @@ extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
   return ft::cd_plan(d, &pl);
 }
 
+// Which weight-stream layout ft_conv_direct_pack builds / ft_conv_direct_fwd expects for `d`: the form (whole-map 3x3, gather
+// or 1x1 with K split 1 / 4, weight-stationary) and its block counts.  The form depends on the pixel count, so one layer can
+// need more than one stream (one per id) when it runs at several batch sizes; all of them have the same byte count.
+extern "C" int ft_conv_direct_stream_id(const ft_conv_desc* d) {
+  ft::CdPlan pl;
+  ft::C3Plan p3;
+  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return 0x40000000 | (p3.ncb << 8) | p3.spt;
+  if (ft::cd_plan(d, &pl) != FT_OK) return -1;
+  return ((pl.ksplit + 1) << 24) | ((pl.nc1 + pl.nc2) << 12) | pl.ncb;
+}
+
 extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;

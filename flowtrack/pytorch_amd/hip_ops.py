@@ -164,12 +164,15 @@ class Program:
         self.lanes.append(0)
         self._choice_flops.append([self.flops, None])
 
-    def option(self) -> None:
+    def option(self, name: str = "") -> None:
+        """Start the next option of the innermost open choice.  `name` identifies the FORM ("fused" / "convs", "direct" /
+        "igemm"): benchmark picks are cached and persisted by name, never by position — the recording order follows
+        heuristics (bottleneck_prefers_fused, whether the direct form exists at all) that may change between versions."""
         base = self._choice_flops[-1]
         if base[1] is None and self.calls[-1][0] != "__choice__":
             base[1] = self.flops - base[0]          # flops of the first option: all options are the same arithmetic
         self.flops = base[0]
-        self.calls.append(("__option__", ()))
+        self.calls.append(("__option__", (name,)))
         self.lanes.append(0)
 
     def end_choice(self) -> None:
@@ -186,9 +189,10 @@ class Program:
             if name == "__choice__":
                 if stack:
                     stack[-1]["nested"] = True
-                stack.append({"key": args[0], "start": i, "marks": [], "nested": False})
+                stack.append({"key": args[0], "start": i, "marks": [], "names": [], "nested": False})
             elif name == "__option__":
                 stack[-1]["marks"].append(i)
+                stack[-1]["names"].append(args[0] or str(len(stack[-1]["names"])))
             elif name == "__endchoice__":
                 g = stack.pop()
                 g["marks"].append(i)
@@ -227,10 +231,10 @@ class Program:
         while True:
             groups = self._innermost_choices()
             if cached_only:
-                groups = [g for g in groups if "choice|" + g["key"] in _TILE_CACHE]
+                groups = [g for g in groups if _cached_choice(g) is not None]
             if not groups:
                 return
-            self._keep_options(groups, [min(int(_TILE_CACHE.get("choice|" + g["key"], 0)), len(g["marks"]) - 2) for g in groups])
+            self._keep_options(groups, [_cached_choice(g) or 0 for g in groups])
 
     @_on_plan_device
     def tune_choices(self, reps: int = 3, verbose: bool = False) -> int:
@@ -247,7 +251,7 @@ class Program:
             groups = self._innermost_choices()
             if not groups:
                 break
-            todo = [g for g in groups if "choice|" + g["key"] not in _TILE_CACHE]
+            todo = [g for g in groups if _cached_choice(g) is None]
             if todo:
                 marks = {}
                 for g in todo:
@@ -273,8 +277,9 @@ class Program:
                             ms = ctypes.c_float()
                             check(lib.ft_event_elapsed_ms(g["ev"][j], g["ev"][j + 1], ctypes.byref(ms)))
                             g["ms"][j] = min(g["ms"][j], ms.value)
-                total = {}
+                total, names = {}, {}
                 for g in todo:
+                    names[g["key"]] = g["names"]
                     tot = total.setdefault(g["key"], [0.0] * len(g["ms"]))
                     for j, v in enumerate(g["ms"]):
                         tot[j] += v
@@ -284,12 +289,12 @@ class Program:
                     best = min(range(len(tot)), key=lambda j: tot[j])
                     if tot[best] > 0.97 * tot[0]:
                         best = 0
-                    _TILE_CACHE["choice|" + key] = best
+                    _TILE_CACHE["choice|" + key] = names[key][best]
                     changed += best != 0
                     if verbose:
-                        print(f"[choice benchmark] {key:60s} " + "  ".join(f"{v * 1e3:7.1f} us" for v in tot) + f"  -> option {best}",
-                              file=sys.stderr)
-            self._keep_options(groups, [min(int(_TILE_CACHE.get("choice|" + g["key"], 0)), len(g["marks"]) - 2) for g in groups])
+                        print(f"[choice benchmark] {key:60s} " + "  ".join(f"{n} {v * 1e3:7.1f} us" for n, v in zip(names[key], tot)) +
+                              f"  -> {names[key][best]}", file=sys.stderr)
+            self._keep_options(groups, [_cached_choice(g) or 0 for g in groups])
         _save_tile_cache()
         return changed
 
@@ -621,6 +626,15 @@ _TILE_CACHE: dict = {}
 _TILE_CACHE_LOADED = False
 
 
+def _cached_choice(group: dict):
+    """Index of the cached pick of a choice group (picks are stored by option NAME), or None when the cache has none or names
+    a form this recording does not offer (a stale file: the group is benchmarked again)."""
+    name = _TILE_CACHE.get("choice|" + group["key"])
+    if not isinstance(name, str) or name not in group["names"]:
+        return None
+    return group["names"].index(name)
+
+
 def _desc_key(d: ConvDesc) -> str:
     return ",".join(str(getattr(d, f)) for f, _ in ConvDesc._fields_ if f != "tile_hint")
 
@@ -633,7 +647,10 @@ def _load_tile_cache() -> None:
     if tile_cache_path and os.path.isfile(tile_cache_path):
         try:
             with open(tile_cache_path) as f:
-                _TILE_CACHE.update({k: int(v) for k, v in json.load(f).items()})
+                # tile picks are integers (tile_hint values); choice picks are option names (a pre-name file's bare indices
+                # are dropped: the order they referred to is not recoverable)
+                _TILE_CACHE.update({k: (str(v) if k.startswith("choice|") else int(v)) for k, v in json.load(f).items()
+                                    if not (k.startswith("choice|") and not isinstance(v, str))})
         except (OSError, ValueError):
             pass
 
@@ -763,13 +780,13 @@ class FusedConv:
             # two forms of the same launch; the in-situ benchmark (Program.tune_choices) keeps the faster one
             dd = ConvDesc.from_buffer_copy(d)
             prog.begin_choice("conv|" + _desc_key(d))
-            prog.option()
+            prog.option("direct")
             prog.flops += flops
             prog.conv_records.append((self.label, len(prog.calls), flops, dd))
             prog.add("ft_conv_direct_fwd", ctypes.byref(dd), x.t.data_ptr(), ws.data_ptr(),
                      scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, res_ptr,
                      yt.data_ptr(), keep=(dd, x.t, yt, ws, scale, shift, residual.t if residual is not None else None))
-            prog.option()
+            prog.option("igemm")
         self._record_igemm(prog, d, x, w, scale, shift, res_ptr, yt, residual, flops)
         if ws is not None:
             prog.end_choice()
@@ -809,10 +826,16 @@ def _direct_stream(owner, d: ConvDesc, w: torch.Tensor, device) -> Optional[torc
         return None     # (beyond the bound only the weight-stationary short-K forms exist: ResNet layer2.0 / layer3.0 conv1)
     if lib.ft_conv_direct_supported(ctypes.byref(d)) != 0:
         return None
-    key = ("direct", int(lib.ft_conv_direct_weight_bytes(ctypes.byref(d))), d.N * d.Ho * d.Wo <= 0, w.data_ptr())
+    # one stream per LAYOUT: the kernel form (K split 1 / 4, weight-stationary, whole-map 3x3) follows the pixel count, every
+    # form orders the fragments differently and all of them have the same byte count — ft_conv_direct_stream_id tells them
+    # apart, so two plans of one model at batch sizes on either side of a form boundary each get their own stream
+    sid = int(lib.ft_conv_direct_stream_id(ctypes.byref(d)))
+    if sid < 0:
+        return None
+    key = ("direct", sid, w.data_ptr())
     hit = owner._packed.get(key)
     if hit is None:
-        ws = torch.empty(key[1], dtype=torch.uint8, device=device)
+        ws = torch.empty(int(lib.ft_conv_direct_weight_bytes(ctypes.byref(d))), dtype=torch.uint8, device=device)
         check(lib.ft_conv_direct_pack(ctypes.byref(d), w.data_ptr(), int(w.shape[-1]), int(w.shape[-2]), ws.data_ptr(),
                                       current_stream_handle(device)), "ft_conv_direct_pack")
         torch.cuda.current_stream(device).synchronize()
@@ -879,12 +902,12 @@ class FusedShortcutConv:
         if ws is not None:
             dd = ConvDesc.from_buffer_copy(d)
             prog.begin_choice("conv|" + _desc_key(d))
-            prog.option()
+            prog.option("direct")
             prog.flops += flops
             prog.conv_records.append((self.label, len(prog.calls), flops, dd))
             prog.add("ft_conv_direct_fwd", ctypes.byref(dd), t2.t.data_ptr(), ws.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),
                      y.t.data_ptr(), keep=(dd, t2.t, x.t, y.t, ws, shift))
-            prog.option()
+            prog.option("igemm")
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
         prog.add("ft_conv2d_fwd", ctypes.byref(d), t2.t.data_ptr(), w.data_ptr(), None, shift.data_ptr(), x.t.data_ptr(),

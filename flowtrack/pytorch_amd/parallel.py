@@ -70,30 +70,46 @@ class RowGatherer:
     batch order for contiguous equal shards).  Nothing is allocated, padded or concatenated per call; `depth` slots
     allow that many exchanges in flight.  On CPU tensors / gloo (the tests) the same calls run synchronously."""
 
-    def __init__(self, n_local: int, row_shape, dtype, device, depth: int = 2):
+    def __init__(self, n_local: int, row_shape, dtype, device, depth: int = 2, force_stream: bool = False):
+        """force_stream (single-process GPU tests): take the communication-stream path at world size 1 too, with a device
+        copy standing in for the collective — the wait_stream -> side-stream exchange -> event -> lagged finish() sequence of
+        the N > 1 path then runs on one GPU."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.n_local, self.depth = n_local, depth
         shape = (n_local,) + tuple(row_shape)
         self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = [torch.empty((self.world * n_local,) + tuple(row_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.cuda = torch.device(device).type == "cuda"
-        self.stream = torch.cuda.Stream(device) if self.cuda and self.world > 1 else None
+        self.stream = torch.cuda.Stream(device) if self.cuda and (self.world > 1 or force_stream) else None
         self.ready = [None] * depth      # per slot: event recorded on the comm stream once the exchange is queued
         self.slot = 0
+
+    def _exchange(self, k: int) -> None:
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv[k], self.send[k])
+        else:
+            self.recv[k].copy_(self.send[k])
 
     def start(self, rows: torch.Tensor) -> int:
         k = self.slot
         self.slot = (k + 1) % self.depth
-        if self.world == 1:
-            self.recv[k].copy_(rows)     # same contract (a stable buffer the caller may read later), no collective
-            return k
-        self.send[k].copy_(rows)
         if self.stream is None:
-            dist.all_gather_into_tensor(self.recv[k], self.send[k])
+            if self.world == 1:
+                self.recv[k].copy_(rows)     # same contract (a stable buffer the caller may read later), no collective
+            else:
+                self.send[k].copy_(rows)
+                self._exchange(k)
             return k
-        self.stream.wait_stream(torch.cuda.current_stream(rows.device))
+        cur = torch.cuda.current_stream(rows.device)
+        if self.ready[k] is not None:
+            # more than `depth` exchanges outstanding: the one that still owns this slot must be done reading send[k] /
+            # writing recv[k] before the slot is refilled (the caller never finish()ed it; its result is dropped)
+            cur.wait_event(self.ready[k])
+            self.ready[k] = None
+        self.send[k].copy_(rows)
+        self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            dist.all_gather_into_tensor(self.recv[k], self.send[k])
+            self._exchange(k)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.ready[k] = ev

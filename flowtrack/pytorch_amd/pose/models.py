@@ -177,10 +177,12 @@ class DeconvResnet(HipModule):
                         c1.record(prog, cur, t1)
                         c2.record(prog, t1, t2)
                         c3.record(prog, t2, out, residual=cur)
-                    forms = (fused_form, conv_form) if bottleneck_prefers_fused(cur, planes) else (conv_form, fused_form)
+                    forms = (("fused", fused_form), ("convs", conv_form))
+                    if not bottleneck_prefers_fused(cur, planes):
+                        forms = forms[::-1]
                     prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
-                    for form in forms:
-                        prog.option()
+                    for form_name, form in forms:
+                        prog.option(form_name)
                         form()
                     prog.end_choice()
                     cur = out
@@ -199,9 +201,9 @@ class DeconvResnet(HipModule):
                     # the 64-wide entry block whole (t1, t2 and the shortcut never leave the CU) or as head + K-concatenated
                     # conv3: both recorded, the first-call benchmark keeps one
                     prog.begin_choice(f"entry|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
-                    prog.option()
+                    prog.option("fused")
                     record_bottleneck_entry(prog, c1, c2, fused, cur, out, name + ".fused")
-                    prog.option()
+                    prog.option("head+exit")
                 if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
                     record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
                 else:

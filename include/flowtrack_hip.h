@@ -197,8 +197,14 @@ double ft_conv_flops(const ft_conv_desc* d);
  *                                Cin, x2_cin multiples of 256 and Cout of 64 for the K-split form)
  *   ft_conv_direct_weight_bytes  size of the weight stream
  *   ft_conv_direct_pack          builds it from the ft_conv_pack_geometry layout w_packed [cout_pad][kpad] (once per weight set)
- *   ft_conv_direct_fwd           arguments as ft_conv2d_fwd (residual = identity residual or the second input x2) */
+ *   ft_conv_direct_fwd           arguments as ft_conv2d_fwd (residual = identity residual or the second input x2)
+ *   ft_conv_direct_stream_id     identifies the stream LAYOUT `d` needs (>= 0; -1 when unsupported).  The kernel form — and
+ *                                with it the fragment order of the stream — depends on the pixel count N * Ho * Wo, not only on
+ *                                the weights: a stream packed for one descriptor may be passed to ft_conv_direct_fwd with
+ *                                another descriptor only when both report the same id (all layouts of a layer have the same
+ *                                byte count, so the size does not tell them apart). */
 int ft_conv_direct_supported(const ft_conv_desc* d);
+int ft_conv_direct_stream_id(const ft_conv_desc* d);
 long long ft_conv_direct_weight_bytes(const ft_conv_desc* d);
 int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, int kpad, int cout_pad, void* wstream, ft_stream_t stream);
 int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const void* wstream, const float* scale, const float* shift,

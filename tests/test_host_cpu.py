@@ -208,10 +208,25 @@ def test_tile_candidates_and_fusion_descriptors(hip_lib):
     assert _geom(hip_lib, kc)[0] == 2                    # a second input needs a 1x1 main conv: unsupported
     kc.kh = kc.kw = 1; kc.pad = 0; kc.x2_hi = 18
     assert _geom(hip_lib, kc)[0] == 1                    # second input does not line up with the output grid
-    # fused tail: fp16, Cout in {64,128,256}, <= 32 tail outputs; one variant only; FLOPs include the tail GEMM
+    # fused tail: fp16, Cout in {64,128,256}, <= 32 tail outputs; FLOPs include the tail GEMM.  256 channels with Cin % 64 == 0:
+    # two variants (the 128-pixel 8-wave tile and the 256 x 256 8-phase tile, wide level 3); otherwise one, nothing to pick
     tl = _desc(dtype=_lib.FT_F16, N=2, Hi=8, Wi=6, Cin=256, x_cstride=256, Cout=256, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=16, Wo=12,
                out_layout=1, y_cstride=0, tail_cout=17)
-    assert _geom(hip_lib, tl)[0] == 0 and _hints(hip_lib, tl) == []
+    assert _geom(hip_lib, tl)[0] == 0
+    assert [(h["bp"], h["bc"], h["wide"], h["sk"]) for h in map(_decode, _hints(hip_lib, tl))] == [(128, 256, 0, 1), (256, 256, 3, 1)]
+    tl128 = _desc(dtype=_lib.FT_F16, N=2, Hi=8, Wi=6, Cin=64, x_cstride=64, Cout=128, kh=4, kw=4, stride=2, pad=1, transposed=1, Ho=16, Wo=12,
+                  out_layout=1, y_cstride=0, tail_cout=17)
+    assert _geom(hip_lib, tl128)[0] == 0 and _hints(hip_lib, tl128) == []
+    # the 8-phase tile is offered for fp16 layers with Cin % 64 == 0 and Cout % 256 == 0 only, with split-K forms when the
+    # layer has fewer 256 x 256 tiles than CUs (deconv.0 of the pose head at batch 64: 48 tiles)
+    d0 = _desc(dtype=_lib.FT_F16, N=64, Hi=8, Wi=6, Cin=2048, x_cstride=2048, Cout=256, y_cstride=256, kh=4, kw=4, stride=2, pad=1,
+               transposed=1, Ho=16, Wo=12)
+    h8 = [h for h in map(_decode, _hints(hip_lib, d0)) if h["wide"] == 3]
+    assert sorted(h["sk"] for h in h8) == [1, 2, 4, 8] and all((h["bp"], h["bc"], h["ks"], h["halo"]) == (256, 256, 1, 0) for h in h8)
+    for bad in (dict(Cin=96, x_cstride=96), dict(Cout=128, y_cstride=128), dict(dtype=_lib.FT_F32)):
+        kw = dict(dtype=_lib.FT_F16, N=8, Hi=32, Wi=24, Ho=32, Wo=24, Cin=128, x_cstride=128, Cout=256, y_cstride=256)
+        kw.update(bad)
+        assert not any(h["wide"] == 3 for h in map(_decode, _hints(hip_lib, _desc(**kw)))), bad
     assert hip_lib.ft_conv_flops(ctypes.byref(tl)) == 2.0 * 2 * 16 * 12 * 256 * (256 * 4 + 17)
     tl.tail_cout = 33
     assert _geom(hip_lib, tl)[0] == 1
@@ -284,20 +299,20 @@ def test_program_choice_groups_bookkeeping(hip_lib, monkeypatch):
         prog.add("a")
         prog.flops += 1.0
         prog.begin_choice("blk")
-        prog.option()                                   # option 0: one fused launch
+        prog.option("fused")                            # option 0: one fused launch
         prog.flops += 10.0
         prog.fused_records.append(("blk.fused", len(prog.calls), 10.0))
         prog.add("fused")
-        prog.option()                                   # option 1: three launches, the middle one itself a choice
+        prog.option("convs")                            # option 1: three launches, the middle one itself a choice
         prog.flops += 3.0
         prog.conv_records.append(("c1", len(prog.calls), 3.0, None))
         prog.add("c1")
         prog.begin_choice("c2")
-        prog.option()
+        prog.option("direct")
         prog.flops += 4.0
         prog.conv_records.append(("c2.direct", len(prog.calls), 4.0, None))
         prog.add("c2_direct")
-        prog.option()
+        prog.option("igemm")
         prog.flops += 4.0
         prog.conv_records.append(("c2.igemm", len(prog.calls), 4.0, None))
         prog.add("c2_igemm")
@@ -315,13 +330,22 @@ def test_program_choice_groups_bookkeeping(hip_lib, monkeypatch):
     assert [c[0] for c in prog.calls] == ["a", "fused", "z"] and prog.lanes == [0, 0, 0]
     assert prog.fused_records == [("blk.fused", 1, 10.0)] and prog.conv_records == []
 
-    hip_ops._TILE_CACHE.update({"choice|blk": 1, "choice|c2": 1})
+    hip_ops._TILE_CACHE.update({"choice|blk": "convs", "choice|c2": "igemm"})      # picks are cached by option NAME
     prog = build()
     prog.resolve_choices()
     assert [c[0] for c in prog.calls] == ["a", "c1", "c2_igemm", "c3", "z"]
     assert [(r[0], r[1]) for r in prog.conv_records] == [("c1", 1), ("c2.igemm", 2), ("c3", 3)] and prog.fused_records == []
 
-    hip_ops._TILE_CACHE.update({"choice|c2": 0})
+    hip_ops._TILE_CACHE.update({"choice|c2": "direct"})
     prog = build()
     prog.resolve_choices()
     assert [c[0] for c in prog.calls] == ["a", "c1", "c2_direct", "c3", "z"]
+
+    # a stale cache — a bare index from a file written before picks were named, or a form this recording does not offer —
+    # is ignored: cached_only leaves the group for the benchmark, a plain resolve falls back to the recorder's first choice
+    hip_ops._TILE_CACHE.update({"choice|blk": 1, "choice|c2": "weight-stationary"})
+    prog = build()
+    prog.resolve_choices(cached_only=True)
+    assert sum(1 for c in prog.calls if c[0] == "__choice__") == 2
+    prog.resolve_choices()
+    assert [c[0] for c in prog.calls] == ["a", "fused", "z"]

@@ -233,6 +233,25 @@ def test_tracking_pass_keeps_five_ids_for_five_people():
     assert max(len(f["boxes"]) for f in out) <= 12
 
 
+def test_tracking_pass_keeps_every_nms_survivor_when_the_detector_misses():
+    """The reference's process_frame keeps `dets[keep]` for every NMS survivor above thresh (tools/tracking/demo.py:38-41): in
+    a frame where the detector returns nothing, the boxes propagated from the previous poses carry all five tracks (and their
+    ids) through; with two detections out of five the three propagated boxes still stay.  No default cap on the union."""
+    from tools.tracking import demo
+    T = 30
+    dets, gts, flows = _separated_people(T)
+    dets[10] = np.zeros((0, 5), dtype=np.float32)
+    dets[20] = dets[20][:2]
+    kp_det = [_gt_pose(gts[t], dets[t][:, :4]) for t in range(T)]
+    out = demo.tracking_pass(dets, kp_det, flows, lambda t, boxes: _gt_pose(gts[t], boxes))
+    assert [len(f["boxes"]) for f in out] == [5] * T
+    ids = [tuple(sorted(f["ids"])) for f in out]
+    assert all(i == ids[0] for i in ids) and len(set(ids[0])) == 5
+    # the opt-in bound of the synthetic-weights demo ("2x" the detector boxes, at least 4) does drop tracks there
+    capped = demo.tracking_pass(dets, kp_det, flows, lambda t, boxes: _gt_pose(gts[t], boxes), max_boxes="2x")
+    assert len(capped[10]["boxes"]) == 4 and len(capped[20]["boxes"]) == 4
+
+
 @pytest.mark.gpu
 def test_clip_pipeline_functional_signal_on_gpu(hip_lib):
     """The GPU pieces of the clip pipeline (device-resident clip, ft_crop_affine_fwd crops, heat-map arg-max + inverse

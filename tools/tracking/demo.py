@@ -95,9 +95,11 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
     boxes that survive, flow-based greedy id assignment.
     dets[t]: [n,5] detector boxes; kp_det[t]: [n,17,3] their key points; flows: [T-1,2,H,W] (host array or anything
     indexable by t giving a [2,H,W] numpy field); pose_boxes(t, boxes[m,4]) -> [m,17,3] for the propagated-only boxes.
-    `max_boxes` bounds the work of a frame (highest scores kept; default: twice the frame's detector boxes — every
-    detection plus one propagated box each): the union is the reference's, and nothing in it ages a propagated box that
-    keeps out-scoring the detector, so an untrained pose net can make the box count grow without limit."""
+    Every NMS survivor is kept, as in the reference (process_frame keeps `dets[keep]`, demo.py:40-41).  `max_boxes` is an
+    explicit opt-in bound on the work of a frame (highest scores kept): an int, or "2x" = twice the frame's detector boxes
+    (every detection plus one propagated box each).  Nothing in the reference's union ages a propagated box that keeps
+    out-scoring the detector, so with an UNTRAINED pose net the box count can grow frame after frame; the synthetic-weights
+    demo therefore passes "2x" (main(), --max_boxes), a trained model runs uncapped."""
     from flowtrack.pytorch_amd.tracking.flow_utils import nms
     tracker = FlowTracker()
     out, prev_kp, prev_dets = [], None, None
@@ -111,7 +113,9 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
             prop = box_propagation(prev_kp, flow)                                         # flow_utils.py:7-35
             prop_dets = np.concatenate((prop, prev_dets[:, 4:5]), axis=1).astype(np.float32)  # demo.py:38
             allb = np.concatenate((cur, prop_dets), 0)
-            keep = nms(allb, thresh)[:max_boxes if max_boxes is not None else max(2 * n_det, 4)]   # (score-descending)
+            keep = nms(allb, thresh)                                                      # (score-descending)
+            if max_boxes is not None:
+                keep = keep[:max(2 * n_det, 4) if max_boxes == "2x" else int(max_boxes)]
             cur, src = allb[keep], keep
         kps = np.zeros((len(cur), 17, 3), dtype=np.float32)
         from_det = src < n_det
@@ -125,7 +129,7 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
 
 
 def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow_batch=16, pose_frames=6, pose_fn=None,
-             flow_fn=None, device=None):
+             flow_fn=None, device=None, max_boxes=None):
     """Returns (per-frame dict list on rank 0 | None elsewhere, timing dict).
     pose_fn(frame [H,W,3] uint8 tensor, boxes [n,4]) -> [n,17,3] and flow_fn(ims [b,3,2,Hp,Wp]) -> [b,2,Hp,Wp] default to
     the HIP networks (pose_est / flow_net); the CPU tests inject stand-ins to check the sharding (device="cpu")."""
@@ -178,7 +182,7 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     t0 = time.perf_counter()
     flows_np = flows_host.numpy()
     out = tracking_pass(dets, [kp_all[t, :len(dets[t])] for t in range(T)], flows_np,
-                        lambda t, boxes: pose_fn(fr[t], boxes), thresh)
+                        lambda t, boxes: pose_fn(fr[t], boxes), thresh, max_boxes)
     tm["track_s"] = time.perf_counter() - t0
     return out, tm
 
@@ -193,16 +197,22 @@ def main(argv=None):
     ap.add_argument("--flow_model", type=str, default="", help="optical flow checkpoint (ckpt['state_dict'])")
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--max_boxes", type=str, default="auto",
+                    help="boxes kept per frame after NMS: 'none' (the reference: every survivor), an integer, '2x' = twice the "
+                         "detector boxes; 'auto' = 'none' with --pose_model, '2x' with the synthetic (untrained) weights")
     args = ap.parse_args(argv)
+    max_boxes = {"auto": None if args.pose_model else "2x", "none": None, "2x": "2x"}.get(args.max_boxes)
+    if args.max_boxes not in ("auto", "none", "2x"):
+        max_boxes = int(args.max_boxes)
     rank, local_rank, world = parallel.init_from_env()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     pose_net, flow_net = build_nets(args, device)
     frames, dets = synthetic_clip(args.frames, n_people=args.people)
-    run_clip(frames, dets, pose_net, flow_net, rank, world)                               # warm-up: every plan / graph the timed run replays
+    run_clip(frames, dets, pose_net, flow_net, rank, world, max_boxes=max_boxes)          # warm-up: every plan / graph the timed run replays
     parallel.barrier()
     t0 = time.perf_counter()
-    out, tm = run_clip(frames, dets, pose_net, flow_net, rank, world)
+    out, tm = run_clip(frames, dets, pose_net, flow_net, rank, world, max_boxes=max_boxes)
     parallel.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
