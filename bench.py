@@ -285,7 +285,7 @@ def pose_parity(models_by_mode, x_cpu, seed, H, W, oracle_out=None):
     return out
 
 
-def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B):
+def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B, force_gather=False):
     """(model, x, step): the pose hot path on a batch resident in HBM, arg-max inside the plan's graph.  N > 1: the
     [B,17,3] key-point rows of every rank are all-gathered (3.3 kB per rank) on a communication stream, one step behind
     the compute stream (parallel.RowGatherer): step t's graph replays while step t-1's rows travel."""
@@ -294,7 +294,8 @@ def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B):
     x = model.static_input(B, H, W)                         # zero-copy binding: the batch is resident in HBM at the
     x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
     kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
-    gather = parallel.RowGatherer(B, (17, 3), torch.float32, device) if world > 1 else None
+    # force_gather (single-GPU tests): run the communication-stream path of the N > 1 step on one GPU
+    gather = parallel.RowGatherer(B, (17, 3), torch.float32, device, force_stream=force_gather) if (world > 1 or force_gather) else None
     state = {"pending": None}
 
     def consume(h):
@@ -319,7 +320,7 @@ def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B):
     return model, x, step
 
 
-def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sampled"):
+def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sampled", force_gather=False):
     """FlowNet on B frame pairs resident in HBM.  What leaves the GPU per step is what the consumer of the flow needs:
     the tracking glue reads the field at the previous frame's key points (lib/tracking/flow_utils.py:21-26), so by default
     the step samples the field at 8 x 17 points per pair and (N > 1) all-gathers those rows (1 kB per pair); `full`
@@ -332,8 +333,8 @@ def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sam
     idx = (pts * (384 * 512 - 1)).long()
     full = gather_mode == "full"
     gather = None
-    if world > 1 and gather_mode != "none":
-        gather = parallel.RowGatherer(B, (2, 384, 512) if full else (2, npts), torch.float32, device)
+    if (world > 1 or force_gather) and gather_mode != "none":
+        gather = parallel.RowGatherer(B, (2, 384, 512) if full else (2, npts), torch.float32, device, force_stream=force_gather)
     samples = torch.empty((B, 2, npts), dtype=torch.float32, device=device)
     state = {"pending": None}
 

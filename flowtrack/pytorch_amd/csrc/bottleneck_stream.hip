@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
               const int m = m_out[j];
               *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
             } else if (!(p.dbg & 4)) {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, y_voff[j], (q * P + i * 32 + h * 8) * 2, FT_YSTORE_BUF_AUX);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, y_voff[j] + (unsigned)((q * P + i * 32 + h * 8) * 2), 0, FT_YSTORE_BUF_AUX);
             }
           }
         }
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 #pragma unroll
         for (int k = 0; k < NSTG; ++k) {
           const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
-          if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
+          if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k] + (unsigned)(q * P * 2), 0, FT_YSTORE_BUF_AUX);
         }
         if constexpr (P == 256 && q < 3) {
           // the staging tile sat in a weight buffer: hand it back (its refill with step glast + 3 was deferred)
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #else
         // straight from the accumulator layout: the lane's 16 consecutive channels = two adjacent 16-byte stores
         const unsigned vo = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + ch + 8 * h) * 2) : kOOB;
-        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo, q * P * 2, FT_BNS_DIRECT_AUX);
+        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo + (unsigned)(q * P * 2), 0, FT_BNS_DIRECT_AUX);
 #endif
       }
     };
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
       for (int k = 0; k < NSTG; ++k) {
         const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + s_off[k]);
-        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k], q * P * 2, FT_YSTORE_BUF_AUX);
+        if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k] + (unsigned)(q * P * 2), 0, FT_YSTORE_BUF_AUX);
       }
     };
     [[maybe_unused]] auto zero_set = [&](float16_t (&A)[2][MT2]) {

@@ -59,6 +59,8 @@ struct ConvParams {
   int h_tx, h_ty;     // halo path: patch tiles per image row / column
   int h_pw, h_npix;   // halo path: input-patch width and pixel count
   int h_npww, h_pb;   // halo path: patch wave-loads per wave per chunk, bytes of one patch buffer
+  unsigned y_bytes;   // conv_igemm8_kernel: size of the output buffer (buffer descriptor range of its direct stores)
+  unsigned w_bytes;   // conv_igemm8_kernel: size of the packed weight set (all phases and channel tiles)
   int dbg;            // developer ablation (FT_CONV_DBG): 1 = no MFMA, 2 = no operand loads, 4 = no epilogue; 0 in production
 };
 
@@ -360,8 +362,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
   }
 }
 
-// conv_igemm8.hip: the 256 x 256 tile on the 8-phase ping-pong schedule (fp16, Cin % 64 == 0, Cout_pad % 256 == 0, no second
-// input); p.kc / p.nk count 64-channel K-tiles, grid = p.npt * p.nct * p.nph * p.sk workgroups of 512 threads.
-int launch_igemm8(const ConvParams& p, unsigned grid, hipStream_t s);
+// conv_igemm8.hip: the 256 x 256 tile on the 8-phase ping-pong schedule, persistent (fp16, Cin % 64 == 0, Cout_pad % 256 == 0,
+// no second input, no residual; output = NHWC fp16 in 8-channel-aligned views, the fused tail's map, or split-K partials);
+// p.kc / p.nk count 64-channel K-tiles, `tiles` = p.npt * p.nct * p.nph * p.sk; one workgroup of 512 threads per CU walks them.
+int launch_igemm8(const ConvParams& p, unsigned tiles, hipStream_t s);
 
 }  // namespace ft

@@ -2091,7 +2091,13 @@ constexpr int kWide8 = 3;           // tile_hint bits 28-29 == 3: the 256 x 256 
 
 // conv_igemm8_kernel: fp16, channel-aligned layout, 64-channel K-tiles (cin_pad % 64 == 0), all-256-channel tiles, no second input
 static bool igemm8_ok(const ft_conv_desc* d, const Geometry& g) {
-  return g.dma && !g.rowpack && d->dtype == FT_F16 && g.kc2 == 0 && g.kc % 2 == 0 && g.cout_pad % 256 == 0 && g.nk / 2 >= 2;
+  if (!(g.dma && !g.rowpack && d->dtype == FT_F16 && g.kc2 == 0 && g.kc % 2 == 0 && g.cout_pad % 256 == 0 && g.nk / 2 >= 2)) return false;
+  if (d->has_residual) return false;     // results leave straight from the accumulator registers: no residual pick-up
+  if ((unsigned long long)g.nphases * g.cout_pad * g.kpad * 2 >= (1ull << 31)) return false;   // one buffer descriptor over all weights
+  if (g.cout_pad > 1024) return false;   // folded-BN scale / shift of every output channel sit in 8 KiB of LDS
+  if (d->tail_cout > 0) return d->Cout == 256 && d->tail_cout <= 24;   // (the channel halves exchange 12 registers = 24 outputs)
+  if (!(d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0)) return false;
+  return (unsigned long long)d->N * d->Ho * d->Wo * d->y_cstride * 2 < (1ull << 31);
 }
 
 static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc, int ks, int wide = 0, bool halo = false,
@@ -2099,7 +2105,10 @@ static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc,
   if (!g.dma) return false;
   if (wide == kWide8) {
     if (!igemm8_ok(d, g) || bp != 256 || bc != 256 || ks != 1 || halo) return false;
-    if (sk != 1 && (!(sk == 2 || sk == 4 || sk == 8) || d->tail_cout > 0 || (g.nk / 2) / sk < 4)) return false;
+    if (sk != 1) {     // every K slice = ceil(K-tiles / sk) but the last, which must still hold two K-tiles (the kernel's tile hand-over)
+      const int nk8 = g.nk / 2, per = (nk8 + sk - 1) / sk;
+      if (!(sk == 2 || sk == 4 || sk == 8) || d->tail_cout > 0 || per < 4 || nk8 - (sk - 1) * per < 2) return false;
+    }
     return true;
   }
   if (sk != 1) {     // split-K across workgroups: fp32 partial tiles in a workspace + a reduce launch
@@ -2373,6 +2382,8 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
       p.kc = g.kc >> 1;
       p.nk = g.nk >> 1;
       if ((long long)p.npt * p.nph > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+      p.y_bytes = 0;     // (the tail writes through plain pointers)
+      p.w_bytes = (unsigned)((unsigned long long)g.nphases * g.cout_pad * g.kpad * 2);
       const int rc8 = launch_igemm8(p, (unsigned)(p.npt * p.nph), s);
       if (rc8 != FT_OK) return rc8;
       FT_LAUNCH_CHECK("conv_igemm8_kernel (tail)");
@@ -2456,17 +2467,16 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
       p.npt = ceil_div(p.M, 256);
       p.nct = g.cout_pad / 256;
       if ((long long)p.npt * p.nct * p.nph * sk > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
-      const char* const res8 = p.res;
+      p.y_bytes = (unsigned)((unsigned long long)d->N * d->Ho * d->Wo * d->y_cstride * 2);
+      p.w_bytes = (unsigned)((unsigned long long)g.nphases * g.cout_pad * g.kpad * 2);
       if (sk > 1) {
         p.sk = sk;
         p.ws = static_cast<float*>(workspace);
-        p.res = nullptr;
       }
       const int rc8 = launch_igemm8(p, (unsigned)(p.npt * p.nct * p.nph * sk), s);
       if (rc8 != FT_OK) return rc8;
       FT_LAUNCH_CHECK("conv_igemm8_kernel");
       if (sk > 1) {
-        p.res = res8;
         const size_t total = (size_t)p.nph * p.M * (p.Cout_pad / 4);
         const unsigned rgrid = (unsigned)(total / 256 + 1 > 4096 ? 4096 : total / 256 + 1);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel<half_t>, dim3(rgrid), dim3(256), 0, s, p);

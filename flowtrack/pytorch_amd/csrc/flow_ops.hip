@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
               const int px = idx / npc, pc = idx - px * npc;
               const uint4_t v = *reinterpret_cast<const uint4_t*>(src + (px < 64 ? px : 63) * PROW + pc * 16);
               const unsigned vo = (px < 64 && px < W) ? (unsigned)((((n * H) * W + px) * y_cstride) * 2 + pc * 16) : kOOB;
-              __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, soff, FT_YSTORE_BUF_AUX);
+              __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo + (unsigned)soff, 0, FT_YSTORE_BUF_AUX);
             }
             if constexpr (tail == 2) {
               const int px = tid;

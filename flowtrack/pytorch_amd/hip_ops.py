@@ -709,8 +709,17 @@ class FusedConv:
             b32 = torch.zeros(32, dtype=torch.float32)
             if tail_bias is not None:
                 b32[:n] = tail_bias.detach().float().cpu()
-            self._tail = torch.cat((w16.view(torch.uint8).flatten(), b32.view(torch.uint8).flatten(),
-                                    wlo.view(torch.uint8).flatten())).to(device)
+            parts = [w16.view(torch.uint8).flatten(), b32.view(torch.uint8).flatten(), wlo.view(torch.uint8).flatten()]
+            if self.cout == 256:
+                # 4th section (include/flowtrack_hip.h, tail pack): the same hi / lo weights in the 8-phase tile's operand order,
+                # fp16 [channel half wc][step st][hi, lo][lane = lhi * 32 + tail output][8]: channels wc * 128 + st * 16 + 4 lhi +
+                # {0..3} and + 8 + {0..3} — the K order in which that kernel's accumulator registers hold a pixel's channels
+                wc, st, lhi, e = torch.meshgrid(torch.arange(2), torch.arange(8), torch.arange(2), torch.arange(8), indexing="ij")
+                ch = wc * 128 + st * 16 + 4 * lhi + (e % 4) + 8 * (e // 4)                  # [2, 8, 2, 8]
+                perm = torch.stack([t[:, ch] for t in (w16, wlo)], dim=0)                    # [hl, 32 rows, wc, st, lhi, e]
+                perm = perm.permute(2, 3, 0, 4, 1, 5).contiguous()                           # [wc, st, hl, lhi, row, e]
+                parts.append(perm.view(torch.uint8).flatten())
+            self._tail = torch.cat(parts).to(device)
             self.tail_cout = n
 
     def _packed_for(self, d: ConvDesc):

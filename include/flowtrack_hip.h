@@ -137,7 +137,10 @@ typedef struct ft_conv_desc {
    * last layers, `heatmap(deconv(...))` (lib/pose/models/pose_deconv.py:43-45), and saves the round trip of the
    * largest tensor of the head.  Requirements: FT_F16, Cout in {64, 128, 256}, has_residual = 0, x2_cin = 0; the
    * tail pack — fp16 [32][Cout] weights `hi` (rows >= tail_cout zero), fp32 [32] bias, fp16 [32][Cout] `lo` with
-   * w = hi + lo (the tail weights keep ~22 bits: the heatmap conv decides the arg-max) — is passed in
+   * w = hi + lo (the tail weights keep ~22 bits: the heatmap conv decides the arg-max), and, REQUIRED when Cout = 256
+   * and `tile_hint` selects the 8-phase tile (bits 28-29 == 3; never chosen without a hint): the same weights once more in
+   * that kernel's operand order, fp16 [2][8][2][64][8] = [channel half wc][step st][hi, lo][lane = lhi * 32 + tail output][e]
+   * holding channel wc * 128 + st * 16 + 4 * lhi + e % 4 + 8 * (e / 4) (32 KiB; total pack 64 KiB + 128 B) — is passed in
    * ft_conv2d_fwd's `residual` argument; `y` / out_layout / y_cstride / y_coff describe the TAIL output
    * (Ho x Wo x tail_cout).  tail_cout = 0: none. */
   int tail_cout;

@@ -58,7 +58,7 @@ def test_pose_r101_384x288_batch16_fp16_vs_fp32(hip_lib):
     assert tuple(hm32.shape) == (16, 17, 96, 72) and torch.isfinite(hm16).all()
     rng = (hm32.max() - hm32.min()).item()
     err = (hm16 - hm32).abs().max().item()
-    assert err <= 0.05 * rng, f"fp16 heatmap error {err:.3e} vs range {rng:.3f}"
+    assert err <= 4e-3 * rng, f"fp16 heatmap error {err:.3e} vs range {rng:.3f} (guard = ~3x the measured 0.1 % of range)"
     i32, s32, _ = heatmap_max_preds(hm32, adjust_coords=False)
     i16, _, _ = heatmap_max_preds(hm16, adjust_coords=False)
     same = (i32 == i16).float().mean().item()
@@ -66,7 +66,7 @@ def test_pose_r101_384x288_batch16_fp16_vs_fp32(hip_lib):
     top2 = flat.topk(2, dim=2).values
     margin = (top2[..., 0] - top2[..., 1])
     flipped = (i32 != i16)
-    assert same >= 0.9 and (not flipped.any() or margin[flipped].max().item() <= 2 * err), \
+    assert same >= 0.97 and (not flipped.any() or margin[flipped].max().item() <= 2 * err), \
         f"{same:.3f} identical arg-max; a flip without a near-tie"
 
 
@@ -119,7 +119,10 @@ def test_full_size_batches_match_the_cpu_oracle(hip_lib, oracle_lib):
     assert torch.equal(got.flatten(2).argmax(2), want.flatten(2).argmax(2))
     got16 = _pose(50, torch.float16)(x.cuda()).cpu()
     rng = (want.max() - want.min()).item()
-    assert (got16 - want).abs().max().item() <= 0.05 * rng
+    e16 = (got16 - want).abs().max().item()
+    same16 = (got16.flatten(2).argmax(2) == want.flatten(2).argmax(2)).float().mean().item()
+    # measured: 0.08 % of the range, 98.4-99.3 % identical arg-max; the guards leave ~3x room
+    assert e16 <= 3e-3 * rng and same16 >= 0.97, f"fp16: max abs err {e16:.3e} on a range of {rng:.2f}, {same16:.4f} identical arg-max"
     pairs = synth.frame_pairs(SEED + 12, 16)
     f = flow_models.FlowNet2S(ARGS)
     fsd = synth.fill_flow_state_dict(f.state_dict(), SEED)
@@ -178,4 +181,7 @@ def test_r101_384x288_batch16_matches_the_cpu_oracle(hip_lib):
     assert e32 <= 1e-3, f"R101 384x288 fp32: max abs err {e32:.3e} vs the north_star bar 1e-3 (measured round 1: ~1e-5)"
     assert torch.equal(got.flatten(2).argmax(2), want.flatten(2).argmax(2))
     got16 = _pose(101, torch.float16)(x.cuda()).cpu()
-    assert (got16 - want).abs().max().item() <= 0.05 * (want.max() - want.min()).item()
+    rng = (want.max() - want.min()).item()
+    e16 = (got16 - want).abs().max().item()
+    same16 = (got16.flatten(2).argmax(2) == want.flatten(2).argmax(2)).float().mean().item()
+    assert e16 <= 4e-3 * rng and same16 >= 0.97, f"R101 fp16: max abs err {e16:.3e} on a range of {rng:.2f}, {same16:.4f} identical arg-max"

@@ -81,8 +81,9 @@ def test_max_preds_edge_cases(hip_lib):
 
 def test_pose_fp16_vs_fp32_oracle(hip_lib):
     """fp16 storage / fp32 accumulate (configs C2): report error and arg-max agreement vs the fp32 CPU
-    oracle. Bar: max-abs <= 5e-2 of the heatmap range, >= 90 % identical arg-max, and every mismatch
-    must be a near-tie (reference top-1/top-2 margin below the fp16 error)."""
+    oracle.  Guards sit at ~3x what is measured (0.08 % of the heat-map range, 98.4-99.3 % identical arg-max — DESIGN §4,
+    bench.py `parity`): max-abs <= 0.3 % of the range, >= 97 % identical arg-max, and every mismatch must be a near-tie
+    (reference top-1/top-2 margin below the fp16 error).  A kernel that corrupts one tile in a hundred fails these."""
     B, H, W = (int(v) for v in G["r50_shape"])
     m, sd = _model(50, torch.float16)
     x = synth.pose_crops(SEED, B, H, W)
@@ -90,10 +91,10 @@ def test_pose_fp16_vs_fp32_oracle(hip_lib):
     want = pose_ref.pose_forward(sd, x, depth=50)
     err = (hm - want).abs().max().item()
     rng = (want.max() - want.min()).item()
-    assert err <= 5e-2 * rng, f"fp16 heatmap error {err:.3e} vs range {rng:.2f}"
+    assert err <= 3e-3 * rng, f"fp16 heatmap error {err:.3e} vs range {rng:.2f}"
     oc, os_, oi = keypoints_ref.max_preds_ref(hm.numpy())
     same = oi == G["r50_idx"]
-    assert same.mean() >= 0.9, f"only {same.mean():.3f} of arg-max indices match"
+    assert same.mean() >= 0.97, f"only {same.mean():.3f} of arg-max indices match"
     margin = G["r50_margin"]
     assert np.all(margin[~same] <= 2 * err + 1e-6), "an arg-max flip that is not explained by a near-tie"
     # mAP@OKS with the CPU-reference keypoints as annotations
@@ -217,3 +218,94 @@ def test_in_place_parameter_edits_rebuild_the_packed_weights(hip_lib):
     m.heatmap.bias.data.add_(0.25)                     # `.data` edits carry no version counter: refresh() is the contract
     m.refresh()
     assert (m(x) - a - 0.25).abs().max().item() <= 2e-3
+
+
+def test_row_gatherer_comm_stream_path_on_one_gpu(hip_lib):
+    """The branch of parallel.RowGatherer that only world > 1 on GPUs takes — wait_stream on the compute stream, the exchange
+    on a communication stream, an event handed back, finish() one step late — run on ONE GPU (force_stream: a device copy
+    stands in for the collective) while the pose plan's graph replays on the compute stream: over 50 steps with a different
+    batch each, the lagged rows are exactly the rows step t-1 produced.  (Replaces, on the reference side, the DataParallel
+    gather of tools/flownet/main.py:133-134,186,197.)"""
+    from flowtrack.pytorch_amd import parallel
+    B = 8
+    m, _ = _model(50, torch.float16)
+    m.keypoints_in_plan = True
+    x = m.static_input(B, 256, 192)
+    base = synth.pose_crops(SEED + 31, B).cuda()
+    g = parallel.RowGatherer(B, (17, 3), torch.float32, x.device, depth=2, force_stream=True)
+    assert g.stream is not None and g.world == 1
+    produced, lagged, pending = [], [], None
+    for t in range(50):
+        x.copy_(torch.roll(base, shifts=3 * t, dims=3))
+        rows = m.forward_keypoint_rows(x)
+        produced.append(rows.clone())
+        h = g.start(rows)
+        if pending is not None:
+            lagged.append(g.finish(pending).clone())
+        pending = h
+    lagged.append(g.finish(pending).clone())
+    torch.cuda.synchronize()
+    assert len(lagged) == 50 and all(torch.equal(a, b) for a, b in zip(produced, lagged))
+    assert not all(torch.equal(produced[0], p) for p in produced[1:]), "the batches were meant to differ"
+    # more starts outstanding than slots: the slot guard makes the refill wait for the exchange that still owns the slot
+    hs = [g.start(produced[i]) for i in range(5)]
+    torch.cuda.synchronize()
+    assert torch.equal(g.finish(hs[-1]), produced[4]) and torch.equal(g.finish(hs[-2]), produced[3])
+
+
+def test_bench_runners_take_the_comm_stream_path_on_one_gpu(hip_lib):
+    """bench.py's N > 1 step (graph replay -> RowGatherer.start -> consume the previous step's rows) for both workloads, on
+    one GPU through the force_gather hook: the drained result equals a plain forward of the same resident batch."""
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda", 0)
+    args = types.SimpleNamespace()
+    model, x, step = bench.make_pose_runner(args, dev, torch.float16, 0, 1, "resnet50", 256, 192, 4, force_gather=True)
+    for _ in range(6):
+        rows = step()
+    step.drain()
+    torch.cuda.synchronize()
+    want = model.forward_keypoint_rows(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(rows, want) and torch.isfinite(want).all()
+    fmodel, fx, fstep = bench.make_flow_runner(args, dev, torch.float16, 0, 1, "FlowNet2S", 2, "sampled", force_gather=True)
+    for _ in range(4):
+        flow = fstep()
+    fstep.drain()
+    torch.cuda.synchronize()
+    assert tuple(flow.shape) == (2, 2, 384, 512) and torch.isfinite(flow).all()
+
+
+@pytest.mark.parametrize("pair", [(64, 128), (8, 256)], ids=["b64_then_b128", "b8_then_b256"])
+def test_two_batch_sizes_of_one_model_get_their_own_conv_direct_streams(hip_lib, monkeypatch, pair):
+    """ft_conv_direct_fwd's kernel form follows the pixel count (K split 1 / 4, weight-stationary), every form orders the
+    weight stream differently and all have the same byte count: two plans of ONE model on either side of a form boundary
+    (tracking's pose_est_frames builds plans for buckets 8..256) must each run on a stream of their own layout
+    (ft_conv_direct_stream_id).  Checked against a model whose 1x1 convs stay on ft_conv2d_fwd, heuristic picks on both
+    sides (no benchmark: the direct form is the recorder's first choice wherever it exists)."""
+    from flowtrack.pytorch_amd import hip_ops
+    monkeypatch.setattr(hip_ops, "benchmark", False)
+    monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
+    monkeypatch.setattr(hip_ops, "_TILE_CACHE_LOADED", True)
+    m, _ = _model(50, torch.float16)
+    monkeypatch.setattr(hip_ops, "CONV_DIRECT", False)
+    ref, _ = _model(50, torch.float16)
+    seen_ids = {}
+    for B in pair:
+        x = synth.pose_crops(SEED + 40 + B, B).cuda()
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", True)
+        got = m(x).float().cpu()
+        names = [n for n, _ in m._last_plan.prog.calls]
+        assert "ft_conv_direct_fwd" in names, "the plan under test runs no ft_conv_direct_fwd launch at all"
+        for rec in m._last_plan.prog.conv_records:
+            if names[rec[1]] == "ft_conv_direct_fwd":
+                import ctypes
+                seen_ids.setdefault(rec[0], set()).add(int(hip_lib.ft_conv_direct_stream_id(ctypes.byref(rec[3]))))
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", False)
+        want = ref(x).float().cpu()
+        rng = (want.max() - want.min()).item()
+        err = (got - want).abs().max().item()
+        assert err <= 0.02 * rng, f"batch {B}: heat maps differ from the ft_conv2d_fwd path by {err:.3e} (range {rng:.2f})"
+    assert any(len(v) > 1 for v in seen_ids.values()), "no layer changed its stream layout between the two batch sizes: the pair does not test the key"
