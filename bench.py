@@ -285,6 +285,30 @@ def pose_parity(models_by_mode, x_cpu, seed, H, W, oracle_out=None):
     return out
 
 
+def clip_record(device, n_frames=300):
+    """BASELINE configs[4] on one GPU: the 300-frame 512x384 synthetic clip through tools/tracking/demo.run_clip with the real
+    nets (fp16, synthetic weights): flow of the 299 pairs + pose of the detector boxes (batched) + the sequential pass
+    (propagate, NMS, pose of the propagated boxes, id assignment).  One warm-up run builds every plan / graph, the second is
+    timed end to end on the host clock (the pass is host-paced)."""
+    from tools.tracking import demo
+    targs = types.SimpleNamespace(pose_backbone=50, pose_model="", flow_net="FlowNet2S", flow_model="", fp16=True)
+    pose, flow = demo.build_nets(targs, device)
+    frames, dets = demo.synthetic_clip(n_frames)
+    demo.run_clip(frames, dets, pose, flow, max_boxes="2x")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res, tm = demo.run_clip(frames, dets, pose, flow, max_boxes="2x")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "full FlowTrack pipeline frames/sec (detector boxes -> pose crops + FlowNet2S box propagation + id assignment)",
+            "frames": n_frames, "frame_hw": [int(frames.shape[1]), int(frames.shape[2])], "people": 5,
+            "frames_per_s": round(n_frames / dt, 1), "wall_s": round(dt, 4), "flow_s": round(tm["flow_s"], 4),
+            "pose_s": round(tm["pose_s"], 4), "pass_s": round(tm["track_s"], 4), "pass_frac": round(tm["track_s"] / dt, 3),
+            "boxes_per_frame_avg": round(sum(len(f["boxes"]) for f in res) / n_frames, 2),
+            "config": "BASELINE.json configs[4] on 1 GPU: ResNet-50 pose fp16 + FlowNet2S fp16, synthetic clip and weights, "
+                      "propagated boxes capped at 2x the detector boxes per frame (untrained pose net)"}
+
+
 def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B, force_gather=False):
     """(model, x, step): the pose hot path on a batch resident in HBM, arg-max inside the plan's graph.  N > 1: the
     [B,17,3] key-point rows of every rank are all-gathered (3.3 kB per rank) on a communication stream, one step behind
@@ -499,6 +523,8 @@ def main():
             # (3) parity of both modes on the benchmarked batch vs the CPU oracle (checker role only, outside timed regions)
             if world == 1:
                 out["parity"] = pose_parity({"fp16": model, "fp32": pmodel}, synth.pose_crops(100 + rank, 64, 256, 192), 1234, 256, 192)
+    if extras and world == 1 and rank == 0:
+        out["clip"] = clip_record(device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     parallel.barrier()

@@ -91,6 +91,130 @@ def pose_est(net, frame_dev: torch.Tensor, boxes: np.ndarray, inp_res=(256, 192)
     return np.concatenate((np.concatenate(out_c), np.concatenate(out_s)), axis=2).astype(np.float32)
 
 
+def heatmap_rows_to_image(rows: np.ndarray, centers: np.ndarray, scales: np.ndarray, hm_hw) -> np.ndarray:
+    """Key-point rows (x, y, score) in heat-map pixels -> image pixels: the inverse of the crop affine of
+    lib/pose/utils/transforms.py:173-184 (rot = 0) in closed form, for all boxes at once — t = [[a, 0, bx], [0, a, by]] with
+    a = h / scale, bx = -h * cx / scale + w / 2, by = -h * cy / scale + h / 2, so x_img = (x - w / 2) * scale / h + cx
+    (evaluation.transform_preds does the same through one 3x3 numpy inverse per box)."""
+    h, w = hm_hw
+    out = np.asarray(rows, dtype=np.float64).copy()
+    k = (np.asarray(scales, dtype=np.float64) / h)[:, None]
+    c = np.asarray(centers, dtype=np.float64)
+    out[..., 0] = (out[..., 0] - 0.5 * w) * k + c[:, 0:1]
+    out[..., 1] = (out[..., 1] - 0.5 * h) * k + c[:, 1:2]
+    return out.astype(np.float32)
+
+
+class PoseRunner:
+    """Pose of a few boxes of one frame with ONE device round trip, asynchronously (the sequential pass of the clip pipeline,
+    lib/tracking/net_utils.py:36-71 + tools/tracking/demo.py:35-42): box parameters go up through a pinned buffer, the crop
+    kernel writes straight into the pose plan's input (zero-copy), the plan's graph ends in the key-point rows launch
+    (arg-max + 0.25 px nudge on the device), the [bucket, K, 3] rows come back into a pinned buffer behind an event.
+    `submit` returns at once; `result` waits for the event — whatever the host does in between overlaps the GPU."""
+    BUCKETS = (4, 8, 16, 32, 64, 128, 256)
+
+    def __init__(self, net, inp_res=(256, 192), normalize=True):
+        self.net, self.inp_res = net, inp_res
+        self.dev = next(net.parameters()).device
+        require_gpu(self.dev)
+        self.lib = _lib.load()
+        net.keypoints_in_plan = True                      # rows with the adjust_coords nudge, inside the plan's graph
+        self.mean = self.inv_std = None
+        self.pre = 1.0
+        if normalize:
+            self.mean = torch.tensor(BGR_MEAN, dtype=torch.float32, device=self.dev)
+            self.inv_std = torch.tensor([1.0 / v for v in BGR_STD], dtype=torch.float32, device=self.dev)
+            self.pre = 1.0 / 255.0
+        self.slots = {}
+
+    def _slot(self, bucket: int):
+        sl = self.slots.get(bucket)
+        if sl is None:
+            sl = self.slots[bucket] = {
+                "params_host": torch.zeros((bucket, 3), dtype=torch.float32).pin_memory(),
+                "params_dev": torch.zeros((bucket, 3), dtype=torch.float32, device=self.dev),
+                "rows_host": torch.zeros((bucket, 17, 3), dtype=torch.float32).pin_memory(),
+                "event": torch.cuda.Event(),
+            }
+        return sl
+
+    def submit(self, frame_dev: torch.Tensor, boxes: np.ndarray):
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+        n = len(boxes)
+        if n == 0:
+            return None
+        if frame_dev.dtype != torch.uint8 or frame_dev.dim() != 3 or not frame_dev.is_contiguous():
+            raise ValueError("frame must be a contiguous uint8 [H,W,C] device tensor")
+        bucket = next((b for b in self.BUCKETS if b >= n), None)
+        if bucket is None:
+            raise ValueError(f"{n} boxes in one frame: more than the largest pose bucket ({self.BUCKETS[-1]})")
+        centers, scales = boxes_to_center_scale(boxes, self.inp_res)
+        sl = self._slot(bucket)
+        ph = sl["params_host"]
+        ph[:n, :2] = torch.from_numpy(centers.astype(np.float32))
+        ph[:n, 2] = torch.from_numpy(scales.astype(np.float32))
+        ph[n:] = ph[0]                                     # padding crops repeat box 0 (their rows are dropped)
+        sl["params_dev"].copy_(ph, non_blocking=True)
+        H, W, C = frame_dev.shape
+        x = self.net.static_input(bucket, self.inp_res[0], self.inp_res[1])
+        check(self.lib.ft_crop_affine_fwd(frame_dev.data_ptr(), H, W, C, sl["params_dev"].data_ptr(), bucket, self.inp_res[0],
+                                          self.inp_res[1], self.mean.data_ptr() if self.mean is not None else None,
+                                          self.inv_std.data_ptr() if self.inv_std is not None else None, self.pre, x.data_ptr(),
+                                          current_stream_handle(self.dev)), "ft_crop_affine_fwd")
+        rows = self.net.forward_keypoint_rows(x)
+        sl["rows_host"].copy_(rows, non_blocking=True)
+        sl["event"].record()
+        plan = self.net._last_plan
+        return (sl, n, centers, scales, (plan.heatmaps.shape[2], plan.heatmaps.shape[3]))
+
+    def submit_frames(self, frames_dev, boxes_list):
+        """The boxes of SEVERAL frames in one network call (phase 2 of the clip pipeline: ~5 detector boxes per frame would
+        otherwise pay one plan replay and one round trip per frame): one crop launch per frame, each writing its slice of the
+        plan's input.  result() returns the rows of all boxes in order."""
+        per = [np.asarray(b, dtype=np.float64).reshape(-1, 4) for b in boxes_list]
+        total = sum(len(b) for b in per)
+        if total == 0:
+            return None
+        bucket = next((b for b in self.BUCKETS if b >= total), None)
+        if bucket is None:
+            raise ValueError(f"{total} boxes in one call: more than the largest pose bucket ({self.BUCKETS[-1]})")
+        allb = np.concatenate(per)
+        centers, scales = boxes_to_center_scale(allb, self.inp_res)
+        sl = self._slot(bucket)
+        ph = sl["params_host"]
+        ph[:total, :2] = torch.from_numpy(centers.astype(np.float32))
+        ph[:total, 2] = torch.from_numpy(scales.astype(np.float32))
+        sl["params_dev"].copy_(ph, non_blocking=True)
+        x = self.net.static_input(bucket, self.inp_res[0], self.inp_res[1])
+        if bucket > total:
+            x[total:].zero_()
+        lo = 0
+        for frame, b in zip(frames_dev, per):
+            if len(b) == 0:
+                continue
+            H, W, C = frame.shape
+            check(self.lib.ft_crop_affine_fwd(frame.data_ptr(), H, W, C, sl["params_dev"][lo:].data_ptr(), len(b), self.inp_res[0],
+                                              self.inp_res[1], self.mean.data_ptr() if self.mean is not None else None,
+                                              self.inv_std.data_ptr() if self.inv_std is not None else None, self.pre,
+                                              x[lo:].data_ptr(), current_stream_handle(self.dev)), "ft_crop_affine_fwd")
+            lo += len(b)
+        rows = self.net.forward_keypoint_rows(x)
+        sl["rows_host"].copy_(rows, non_blocking=True)
+        sl["event"].record()
+        plan = self.net._last_plan
+        return (sl, total, centers, scales, (plan.heatmaps.shape[2], plan.heatmaps.shape[3]))
+
+    def result(self, handle) -> np.ndarray:
+        if handle is None:
+            return np.zeros((0, 17, 3), dtype=np.float32)
+        sl, n, centers, scales, hm_hw = handle
+        sl["event"].synchronize()
+        return heatmap_rows_to_image(sl["rows_host"][:n].numpy(), centers, scales, hm_hw)
+
+    def __call__(self, frame_dev: torch.Tensor, boxes: np.ndarray) -> np.ndarray:
+        return self.result(self.submit(frame_dev, boxes))
+
+
 def pose_est_frames(net, frames_dev, boxes_list, inp_res=(256, 192), normalize=True):
     """pose_est for the boxes of SEVERAL frames in one network call: crops of every frame (one ft_crop_affine_fwd launch
     per frame) are stacked into one batch, padded to the plan bucket, and leave through one final_preds.  Returns a list of

@@ -349,3 +349,23 @@ def test_program_choice_groups_bookkeeping(hip_lib, monkeypatch):
     assert sum(1 for c in prog.calls if c[0] == "__choice__") == 2
     prog.resolve_choices()
     assert [c[0] for c in prog.calls] == ["a", "fused", "z"]
+
+
+def test_flownet_demo_pads_by_edge_replication():
+    """tools/flownet/demo.py packs a pair with the tracking glue's helper (net_utils.pad_pairs_to_64): sizes that are not
+    multiples of 64 are filled by replicating the last row / column, never with zeros — the network's per-pair rgb_mean
+    (lib/flownet/model/models.py:255) of a padded 1080-row frame stays the frame's own."""
+    import numpy as np
+    from tools.flownet import demo
+    rng = np.random.default_rng(0)
+    im1 = rng.integers(60, 200, (70, 100, 3)).astype(np.uint8)
+    im2 = rng.integers(60, 200, (70, 100, 3)).astype(np.uint8)
+    ims = demo.pack_pair(im1, im2)
+    assert tuple(ims.shape) == (1, 3, 2, 128, 128) and ims.dtype == torch.float32
+    assert torch.equal(ims[0, :, 0, :70, :100], torch.from_numpy(im1.astype(np.float32)).permute(2, 0, 1))
+    assert torch.equal(ims[0, :, 1, :70, :100], torch.from_numpy(im2.astype(np.float32)).permute(2, 0, 1))
+    assert torch.equal(ims[0, :, :, 70:, :100], ims[0, :, :, 69:70, :100].expand(-1, -1, 58, -1))      # last row repeated
+    assert torch.equal(ims[0, :, :, :, 100:], ims[0, :, :, :, 99:100].expand(-1, -1, -1, 28))           # last column repeated
+    assert ims.min().item() >= 60.0, "zero padding leaked in"
+    same = demo.pack_pair(np.zeros((64, 128, 3), np.uint8), np.ones((64, 128, 3), np.uint8))
+    assert tuple(same.shape) == (1, 3, 2, 64, 128)

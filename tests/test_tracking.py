@@ -303,3 +303,58 @@ def test_flow_frames_are_edge_replicated_to_multiples_of_64():
     assert torch.equal(y[..., :70, 100:], x[..., :, 99:100].expand(-1, -1, -1, -1, 28))
     z = torch.zeros(1, 3, 2, 64, 128)
     assert pad_pairs_to_64(z) is z
+
+
+@pytest.mark.gpu
+def test_clip_300_frames_with_the_real_nets_is_deterministic_and_bounded(hip_lib):
+    """BASELINE configs[4] at size on one GPU: the 300-frame 512x384 synthetic clip through the REAL nets (ResNet-50 pose fp16,
+    FlowNet2S fp16, synthetic weights) — flow of the 299 pairs, pose of the detector boxes, the sequential pass with the
+    asynchronous per-frame pose runner (tools/tracking/demo.py:35-42, lib/tracking/net_utils.py:36-92).  Properties that hold
+    whatever the weights are: every output finite and inside the frame, the per-frame box count within the "2x" bound the
+    synthetic-weights demo opts into, ids unique per frame, and two runs identical in every box, key point and id."""
+    import types
+    from tools.tracking import demo
+    args = types.SimpleNamespace(pose_backbone=50, pose_model="", flow_net="FlowNet2S", flow_model="", fp16=True)
+    dev = torch.device("cuda", 0)
+    pose, flow = demo.build_nets(args, dev)
+    frames, dets = demo.synthetic_clip(300)
+    assert frames.shape == (300, 384, 512, 3)
+    runs = []
+    for _ in range(2):
+        out, tm = demo.run_clip(frames, dets, pose, flow, max_boxes="2x")
+        assert len(out) == 300 and set(tm) >= {"flow_s", "pose_s", "track_s"}
+        runs.append(out)
+    for f, d in zip(runs[0], dets):
+        assert 1 <= len(f["boxes"]) <= max(2 * len(d), 4)
+        assert np.isfinite(f["boxes"]).all() and np.isfinite(f["keypoints"]).all()
+        assert f["keypoints"].shape == (len(f["boxes"]), 17, 3) and len(f["ids"]) == len(f["boxes"])
+        assert len(set(f["ids"])) == len(f["ids"]), "an id assigned twice in one frame"
+        assert (f["boxes"][:, :2] >= -6).all() and (f["boxes"][:, 2] <= 511 + 6).all() and (f["boxes"][:, 3] <= 383 + 6).all()   # (detector jitter: +-3 px)
+    for a, b in zip(*runs):
+        assert np.array_equal(a["boxes"], b["boxes"]) and np.array_equal(a["keypoints"], b["keypoints"]) and list(a["ids"]) == list(b["ids"])
+
+
+@pytest.mark.gpu
+def test_pose_runner_matches_pose_est(hip_lib):
+    """The asynchronous runner (crop into the plan's input, key-point rows inside the graph, closed-form inverse affine) gives
+    what pose_est gives through final_preds (heat maps -> ft_heatmap_max_preds -> one 3x3 inverse per box), to 1e-3 px."""
+    from flowtrack.pytorch_amd.pose import models as pose_models
+    from flowtrack.pytorch_amd.tracking import PoseRunner, pose_est
+    dev = torch.device("cuda", 0)
+    net = pose_models.deconv("resnet50", num_classes=17, pretrained=False)
+    net.load_state_dict(synth.fill_pose_state_dict(net.state_dict(), 11))
+    net = net.to(dev).eval()
+    net.compute_dtype = torch.float16
+    frame = torch.from_numpy((synth.uniform01(5, "frame", (384, 512, 3)) * 255).astype(np.uint8)).to(dev)
+    boxes = np.array([[30, 40, 130, 300], [200, 10, 330, 380], [400, 100, 500, 250], [5, 5, 60, 90], [250, 200, 300, 260]], dtype=np.float64)
+    want = pose_est(net, frame, boxes, max_batch=8)
+    runner = PoseRunner(net)
+    got = runner(frame, boxes)
+    assert got.shape == want.shape == (5, 17, 3)
+    assert np.abs(got[..., :2] - want[..., :2]).max() <= 1e-3 and np.array_equal(got[..., 2], want[..., 2])
+    # three boxes run in the 4-crop plan (other tile picks than the 8-crop plan: compare with pose_est in that same bucket)
+    h1 = runner.submit(frame, boxes[:3])
+    got3, want3 = runner.result(h1), pose_est(net, frame, boxes[:3], max_batch=8)
+    assert np.abs(got3[..., :2] - want3[..., :2]).max() <= 1e-3 and np.array_equal(got3[..., 2], want3[..., 2])
+    both = runner.result(runner.submit_frames([frame, frame], [boxes[:2], boxes[2:]]))
+    assert np.array_equal(both, got)

@@ -5,7 +5,7 @@
 Builds `models.<model>(args, **model_kwargs)` through the same argument reflection (`--model_<kw>` flags),
 loads `checkpoint['state_dict']`, packs the pair as [1,3,2,H,W] RGB 0..255, runs the HIP forward and writes
 `<save>/output.flo` + `<save>/flow.png`.  Differences: images are read with PIL (scipy.misc.imread is gone);
-frames whose size is not a multiple of 64 are zero-padded bottom/right and the flow cropped back;
+frames whose size is not a multiple of 64 are edge-replicated bottom/right (pack_pair) and the flow cropped back;
 `--random_weights` allows a run without a checkpoint (the reference quits, demo.py:57-59);
 `--number_gpus > 1` is accepted but the single pair runs on one GPU (multi-GPU = one process per GPU, bench.py).
 """
@@ -46,15 +46,21 @@ def load_image(path):
     return np.asarray(Image.open(path).convert('RGB'))
 
 
+def pack_pair(im1, im2):
+    """im1, im2: HxWx3 RGB -> fp32 tensor [1,3,2,Hp,Wp], Hp / Wp the next multiples of 64, filled by REPLICATING the last row /
+    column — the one helper the tracking glue uses too (flowtrack.pytorch_amd.tracking.net_utils.pad_pairs_to_64): zero padding
+    would put a hard black edge into the frame and pull the network's own rgb_mean (lib/flownet/model/models.py:255) towards
+    black for 1080p-type inputs.  The reference's demo feeds frames as they are and only works for sizes the net divides."""
+    from flowtrack.pytorch_amd.tracking.net_utils import pad_pairs_to_64
+    pair = np.stack((np.asarray(im1, dtype=np.float32), np.asarray(im2, dtype=np.float32)))    # [2,H,W,3]
+    return pad_pairs_to_64(torch.from_numpy(pair).permute(3, 0, 1, 2).unsqueeze(0).contiguous())
+
+
 def run_pair(model, im1, im2):
     """im1, im2: HxWx3 uint8/float RGB -> flow HxWx2 fp32 (pixels)."""
     H, W = im1.shape[:2]
-    Hp, Wp = -(-H // 64) * 64, -(-W // 64) * 64
-    ims = np.zeros((1, 3, 2, Hp, Wp), dtype=np.float32)
-    ims[0, :, 0, :H, :W] = np.asarray(im1, dtype=np.float32).transpose(2, 0, 1)
-    ims[0, :, 1, :H, :W] = np.asarray(im2, dtype=np.float32).transpose(2, 0, 1)
     with torch.no_grad():
-        flow = model(torch.from_numpy(ims).cuda()).cpu()
+        flow = model(pack_pair(im1, im2).cuda()).cpu()
     return flow[0, :, :H, :W].numpy().transpose(1, 2, 0)
 
 

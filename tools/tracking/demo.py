@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 from flowtrack.pytorch_amd import parallel, synth                                  # noqa: E402
 from flowtrack.pytorch_amd.flownet import models as flow_models                     # noqa: E402
 from flowtrack.pytorch_amd.pose import models as pose_models                        # noqa: E402
-from flowtrack.pytorch_amd.tracking import FlowTracker, box_propagation, detect, flow_est, net_utils, pose_est, pose_est_frames  # noqa: E402
+from flowtrack.pytorch_amd.tracking import FlowTracker, PoseRunner, box_propagation, detect, flow_est, net_utils, pose_est, pose_est_frames  # noqa: E402
 
 
 def synthetic_clip(n_frames, H=384, W=512, n_people=5, seed=0):
@@ -94,7 +94,10 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
     flow, union with the detector boxes + box NMS (process_frame, tools/tracking/demo.py:35-42), pose of the propagated
     boxes that survive, flow-based greedy id assignment.
     dets[t]: [n,5] detector boxes; kp_det[t]: [n,17,3] their key points; flows: [T-1,2,H,W] (host array or anything
-    indexable by t giving a [2,H,W] numpy field); pose_boxes(t, boxes[m,4]) -> [m,17,3] for the propagated-only boxes.
+    indexable by t giving a [2,H,W] numpy field); pose_boxes: either a callable (t, boxes[m,4]) -> [m,17,3] for the
+    propagated-only boxes, or an object with submit(t, boxes) -> handle and result(handle) -> [m,17,3] (the GPU runner:
+    frame t's id assignment — host work that nothing downstream of the next propagation depends on — then runs while the GPU
+    computes frame t + 1's poses).
     Every NMS survivor is kept, as in the reference (process_frame keeps `dets[keep]`, demo.py:40-41).  `max_boxes` is an
     explicit opt-in bound on the work of a frame (highest scores kept): an int, or "2x" = twice the frame's detector boxes
     (every detection plus one propagated box each).  Nothing in the reference's union ages a propagated box that keeps
@@ -102,7 +105,11 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
     demo therefore passes "2x" (main(), --max_boxes), a trained model runs uncapped."""
     from flowtrack.pytorch_amd.tracking.flow_utils import nms
     tracker = FlowTracker()
+    is_async = hasattr(pose_boxes, "submit")
     out, prev_kp, prev_dets = [], None, None
+    deferred = None                                        # (frame index, kps, boxes, flow) whose ids are still to be assigned
+    def assign(item):
+        out[item[0]]["ids"] = tracker.update(item[1], item[2], item[3])
     for t in range(len(dets)):
         cur = np.asarray(dets[t], dtype=np.float32).reshape(-1, 5)
         n_det = len(cur)
@@ -120,11 +127,21 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
         kps = np.zeros((len(cur), 17, 3), dtype=np.float32)
         from_det = src < n_det
         kps[from_det] = np.asarray(kp_det[t])[src[from_det]]
+        handle = None
         if (~from_det).any():                                                            # propagated-only boxes
-            kps[~from_det] = pose_boxes(t, cur[~from_det, :4])
-        ids = tracker.update(kps, cur, flow)
-        out.append({"boxes": cur, "keypoints": kps, "ids": ids})
+            if is_async:
+                handle = pose_boxes.submit(t, cur[~from_det, :4])
+            else:
+                kps[~from_det] = pose_boxes(t, cur[~from_det, :4])
+        if deferred is not None:                           # the previous frame's ids: while the GPU works on this frame
+            assign(deferred)
+        if handle is not None:
+            kps[~from_det] = pose_boxes.result(handle)
+        out.append({"boxes": cur, "keypoints": kps, "ids": None})
+        deferred = (t, kps, cur, flow)
         prev_kp, prev_dets = kps, cur
+    if deferred is not None:
+        assign(deferred)
     return out
 
 
@@ -136,7 +153,10 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     T = len(frames)
     dev = torch.device(device) if device is not None else next(pose_net.parameters()).device
     batched_pose = pose_fn is None
-    if pose_fn is None:
+    # the HIP pose net: one device round trip per call, asynchronous (PoseRunner); any other module that maps crops to heat maps
+    # (the tests' stand-ins): the generic pose_est / pose_est_frames path
+    runner = PoseRunner(pose_net) if (batched_pose and hasattr(pose_net, "forward_keypoint_rows")) else None
+    if pose_fn is None and runner is None:
         pose_fn = lambda frame, boxes: pose_est(pose_net, frame, boxes, max_batch=8)     # noqa: E731
     if flow_fn is None:
         flow_fn = flow_net
@@ -167,7 +187,13 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     if batched_pose:       # the HIP networks: several frames' crops per network call
         for t0_ in range(lo, hi, pose_frames):
             ts = range(t0_, min(hi, t0_ + pose_frames))
-            for t, kp in zip(ts, pose_est_frames(pose_net, [fr[t] for t in ts], [dets[t][:, :4] for t in ts])):
+            if runner is None:
+                kps_ts = pose_est_frames(pose_net, [fr[t] for t in ts], [dets[t][:, :4] for t in ts])
+            else:
+                flat = runner.result(runner.submit_frames([fr[t] for t in ts], [dets[t][:, :4] for t in ts]))
+                cuts = np.cumsum([0] + [len(dets[t]) for t in ts])
+                kps_ts = [flat[cuts[i]:cuts[i + 1]] for i in range(len(ts))]
+            for t, kp in zip(ts, kps_ts):
                 kp_local[t - lo, :len(kp)] = torch.from_numpy(kp).to(dev)
     else:
         for t in range(lo, hi):
@@ -181,8 +207,14 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     # ---- phase 3: sequential tracking pass ----------------------------------------------------------------
     t0 = time.perf_counter()
     flows_np = flows_host.numpy()
-    out = tracking_pass(dets, [kp_all[t, :len(dets[t])] for t in range(T)], flows_np,
-                        lambda t, boxes: pose_fn(fr[t], boxes), thresh, max_boxes)
+    if runner is not None:
+        class _Frames:                                      # the runner, addressed by frame index
+            submit = staticmethod(lambda t, boxes: runner.submit(fr[t], boxes))
+            result = staticmethod(runner.result)
+        pose_boxes = _Frames
+    else:
+        pose_boxes = lambda t, boxes: pose_fn(fr[t], boxes)  # noqa: E731
+    out = tracking_pass(dets, [kp_all[t, :len(dets[t])] for t in range(T)], flows_np, pose_boxes, thresh, max_boxes)
     tm["track_s"] = time.perf_counter() - t0
     return out, tm
 
