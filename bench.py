@@ -285,6 +285,60 @@ def pose_parity(models_by_mode, x_cpu, seed, H, W, oracle_out=None):
     return out
 
 
+def exact_argmax_record(model16, model32, x16, x32, device, steps, world):
+    """north_star's "keypoint argmax bit-exact" for the FAST mode: DeconvResnet.forward_keypoint_rows_exact (fp16 pass, margin
+    screen on the device, fp32 re-run of the crops whose top-1 / top-2 margin is inside twice the fp16 error bound).  Timed with
+    the protocol of the headline on the benchmarked batch; arg-max identity against the fp32 parity mode (itself identical
+    to the CPU reference: `parity.fp32`, tests) on that batch and on 1024 further synthetic crops."""
+    import numpy as np
+    rerun = {"n": 0, "calls": 0}
+
+    def step():
+        _, n = model16.forward_keypoint_rows_exact(x16)
+        rerun["n"] += n
+        rerun["calls"] += 1
+    el, rep, tot = measure(step, steps, 3, device)
+    B = x16.shape[0]
+
+    def idx_of(rows):
+        r = rows.float().cpu().numpy()
+        return (np.floor(r[..., 1] + 0.5) * 4096 + np.floor(r[..., 0] + 0.5)).astype(np.int64)
+    import ctypes
+    from flowtrack.pytorch_amd import _lib
+    from flowtrack.pytorch_amd.hip_ops import check, current_stream_handle
+    same = total = flagged = 0
+    same_b = None
+    margins = []
+    mbuf = torch.empty(B, dtype=torch.float32, device=device)
+    for k in range(17):                                   # k = 0: the benchmarked batch, then 16 x 64 other crops
+        crops = synth.pose_crops(100, B, x16.shape[2], x16.shape[3]) if k == 0 else synth.pose_crops(5000 + k, B, x16.shape[2], x16.shape[3])
+        x16.copy_(crops)
+        x32.copy_(crops)
+        rows16, n = model16.forward_keypoint_rows_exact(x16)
+        rows32 = model32.forward_keypoint_rows(x32)
+        eq = idx_of(rows16) == idx_of(rows32)
+        if k == 0:
+            same_b = float(eq.mean())
+        else:
+            same += int(eq.sum()); total += eq.size; flagged += n
+            model16.forward_keypoint_rows(x16)             # the fp16 heat maps of these crops once more, for the margin statistics
+            hm = model16._last_plan.heatmaps
+            check(_lib.load().ft_heatmap_min_margin(hm.data_ptr(), B, hm.shape[1], hm.shape[2], hm.shape[3], mbuf.data_ptr(),
+                                                    current_stream_handle(device)), "ft_heatmap_min_margin")
+            margins.append(mbuf.cpu().numpy().copy())
+    x16.copy_(synth.pose_crops(100, B, x16.shape[2], x16.shape[3]))
+    x32.copy_(synth.pose_crops(100, B, x16.shape[2], x16.shape[3]))
+    return {"value": round(B * world * steps / el, 2), "unit": "crops/s", "steps": steps, "repeats": rep, "ms_per_step": round(1e3 * el / steps, 4),
+            "timed_region_s": round(tot, 4), "margin_threshold": model16.exact_argmax_margin,
+            "rerun_frac": round(rerun["n"] / max(rerun["calls"] * B, 1), 4),
+            "argmax_identical_frac": same_b, "argmax_identical_frac_1024_crops": round(same / max(total, 1), 6),
+            "rerun_frac_1024_crops": round(flagged / 1024.0, 4),
+            "crop_min_margin_quantiles_1024_crops": {q: float(np.quantile(np.concatenate(margins), float(q))) for q in ("0.1", "0.5", "0.9")},
+            "crops_below_margin_1024_crops": {str(t): round(float((np.concatenate(margins) < t).mean()), 4) for t in (1e-3, 2e-3, 4e-3, 8e-3)},
+            "note": "fp16 pass + device margin screen + fp32 re-run of the crops with a heat map whose top-1 / top-2 margin is below "
+                    "the threshold (2 x the fp16 max-abs bound); identity is against the fp32 parity mode of the same weights"}
+
+
 def clip_record(device, n_frames=300):
     """BASELINE configs[4] on one GPU: the 300-frame 512x384 synthetic clip through tools/tracking/demo.run_clip with the real
     nets (fp16, synthetic weights): flow of the 299 pairs + pose of the detector boxes (batched) + the sequential pass
@@ -523,6 +577,11 @@ def main():
             # (3) parity of both modes on the benchmarked batch vs the CPU oracle (checker role only, outside timed regions)
             if world == 1:
                 out["parity"] = pose_parity({"fp16": model, "fp32": pmodel}, synth.pose_crops(100 + rank, 64, 256, 192), 1234, 256, 192)
+        # (4) the fast mode with the parity mode's arg-max (every rank steps: the exact path holds no collective)
+        esteps = max(10, min(args.steps // 4, 200))
+        erec = exact_argmax_record(model, pmodel, x, px, device, esteps, world)
+        if rank == 0:
+            out["fp16_exact_argmax"] = erec
     if extras and world == 1 and rank == 0:
         out["clip"] = clip_record(device)
     if rank == 0:

@@ -185,6 +185,43 @@ __global__ __launch_bounds__(256) void heatmap_max_preds_kernel(const float* __r
   }
 }
 
+// ---- arg-max margin screen: per crop, the smallest (top-1 - top-2) over its K maps ------------------------------------
+// One workgroup per crop walks its K maps; a thread keeps the two largest values it has seen (at different pixels), waves
+// and workgroup merge pairs: best = max(b1, b2), second = max(min(b1, b2), s1, s2).  Equal maxima at two pixels -> margin 0.
+__global__ __launch_bounds__(256) void heatmap_min_margin_kernel(const float* __restrict__ hm, int K, int HW, float* __restrict__ out) {
+  const int n = blockIdx.x;
+  __shared__ float s_b[4], s_s[4];
+  float crop_min = INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const float* p = hm + ((size_t)n * K + k) * HW;
+    float b = -INFINITY, s2 = -INFINITY;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float v = p[i];
+      if (v > b) { s2 = b; b = v; } else if (v > s2) s2 = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(b, off), os = __shfl_xor(s2, off);
+      const float nb = fmaxf(b, ob);
+      s2 = fmaxf(fminf(b, ob), fmaxf(s2, os));
+      b = nb;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                  // (the previous map's s_b / s_s have been read)
+    if ((threadIdx.x & 63) == 0) { s_b[wave] = b; s_s[wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+        const float nb = fmaxf(b, s_b[w]);
+        s2 = fmaxf(fminf(b, s_b[w]), fmaxf(s2, s_s[w]));
+        b = nb;
+      }
+      crop_min = fminf(crop_min, b - s2);
+    }
+  }
+  if (threadIdx.x == 0) out[n] = crop_min;
+}
+
 // ---- FlowNet2* rgb mean: stage 1 partial sums, stage 2 finish -----------------------------------
 __global__ __launch_bounds__(256) void rgb_partial_sum_kernel(const float* __restrict__ x, size_t L,
                                                               float* __restrict__ partial) {
@@ -415,6 +452,13 @@ extern "C" int ft_heatmap_keypoint_rows(const float* heatmaps, int N, int K, int
   hipLaunchKernelGGL(heatmap_max_preds_kernel, dim3(N * K), dim3(256), 0, as_stream(stream), heatmaps, H, W,
                      adjust_coords, idx, rows + 2, rows, 3, 3);
   FT_LAUNCH_CHECK("heatmap_max_preds_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_heatmap_min_margin(const float* heatmaps, int N, int K, int H, int W, float* min_margin, ft_stream_t stream) {
+  if (!heatmaps || !min_margin || N <= 0 || K <= 0 || H <= 0 || W <= 0 || (long long)H * W < 2) return FT_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(heatmap_min_margin_kernel, dim3(N), dim3(256), 0, as_stream(stream), heatmaps, K, H * W, min_margin);
+  FT_LAUNCH_CHECK("heatmap_min_margin_kernel");
   return FT_OK;
 }
 

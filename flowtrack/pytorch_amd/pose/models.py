@@ -73,6 +73,11 @@ class DeconvResnet(HipModule):
     keypoints_in_plan = None
     #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
     fuse_heatmap: bool = os.environ.get("FT_FUSE_HEATMAP", "1") != "0"
+    #: forward_keypoint_rows_exact(): a crop is re-run in the fp32 parity arithmetic when the (top-1 - top-2) margin of any of
+    #: its fp16 heat maps is below this.  2 x the heat-map error bound of the fp16 mode guarantees the fp32 arg-max (an error
+    #: of at most E per element cannot reorder two values more than 2 E apart); default = 2 x 4e-3, the stated max-abs bound
+    #: at a heat-map range of ~5 (measured 3.2e-3 .. 3.8e-3)
+    exact_argmax_margin: float = 8e-3
 
     def __init__(self, layers: List[int], num_classes: int):
         super().__init__()
@@ -306,6 +311,57 @@ class DeconvResnet(HipModule):
         until the next call): the form `lib/tracking/net_utils.py` concatenates preds and maxvals into."""
         self.forward_keypoints(x)
         return self._last_plan.kp_rows
+
+
+    @torch.no_grad()
+    def forward_keypoint_rows_exact(self, x: torch.Tensor):
+        """Key-point rows [B,K,3] with the arg-max of the fp32 parity mode at (mostly) fp16 speed — north_star's "keypoint
+        argmax bit-exact vs CPU reference" for the fast mode (max_preds, lib/pose/utils/evaluation.py:11-20):
+          1. the fp16 plan (heat maps + rows, as forward_keypoint_rows);
+          2. ft_heatmap_min_margin: per crop the smallest top-1 / top-2 margin over its K maps;
+          3. crops whose margin is below `exact_argmax_margin` go through the fp32 plan (buckets of 8 .. B crops), their rows
+             replace the fp16 ones.
+        A crop that is not re-run has margins above twice the fp16 error bound, so its arg-max cannot differ from fp32's
+        (its score and the +-0.25 px nudge come from the fp16 map).  Returns (rows [B,K,3] on the device — a buffer of this
+        call, not the plan's —, number of crops re-run).  One device -> host read of B floats per call sits between 2 and 3."""
+        if self.keypoints_in_plan is None:
+            raise FlowtrackHipError("set model.keypoints_in_plan = True / False (adjust_coords) before forward_keypoint_rows_exact()")
+        want = self.compute_dtype
+        if want not in (None, torch.float16) and next(self.parameters()).dtype != torch.float16:
+            raise FlowtrackHipError("forward_keypoint_rows_exact() is the fp16 mode's exact-arg-max path: compute_dtype must be fp16")
+        import ctypes
+        from .. import _lib
+        from ..hip_ops import check, current_stream_handle
+        B = x.shape[0]
+        self.compute_dtype = torch.float16
+        try:
+            rows = self.forward_keypoint_rows(x).clone()
+            plan = self._last_plan
+            hm = plan.heatmaps
+            margin = torch.empty(B, dtype=torch.float32, device=x.device)
+            check(_lib.load().ft_heatmap_min_margin(hm.data_ptr(), B, hm.shape[1], hm.shape[2], hm.shape[3], margin.data_ptr(),
+                                                    current_stream_handle(x.device)), "ft_heatmap_min_margin")
+            todo = torch.nonzero(margin.cpu() < self.exact_argmax_margin).flatten()
+            n = int(todo.numel())
+            if n:
+                self.compute_dtype = torch.float32
+                todo_dev = todo.to(x.device)
+                lo = 0
+                while lo < n:
+                    m = min(n - lo, B)
+                    bucket = next(b for b in (8, 16, 32, 64, 128, 256, 1 << 30) if b >= m or b >= B)
+                    bucket = min(bucket, max(B, 8))
+                    xb = self.static_input(bucket, x.shape[2], x.shape[3])
+                    sel = todo_dev[lo:lo + min(m, bucket)]
+                    xb[:len(sel)].copy_(x.index_select(0, sel))
+                    if len(sel) < bucket:
+                        xb[len(sel):].zero_()
+                    r32 = self.forward_keypoint_rows(xb)
+                    rows.index_copy_(0, sel, r32[:len(sel)])
+                    lo += len(sel)
+        finally:
+            self.compute_dtype = want
+        return rows, n
 
 
 def deconv(backbone: str, num_classes: int, pretrained: bool) -> DeconvResnet:

@@ -299,6 +299,12 @@ int ft_heatmap_keypoint_rows(const float* heatmaps, int N, int K, int H, int W,
                              int adjust_coords, int32_t* idx, float* rows,
                              ft_stream_t stream);
 
+/* Arg-max margin screen of the fast (fp16) mode: min_margin[n] = min over the K maps of crop n of (largest - second largest
+ * value, at different pixels; 0 for a tie).  A crop whose min_margin exceeds twice the heat-map error bound of the fp16
+ * arithmetic has the same arg-max in every map as the fp32 parity mode (max_preds, evaluation.py:11-20); the others are the
+ * ones a caller re-runs in fp32 (DeconvResnet.forward_keypoint_rows_exact).  heatmaps NCHW fp32 [N,K,H,W], min_margin fp32 [N]. */
+int ft_heatmap_min_margin(const float* heatmaps, int N, int K, int H, int W, float* min_margin, ft_stream_t stream);
+
 /* ---- F1: FlowNet2* input normalisation ------------------------------------
  * rgb_mean over (pair,H,W) per (b,colour) then (x - mean) / rgb_max
  * (lib/flownet/model/models.py:255-257).  inputs: fp32 [B,3,2,H,W].

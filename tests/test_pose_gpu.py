@@ -309,3 +309,42 @@ def test_two_batch_sizes_of_one_model_get_their_own_conv_direct_streams(hip_lib,
         err = (got - want).abs().max().item()
         assert err <= 0.02 * rng, f"batch {B}: heat maps differ from the ft_conv2d_fwd path by {err:.3e} (range {rng:.2f})"
     assert any(len(v) > 1 for v in seen_ids.values()), "no layer changed its stream layout between the two batch sizes: the pair does not test the key"
+
+
+def test_min_margin_kernel_matches_topk(hip_lib):
+    """ft_heatmap_min_margin: per crop the smallest (largest - second largest) over its maps; ties -> 0."""
+    import ctypes
+    from flowtrack.pytorch_amd.hip_ops import current_stream_handle
+    hm = synth.normal(77, "margin.hm", (5, 17, 64, 48)).cuda().contiguous()
+    hm[1, 3, 10, 7] = hm[1, 3].max() + 0.25        # a clear winner ...
+    hm[2, 5, 0, 0] = hm[2, 5, 63, 47] = hm[2, 5].max() + 1.0     # ... and an exact tie in another crop
+    out = torch.empty(5, dtype=torch.float32, device="cuda")
+    assert hip_lib.ft_heatmap_min_margin(hm.data_ptr(), 5, 17, 64, 48, out.data_ptr(), current_stream_handle()) == 0
+    top2 = hm.flatten(2).topk(2, dim=2).values
+    want = (top2[..., 0] - top2[..., 1]).min(dim=1).values
+    assert torch.equal(out, want) and out[2].item() == 0.0
+
+
+def test_fp16_exact_argmax_mode_has_the_fp32_argmax(hip_lib):
+    """DeconvResnet.forward_keypoint_rows_exact: fp16 pass, margin screen, fp32 re-run of the screened crops — every key point's
+    arg-max pixel equals the fp32 parity mode's (which equals the CPU reference's: test_pose_fp32_matches_reference_golden) on
+    192 synthetic crops; some crops are re-run, far from all of them would be a useless screen, and crops that are not re-run
+    keep the fp16 rows."""
+    m16, _ = _model(50, torch.float16)
+    m32, _ = _model(50, torch.float32)
+    m16.keypoints_in_plan = m32.keypoints_in_plan = True
+    W = 48
+    idx = lambda rows: (torch.floor(rows[..., 1] + 0.5) * W + torch.floor(rows[..., 0] + 0.5)).long()
+    reran = flips16 = 0
+    for k in range(3):
+        x = synth.pose_crops(SEED + 60 + k, 64).cuda()
+        plain = m16.forward_keypoint_rows(x).clone()
+        rows, n = m16.forward_keypoint_rows_exact(x)
+        want = m32.forward_keypoint_rows(x).clone()
+        assert torch.equal(idx(rows), idx(want)), "exact mode: an arg-max differs from the fp32 parity mode"
+        flips16 += int((idx(plain) != idx(want)).sum())
+        reran += n
+        untouched = (rows == plain).flatten(1).all(dim=1)
+        assert int((~untouched).sum()) <= n
+    assert 0 < reran < 192, f"{reran} of 192 crops re-run"
+    print("fp16 arg-max flips without the screen:", flips16, "of", 192 * 17, "- crops re-run:", reran)
