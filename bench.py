@@ -70,21 +70,57 @@ def pmc_traffic(workload):
     return None
 
 
+def graph_step_ms(prog, reps=3, min_s=0.25):
+    """Average time of one replay of the plan's captured graph, hipEvents on the plan's stream around >= min_s of back-to-back
+    replays (median of `reps` such blocks)."""
+    import ctypes
+    from flowtrack.pytorch_amd._lib import check
+    lib, sh = prog.lib, prog.stream_handle
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib.ft_event_create(ctypes.byref(e0))); check(lib.ft_event_create(ctypes.byref(e1)))
+    prog.run(); prog.stream.synchronize()
+    n, out = 8, []
+    while True:                                           # size the block
+        check(lib.ft_event_record(e0, sh))
+        for _ in range(n):
+            prog.run()
+        check(lib.ft_event_record(e1, sh)); check(lib.ft_event_synchronize(e1))
+        ms = ctypes.c_float(); check(lib.ft_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        if ms.value >= 1e3 * min_s or n >= 1 << 16:
+            break
+        n *= 2
+    for _ in range(reps):
+        check(lib.ft_event_record(e0, sh))
+        for _ in range(n):
+            prog.run()
+        check(lib.ft_event_record(e1, sh)); check(lib.ft_event_synchronize(e1))
+        ms = ctypes.c_float(); check(lib.ft_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        out.append(ms.value / n)
+    lib.ft_event_destroy(e0); lib.ft_event_destroy(e1)
+    return sorted(out)[len(out) // 2]
+
+
 def conv_roofline(prog, dtype_name, iters=5):
-    """hipEvent timing of the plan's launches on its own stream.  `achieved` uses events at the boundaries of each run
-    of consecutive conv launches (kernels back to back as in the graph); the per-launch pass (an event after every
-    launch, ~1 us of overhead each) only feeds the --layers table and the cross-check field."""
+    """Live hipEvent timing of the plan's launches on its own stream.
+    `achieved` = conv FLOPs / conv kernel time AS THE STEP RUNS THEM: the replay time of the captured graph (>= 0.25 s of
+    back-to-back replays between two events) minus the few non-conv launches (pack, arg-max: timed eagerly at the boundaries
+    of their runs, a device-side spin ahead so no host latency is inside).  The inter-kernel gaps of the graph stay in the
+    conv time (conservative), and conv_ms_per_step <= the step time by construction.  The eager passes (an event at the
+    boundaries of each conv run / after every launch: a few us of gap per launch that the graph does not have) are kept as
+    cross-checks and feed the --layers table."""
     times = prog.time_calls(iters=iters)
     per_launch_conv_ms = sum(ms for name, ms in times if is_conv_call(name))
-    # the conv-run pass is the one `achieved` comes from: >= 50 passes (>= 0.25 s) right after a spin-up of the same plan,
-    # so it runs at the clocks of the timed region and conv_ms_per_step <= ms_per_step holds for every record of the line
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.3:
+    while time.perf_counter() - t0 < 0.3:               # spin-up: the passes below run at the clocks of the timed region
         for _ in range(5):
             prog.run()
         prog.stream.synchronize()
-    conv_ms, other_ms = prog.time_conv_runs(iters=max(iters, 50))
-    total_ms = conv_ms + other_ms
+    eager_conv_ms, other_ms = prog.time_conv_runs(iters=max(iters, 50))
+    if prog.graph_exec is not None:
+        step_ms = graph_step_ms(prog)
+        conv_ms = step_ms - other_ms
+    else:
+        step_ms, conv_ms = eager_conv_ms + other_ms, eager_conv_ms
     n_conv = sum(1 for name, _ in times if is_conv_call(name))
     flops = prog.flops
     achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -94,12 +130,12 @@ def conv_roofline(prog, dtype_name, iters=5):
         ms = times[call_idx][1]
         per_layer.append((label, fl, ms))
     return {
-        "bound": "mfma", "kernel": "every conv launch of the step (ft_conv2d_fwd / ft_conv_direct_fwd / ft_bottleneck_fwd / ft_bottleneck_stream_fwd): conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow) and few-output variants, conv_direct / conv3x3_direct (weights straight to registers), the fused bottleneck kernels (LDS-resident and streamed weights)", "achieved": round(achieved, 2), "peak": peak,
+        "bound": "mfma", "kernel": "every conv launch of the step (ft_conv2d_fwd / ft_conv_direct_fwd / ft_bottleneck_fwd / ft_bottleneck_stream_fwd): conv_igemm8_kernel (persistent 256x256 8-phase tile), conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow) and few-output variants, conv_direct / conv3x3_direct (weights straight to registers), the fused bottleneck kernels (LDS-resident and streamed weights)", "achieved": round(achieved, 2), "peak": peak,
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
         "launches_per_step": n_conv, "flop_per_launch_avg": flops / max(n_conv, 1),
         "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
-        "conv_ms_per_step": round(conv_ms, 4), "all_kernels_ms_per_step_eager_events": round(total_ms, 4),
-        "conv_ms_per_step_event_per_launch": round(per_launch_conv_ms, 4),
+        "conv_ms_per_step": round(conv_ms, 4), "graph_replay_ms_per_step": round(step_ms, 4), "other_kernels_ms_per_step": round(other_ms, 4),
+        "conv_ms_per_step_eager_run_events": round(eager_conv_ms, 4), "conv_ms_per_step_event_per_launch": round(per_launch_conv_ms, 4),
     }, per_layer
 
 
@@ -572,11 +608,29 @@ def main():
             if not args.no_roofline:
                 proof, _ = conv_roofline(pplan.prog, "fp32")
                 rec["roofline"] = {k: proof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
-                                                         "conv_ms_per_step")}
+                                                         "conv_ms_per_step", "graph_replay_ms_per_step")}
             out["fp32_parity_mode"] = rec
             # (3) parity of both modes on the benchmarked batch vs the CPU oracle (checker role only, outside timed regions)
             if world == 1:
                 out["parity"] = pose_parity({"fp16": model, "fp32": pmodel}, synth.pose_crops(100 + rank, 64, 256, 192), 1234, 256, 192)
+        # (3b) BASELINE configs[2]'s PER-GPU shape: ResNet-101, 16 x 384x288 crops per GPU (128 crops over 8 GPUs) — what each rank
+        # of the 8-GPU run executes; same protocol
+        csteps = max(10, min(args.steps // 2, 400))
+        cmodel, cx, cstep = make_pose_runner(args, device, torch.float16, rank, world, "resnet101", 384, 288, 16)
+        cel, crep, ctot = measure(cstep, csteps, 3, device)
+        if rank == 0:
+            cplan = next(iter(cmodel._plans.values()))
+            rec = {"metric": "pose crops/sec (ResNet-101 + 3-deconv head, 384x288)", "value": round(16 * world * csteps / cel, 2), "unit": "crops/s",
+                   "steps": csteps, "repeats": crep, "ms_per_step": round(1e3 * cel / csteps, 4), "timed_region_s": round(ctot, 4), "dtype": "fp16",
+                   "config": {"workload": "ResNet-101 pose head fp16, batch 16 x 384x288 synthetic crops per GPU (BASELINE.json configs[2]: "
+                                          "128 crops sharded over 8 GPUs = this per-GPU shape)", "per_gpu_batch": 16},
+                   "gflop_per_unit": round(cplan.prog.flops / 16 / 1e9, 3)}
+            if not args.no_roofline:
+                croof, _ = conv_roofline(cplan.prog, "fp16")
+                rec["roofline"] = {k: croof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
+                                                         "conv_ms_per_step", "graph_replay_ms_per_step")}
+            out["c3_per_gpu"] = rec
+        del cmodel, cx, cstep
         # (4) the fast mode with the parity mode's arg-max (every rank steps: the exact path holds no collective)
         esteps = max(10, min(args.steps // 4, 200))
         erec = exact_argmax_record(model, pmodel, x, px, device, esteps, world)
