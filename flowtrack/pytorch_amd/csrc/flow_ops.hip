@@ -692,6 +692,49 @@ __global__ __launch_bounds__(256) void resample2d_kernel(const float* __restrict
   }
 }
 
+// The same with the two x-neighbours of a row fetched as ONE 8-byte load: the kernel is bound by cache-line requests (every
+// lane gathers from its own line: 4 taps x C channels = 12 requests per pixel, 38 M per launch at BASELINE configs[3] shapes
+// = the measured 58 us at ~1 request per clock per CU), not by bytes and not by the per-thread dependency chain (four pixels
+// per thread with all 48 gathers independent measured 70 us).  xL and xR are adjacent except where the clamp folds them onto
+// one column, so a pair starting at column min(xL, W - 2) always holds both: 2 requests per row pair instead of 4.
+template <int C>
+__global__ __launch_bounds__(256) void resample2d_pair_kernel(const float* __restrict__ in1, const float* __restrict__ flow,
+                                                              float* __restrict__ out, int H, int W, size_t total) {
+  typedef float float2_t __attribute__((ext_vector_type(2), aligned(4)));
+  const size_t HW = (size_t)H * W;
+  for (size_t i = xcd_contiguous_block() * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    const float dx = flow[(b * 2 + 0) * HW + pix], dy = flow[(b * 2 + 1) * HW + pix];
+    const float xf = (float)x + dx, yf = (float)y + dy;
+    const float fx = floorf(xf), fy = floorf(yf);
+    const float alpha = xf - fx, beta = yf - fy;
+    const int xL = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    const int xR = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
+    const int yT = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    const int yB = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
+    const float w00 = (1.f - alpha) * (1.f - beta), w01 = alpha * (1.f - beta);
+    const float w10 = (1.f - alpha) * beta, w11 = alpha * beta;
+    const int xb = xL < W - 2 ? xL : W - 2;       // pair [xb, xb + 1] holds columns xL and xR
+    const bool l1 = xL != xb, r1 = xR != xb;
+    float2_t t[C], u[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* p = in1 + (b * C + c) * HW;
+      t[c] = *reinterpret_cast<const float2_t*>(p + (size_t)yT * W + xb);
+      u[c] = *reinterpret_cast<const float2_t*>(p + (size_t)yB * W + xb);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = w00 * (l1 ? t[c][1] : t[c][0]);
+      v += w01 * (r1 ? t[c][1] : t[c][0]);
+      v += w10 * (l1 ? u[c][1] : u[c][0]);
+      v += w11 * (r1 ? u[c][1] : u[c][0]);
+      out[(b * C + c) * HW + pix] = v;
+    }
+  }
+}
+
 // ---- ChannelNorm: sqrt(sum_c x^2) ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channelnorm_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
                                                           size_t HW, size_t total) {
@@ -988,6 +1031,18 @@ extern "C" int ft_resample2d_fwd(const float* in1, const float* flow, float* out
                                  ft_stream_t stream) {
   if (!in1 || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
   const size_t total = (size_t)B * H * W;
+  static const bool no_pair = getenv("FT_RESAMPLE_PAIR") && atoi(getenv("FT_RESAMPLE_PAIR")) == 0;   // dev A/B
+  if (!no_pair && W >= 2 && C >= 1 && C <= 4 && (long long)H * W < (1LL << 31)) {
+    const dim3 grid(grid_for(total));
+    switch (C) {
+      case 1: hipLaunchKernelGGL(resample2d_pair_kernel<1>, grid, dim3(256), 0, as_stream(stream), in1, flow, out, H, W, total); break;
+      case 2: hipLaunchKernelGGL(resample2d_pair_kernel<2>, grid, dim3(256), 0, as_stream(stream), in1, flow, out, H, W, total); break;
+      case 3: hipLaunchKernelGGL(resample2d_pair_kernel<3>, grid, dim3(256), 0, as_stream(stream), in1, flow, out, H, W, total); break;
+      default: hipLaunchKernelGGL(resample2d_pair_kernel<4>, grid, dim3(256), 0, as_stream(stream), in1, flow, out, H, W, total); break;
+    }
+    FT_LAUNCH_CHECK("resample2d_pair_kernel");
+    return FT_OK;
+  }
   hipLaunchKernelGGL(resample2d_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), in1, flow, out, C, H, W,
                      total);
   FT_LAUNCH_CHECK("resample2d_kernel");

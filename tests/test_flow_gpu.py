@@ -134,6 +134,17 @@ def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
     check(hip_lib.ft_channelnorm_fwd(gimg.data_ptr(), nrm.data_ptr(), B, C, H, W, _stream()))
     torch.cuda.synchronize()
     assert np.abs(nrm.cpu().numpy() - ops_ref.channelnorm_c(img)).max() <= 1e-6
+    # the other kernel forms: a width that is no multiple of 4 and more than 4 channels (one pixel per thread), 1 / 2 / 4
+    # channels (four pixels per thread); out-of-frame flows in every case
+    for (b2, c2, h2, w2) in ((1, 3, 10, 13), (1, 5, 8, 12), (2, 1, 9, 16), (1, 2, 7, 8), (1, 4, 6, 20)):
+        img2 = synth.normal(6, f"img{c2}{w2}", (b2, c2, h2, w2)).numpy()
+        flow2 = synth.flow_field(6, b2, h2, w2, magnitude=5.0).numpy()
+        flow2[0, :, h2 - 1, w2 - 1] = (300.0, -40.0)
+        out2 = torch.empty((b2, c2, h2, w2), dtype=torch.float32, device="cuda")
+        gi, gf = _cuda(img2), _cuda(flow2)
+        check(hip_lib.ft_resample2d_fwd(gi.data_ptr(), gf.data_ptr(), out2.data_ptr(), b2, c2, h2, w2, _stream()))
+        torch.cuda.synchronize()
+        assert np.abs(out2.cpu().numpy() - ops_ref.resample2d_c(img2, flow2)).max() <= 1e-5, (b2, c2, h2, w2)
 
 
 def test_upsample_and_normalise(hip_lib, oracle_lib):
