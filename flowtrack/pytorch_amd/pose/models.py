@@ -296,6 +296,16 @@ class DeconvResnet(HipModule):
         return plan.heatmaps.clone() if copy_output else plan.heatmaps
 
     @torch.no_grad()
+    def replay(self, plan: "_PosePlan") -> "_PosePlan":
+        """Run a plan whose static input the caller filled in place (plan_for(...).x_static): forward() without the second
+        plan look-up and the shape checks — the per-call host cost matters to the tracking pass, one small batch per frame."""
+        self._check_eval()
+        self._run_plan(plan.prog, first=plan.runs == 0)
+        plan.runs += 1
+        self._last_plan = plan
+        return plan
+
+    @torch.no_grad()
     def forward_keypoints(self, x: torch.Tensor):
         """forward() with max_preds inside the plan (set `keypoints_in_plan` first): returns the plan's static buffers
         (heatmaps [B,K,h,w], idx int32 [B,K], scores [B,K,1], coords [B,K,2] in heatmap pixels), valid until the next call."""

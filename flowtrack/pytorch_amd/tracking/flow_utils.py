@@ -40,18 +40,23 @@ def nms(dets: np.ndarray, thresh: float) -> np.ndarray:
     x1, y1, x2, y2, scores = dets.T
     areas = (x2 - x1 + 1) * (y2 - y1 + 1)
     order = np.argsort(-scores, kind="stable")
-    suppressed = np.zeros(dets.shape[0], dtype=bool)
+    # all pairwise overlaps at once, in score order (the same float32 operations nms.c:45-59 does pair by pair; a box that
+    # is already suppressed suppresses nothing because the greedy walk below skips its row), then the walk on plain lists:
+    # this function sits on the critical path of the clip's sequential pass, one call per frame on ~10 boxes
+    x1, y1, x2, y2, areas = x1[order], y1[order], x2[order], y2[order], areas[order]
+    w = np.maximum(0.0, np.minimum(x2[:, None], x2[None, :]) - np.maximum(x1[:, None], x1[None, :]) + 1)
+    h = np.maximum(0.0, np.minimum(y2[:, None], y2[None, :]) - np.maximum(y1[:, None], y1[None, :]) + 1)
+    inter = w * h
+    hit = (inter / (areas[:, None] + areas[None, :] - inter) >= thresh).tolist()
+    n = len(hit)
+    suppressed = [False] * n
     keep = []
-    for _i in range(order.size):
-        i = order[_i]
+    for i in range(n):
         if suppressed[i]:
             continue
         keep.append(i)
-        rest = order[_i + 1:]
-        rest = rest[~suppressed[rest]]
-        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
-        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
-        inter = w * h
-        ovr = inter / (areas[i] + areas[rest] - inter)
-        suppressed[rest[ovr >= thresh]] = True
-    return np.asarray(keep, dtype=np.int64)
+        row = hit[i]
+        for j in range(i + 1, n):
+            if row[j]:
+                suppressed[j] = True
+    return order[keep].astype(np.int64) if keep else np.zeros((0,), dtype=np.int64)

@@ -110,7 +110,11 @@ class PoseRunner:
     lib/tracking/net_utils.py:36-71 + tools/tracking/demo.py:35-42): box parameters go up through a pinned buffer, the crop
     kernel writes straight into the pose plan's input (zero-copy), the plan's graph ends in the key-point rows launch
     (arg-max + 0.25 px nudge on the device), the [bucket, K, 3] rows come back into a pinned buffer behind an event.
-    `submit` returns at once; `result` waits for the event — whatever the host does in between overlaps the GPU."""
+    `submit` returns at once; `result` waits for the event — whatever the host does in between overlaps the GPU.
+    One slot (parameter + row buffers) per bucket: call result() of a handle before the next submit of the same bucket size
+    (the tracking pass does: frame t + 1's boxes depend on frame t's rows).  The host side of a submit is on the critical
+    path of that pass (the GPU idles while boxes are prepared), hence the numpy views of the pinned buffers and the single
+    plan look-up per call (tools/dev/clip_profile.py: 0.21 -> ~0.1 ms per frame)."""
     BUCKETS = (4, 8, 16, 32, 64, 128, 256)
 
     def __init__(self, net, inp_res=(256, 192), normalize=True):
@@ -130,13 +134,26 @@ class PoseRunner:
     def _slot(self, bucket: int):
         sl = self.slots.get(bucket)
         if sl is None:
-            sl = self.slots[bucket] = {
-                "params_host": torch.zeros((bucket, 3), dtype=torch.float32).pin_memory(),
-                "params_dev": torch.zeros((bucket, 3), dtype=torch.float32, device=self.dev),
-                "rows_host": torch.zeros((bucket, 17, 3), dtype=torch.float32).pin_memory(),
-                "event": torch.cuda.Event(),
-            }
+            # box parameters live in pinned host memory the crop kernel reads directly (host allocations are mapped into the
+            # device's address space at the same address): no H2D copy op on the stream, no staging tensor
+            ph = torch.zeros((bucket, 3), dtype=torch.float32).pin_memory()
+            rh = torch.zeros((bucket, 17, 3), dtype=torch.float32).pin_memory()
+            sl = self.slots[bucket] = {"params_host": ph, "params_np": ph.numpy(), "rows_host": rh, "rows_np": rh.numpy(),
+                                       "event": torch.cuda.Event()}
         return sl
+
+    def _fill_params(self, sl, centers, scales, n, bucket):
+        pn = sl["params_np"]
+        pn[:n, :2] = centers
+        pn[:n, 2] = scales
+        if n < bucket:
+            pn[n:] = pn[0]                                 # padding crops repeat box 0 (their rows are dropped)
+
+    def _launch(self, sl, plan):
+        """Plan replay + rows back into the pinned buffer + event (one plan look-up per call: the caller resolved it)."""
+        self.net.replay(plan)
+        sl["rows_host"].copy_(plan.kp_rows, non_blocking=True)
+        sl["event"].record()
 
     def submit(self, frame_dev: torch.Tensor, boxes: np.ndarray):
         boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
@@ -150,21 +167,14 @@ class PoseRunner:
             raise ValueError(f"{n} boxes in one frame: more than the largest pose bucket ({self.BUCKETS[-1]})")
         centers, scales = boxes_to_center_scale(boxes, self.inp_res)
         sl = self._slot(bucket)
-        ph = sl["params_host"]
-        ph[:n, :2] = torch.from_numpy(centers.astype(np.float32))
-        ph[:n, 2] = torch.from_numpy(scales.astype(np.float32))
-        ph[n:] = ph[0]                                     # padding crops repeat box 0 (their rows are dropped)
-        sl["params_dev"].copy_(ph, non_blocking=True)
+        self._fill_params(sl, centers, scales, n, bucket)
         H, W, C = frame_dev.shape
-        x = self.net.static_input(bucket, self.inp_res[0], self.inp_res[1])
-        check(self.lib.ft_crop_affine_fwd(frame_dev.data_ptr(), H, W, C, sl["params_dev"].data_ptr(), bucket, self.inp_res[0],
+        plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1])
+        check(self.lib.ft_crop_affine_fwd(frame_dev.data_ptr(), H, W, C, sl["params_host"].data_ptr(), bucket, self.inp_res[0],
                                           self.inp_res[1], self.mean.data_ptr() if self.mean is not None else None,
-                                          self.inv_std.data_ptr() if self.inv_std is not None else None, self.pre, x.data_ptr(),
-                                          current_stream_handle(self.dev)), "ft_crop_affine_fwd")
-        rows = self.net.forward_keypoint_rows(x)
-        sl["rows_host"].copy_(rows, non_blocking=True)
-        sl["event"].record()
-        plan = self.net._last_plan
+                                          self.inv_std.data_ptr() if self.inv_std is not None else None, self.pre,
+                                          plan.x_static.data_ptr(), current_stream_handle(self.dev)), "ft_crop_affine_fwd")
+        self._launch(sl, plan)
         return (sl, n, centers, scales, (plan.heatmaps.shape[2], plan.heatmaps.shape[3]))
 
     def submit_frames(self, frames_dev, boxes_list):
@@ -181,11 +191,9 @@ class PoseRunner:
         allb = np.concatenate(per)
         centers, scales = boxes_to_center_scale(allb, self.inp_res)
         sl = self._slot(bucket)
-        ph = sl["params_host"]
-        ph[:total, :2] = torch.from_numpy(centers.astype(np.float32))
-        ph[:total, 2] = torch.from_numpy(scales.astype(np.float32))
-        sl["params_dev"].copy_(ph, non_blocking=True)
-        x = self.net.static_input(bucket, self.inp_res[0], self.inp_res[1])
+        self._fill_params(sl, centers, scales, total, total)
+        plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1])
+        x = plan.x_static
         if bucket > total:
             x[total:].zero_()
         lo = 0
@@ -193,15 +201,12 @@ class PoseRunner:
             if len(b) == 0:
                 continue
             H, W, C = frame.shape
-            check(self.lib.ft_crop_affine_fwd(frame.data_ptr(), H, W, C, sl["params_dev"][lo:].data_ptr(), len(b), self.inp_res[0],
+            check(self.lib.ft_crop_affine_fwd(frame.data_ptr(), H, W, C, sl["params_host"][lo:].data_ptr(), len(b), self.inp_res[0],
                                               self.inp_res[1], self.mean.data_ptr() if self.mean is not None else None,
                                               self.inv_std.data_ptr() if self.inv_std is not None else None, self.pre,
                                               x[lo:].data_ptr(), current_stream_handle(self.dev)), "ft_crop_affine_fwd")
             lo += len(b)
-        rows = self.net.forward_keypoint_rows(x)
-        sl["rows_host"].copy_(rows, non_blocking=True)
-        sl["event"].record()
-        plan = self.net._last_plan
+        self._launch(sl, plan)
         return (sl, total, centers, scales, (plan.heatmaps.shape[2], plan.heatmaps.shape[3]))
 
     def result(self, handle) -> np.ndarray:
@@ -209,7 +214,7 @@ class PoseRunner:
             return np.zeros((0, 17, 3), dtype=np.float32)
         sl, n, centers, scales, hm_hw = handle
         sl["event"].synchronize()
-        return heatmap_rows_to_image(sl["rows_host"][:n].numpy(), centers, scales, hm_hw)
+        return heatmap_rows_to_image(sl["rows_np"][:n], centers, scales, hm_hw)
 
     def __call__(self, frame_dev: torch.Tensor, boxes: np.ndarray) -> np.ndarray:
         return self.result(self.submit(frame_dev, boxes))
