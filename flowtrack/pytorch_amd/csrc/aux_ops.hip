@@ -232,9 +232,19 @@ __global__ __launch_bounds__(256) void rgb_partial_sum_kernel(const float* __res
   const float* p = x + (size_t)bc * L;
   float s = 0.f;
   if ((L & 3) == 0 && (per & 3) == 0) {      // 16-byte loads, four independent partial sums per lane
-    float4_t a = {0.f, 0.f, 0.f, 0.f};
+    // four loads in flight per lane (the one-load loop ran at 3.3 TB/s: latency-bound), combined in a fixed order
+    float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     const float4_t* p4 = reinterpret_cast<const float4_t*>(p);
-    for (size_t i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) a += p4[i];
+    const size_t e = hi / 4;
+    size_t i = lo / 4 + threadIdx.x;
+    for (; i + 768 < e; i += 1024) {
+      a0 += p4[i];
+      a1 += p4[i + 256];
+      a2 += p4[i + 512];
+      a3 += p4[i + 768];
+    }
+    for (; i < e; i += 256) a0 += p4[i];
+    const float4_t a = (a0 + a1) + (a2 + a3);
     s = (a[0] + a[1]) + (a[2] + a[3]);
   } else {
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
@@ -285,6 +295,61 @@ __global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __rest
       for (int f = 0; f < 2; ++f) {
         const float o[4] = {v[f][0], v[f][1], v[f][2], 0.f};
         store4c<T>(y + (((size_t)f * B + b) * H * wpitch + yy * wpitch + xp) * 4, o);
+      }
+    }
+  }
+}
+
+// fast path of the above (W % 4 == 0, 16-byte aligned planes): one thread = 4 consecutive pixels = six 16-byte planar reads
+// and 64 (mode 0) / 2 x 32 (mode 1) contiguous output bytes; the first / last thread of a row also zero the pad columns.
+// Same arithmetic per element as the scalar kernel ((x - mean) / rgb_max in fp32, then the cast).
+template <typename T>
+__global__ __launch_bounds__(256) void flow_pack_pair4_kernel(const float* __restrict__ in, const float* __restrict__ mean,
+                                                              float rgb_max, T* __restrict__ y, int B, int H, int W,
+                                                              int lpad, int wpitch, size_t total, int mode) {
+  const size_t HW = (size_t)H * W;
+  const int W4 = W >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % W4);
+    const size_t row = i / W4;              // b * H + yy
+    const size_t b = row / H, yy = row - b * H;
+    float4_t v[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float m = mean[b * 3 + c];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float4_t x4 = *reinterpret_cast<const float4_t*>(in + ((b * 3 + c) * 2 + f) * HW + yy * W + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[f][c][e] = (x4[e] - m) / rgb_max;
+      }
+    }
+    const size_t rowbase = row * wpitch;    // pixel index of the row's first (pad) column
+    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, z4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mode == 0) {
+      T* yr = y + rowbase * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float o[8] = {v[0][0][e], v[0][1][e], v[0][2][e], v[1][0][e], v[1][1][e], v[1][2][e], 0.f, 0.f};
+        store8<T>(yr + (size_t)(lpad + 4 * g + e) * 8, o);
+      }
+      if (g == 0)
+        for (int xp = 0; xp < lpad; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+      if (g == W4 - 1)
+        for (int xp = lpad + W; xp < wpitch; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        T* yr = y + (((size_t)f * B + b) * H * wpitch + yy * wpitch) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float o[4] = {v[f][0][e], v[f][1][e], v[f][2][e], 0.f};
+          store4c<T>(yr + (size_t)(lpad + 4 * g + e) * 4, o);
+        }
+        if (g == 0)
+          for (int xp = 0; xp < lpad; ++xp) store4c<T>(yr + (size_t)xp * 4, z4);
+        if (g == W4 - 1)
+          for (int xp = lpad + W; xp < wpitch; ++xp) store4c<T>(yr + (size_t)xp * 4, z4);
       }
     }
   }
@@ -481,6 +546,17 @@ extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float r
     return FT_ERR_INVALID_ARG;
   if (lpad < 0 || wpitch < lpad + W) return FT_ERR_INVALID_ARG;
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(inputs) & 15) == 0) {
+    const size_t groups = (size_t)B * H * (W / 4);
+    if (dtype == FT_F16)
+      hipLaunchKernelGGL(flow_pack_pair4_kernel<half_t>, dim3(grid_for(groups)), dim3(256), 0, as_stream(stream), inputs, mean,
+                         rgb_max, static_cast<half_t*>(y), B, H, W, lpad, wpitch, groups, mode);
+    else
+      hipLaunchKernelGGL(flow_pack_pair4_kernel<float>, dim3(grid_for(groups)), dim3(256), 0, as_stream(stream), inputs, mean,
+                         rgb_max, static_cast<float*>(y), B, H, W, lpad, wpitch, groups, mode);
+    FT_LAUNCH_CHECK("flow_pack_pair4_kernel");
+    return FT_OK;
+  }
   const size_t total = (size_t)B * H * wpitch;
   if (dtype == FT_F16)
     hipLaunchKernelGGL(flow_pack_pair_kernel<half_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,

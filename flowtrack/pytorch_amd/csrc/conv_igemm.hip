@@ -1784,6 +1784,164 @@ __global__ __launch_bounds__(256, 3) void conv_pflow_kernel(const ConvParams p) 
 #endif
 }
 
+// ---- predict_flow on the matrix pipe (fp16): the 3x3 conv to <= 2 channels as ONE 1x1 GEMM to 18 (tap, co) rows per INPUT
+// pixel + a 9-term shift-and-add.  conv_pflow_kernel above still reads every input fragment nine times from LDS and runs the
+// dot products on the vector ALU (45 us at 96x128x16 x 194 channels against an 11-us byte floor); here a workgroup takes the
+// 14 x 18 input patch of a 12 x 16 output tile (252 pixels = 8 MFMA pixel tiles, two per wave), streams it ONCE through a
+// 4-deep ring of 32-channel chunks (LDS-DMA, 64-byte pixel rows, chunk key (pixel / 4) & 3: conflict-free fragment reads),
+// multiplies each chunk by the [32 x 16] weight fragments (rows tap * 2 + co, 18 live; all chunks resident in LDS in fragment
+// order), parks the fp32 [pixel][18] partials in LDS and lets 192 threads add the nine neighbours of their output pixel.
+// MFMA work: 16 instructions per 32 channels per workgroup — the kernel is a stream over its input (1.31x with the halo).
+// fp32 summation order differs from the other two kernels (channels inside a tap first), well inside the fp16 tolerance.
+__global__ __launch_bounds__(256, 2) void conv_pflow_mfma_kernel(const ConvParams p, int nchunks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TW = 16, TH = 12, PW = TW + 2, NPIX = (TH + 2) * PW;   // 252
+  constexpr int NW = 4, RING = 4, CHB = 16384;                       // 256 pixel slots x 64 bytes per chunk
+  constexpr int SP = 20;                                             // floats per pixel of the partial tile (18 + pad: 16-byte rows)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  char* const ring = smem;
+  char* const wts = smem + RING * CHB;                               // nchunks x 2 slices x 1 KiB
+  float* const part = reinterpret_cast<float*>(smem);                // aliases the ring once the last chunk has been read
+
+  int ptile;
+  {
+    const int total = p.npt;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    ptile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tiles_per_img = p.h_ty * p.h_tx;
+  const int n = ptile / tiles_per_img;
+  const int trem = ptile - n * tiles_per_img;
+  const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+  const int qy0 = tyi * TH, qx0 = txi * TW;
+
+  // ---- weights: piece (slice s, k half, row co') = 8 consecutive channels of one (tap, co); ordinary loads, before any DMA --
+  {
+    const int cin8 = p.cin_groups * 8;
+    const int npieces = nchunks * 2 * 64;
+    for (int i = tid; i < npieces; i += 256) {
+      const int sl = i >> 6, l = i & 63, row = l & 31, cg = sl * 2 + (l >> 5);
+      const int tap = row >> 1, co = row & 1;
+      uint4_t v = {0u, 0u, 0u, 0u};
+      if (row < 18 && cg < p.cin_groups && co < p.Cout)
+        v = *reinterpret_cast<const uint4_t*>(p.w + ((size_t)co * p.Kpad + (size_t)tap * cin8 + cg * 8) * 2);
+      *reinterpret_cast<uint4_t*>(wts + i * 16) = v;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+  unsigned p_voff[4];            // 16 pixels per wave-load (4 lanes x 16 bytes each), 4 wave-loads per wave per chunk
+  {
+    const int ppl = lane >> 2, pos = lane & 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pp = (t * NW + wave) * 16 + ppl;
+      unsigned v = kOOB;
+      if (pp < NPIX) {
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
+        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+          v = (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff) * 2 + ((pos ^ ((pp >> 2) & 3)) << 4));
+      }
+      p_voff[t] = v;
+    }
+  }
+  auto load_chunk = [&](int c) {       // past the last chunk: out-of-range loads (zeros into a slot nobody reads) keep vmcnt uniform
+    const bool live = c < nchunks;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(ring + (c & (RING - 1)) * CHB + (t * NW + wave) * 1024), 16,
+                                               live ? p_voff[t] : kOOB, live ? c * 64 : 0, 0, 0);
+  };
+  load_chunk(0);
+  load_chunk(1);
+  load_chunk(2);
+
+  float16_t acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  int b_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int pp = (wave * 2 + t) * 32 + l31;
+    b_off[t] = pp * 64 + ((lhi ^ ((pp >> 2) & 3)) << 4);
+  }
+  const int a_off = lane * 16;
+
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk c has landed (this wave's pieces); chunks c+1, c+2 may fly
+    FT_LDS_BARRIER();                                       // ... everyone's pieces; and every read of chunk c-1 is done
+    load_chunk(c + 3);
+    const char* cb = ring + (c & (RING - 1)) * CHB;
+    const char* wb = wts + c * 2048 + a_off;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint4_t fa = *reinterpret_cast<const uint4_t*>(wb + k * 1024);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint4_t fb = *reinterpret_cast<const uint4_t*>(cb + (b_off[t] ^ (k << 5)));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa), __builtin_bit_cast(half8_t, fb), acc[t], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the dummy tail loads too: the ring becomes the partial tile
+  FT_LDS_BARRIER();
+  // ---- partials [pixel][18]: accumulator register r of lane (pixel, half) is row 8 * (r / 4) + 4 * half + r % 4 -------------
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int pp = (wave * 2 + t) * 32 + l31;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int row0 = g * 8 + lhi * 4;
+      if (row0 < 18)
+        *reinterpret_cast<float4_t*>(part + pp * SP + row0) = float4_t{acc[t][g * 4], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]};
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FT_LDS_BARRIER();
+  if (tid < TW * TH) {
+    const int oy_l = tid / TW, ox_l = tid - oy_l * TW;
+    const int oy = qy0 + oy_l, ox = qx0 + ox_l;
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float2 s2 = *reinterpret_cast<const float2*>(part + ((oy_l + tap / 3) * PW + ox_l + tap % 3) * SP + tap * 2);
+      v[0] += s2.x;
+      v[1] += s2.y;
+    }
+    if (oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+      for (int co = 0; co < 2; ++co) {
+        if (co < p.Cout) {
+          if (p.scale) v[co] *= p.scale[co];
+          if (p.shift) v[co] += p.shift[co];
+          v[co] = apply_act(v[co], p.act, p.slope);
+        }
+      }
+      if (p.out_layout == FT_LAYOUT_NHWC) {
+        half_t* yp = reinterpret_cast<half_t*>(p.y) + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.y_cstride + p.y_coff;
+        yp[0] = (half_t)v[0];
+        if (p.Cout > 1) yp[1] = (half_t)v[1];
+      } else {
+        float* yp = reinterpret_cast<float*>(p.y);
+        const size_t hw = (size_t)p.Ho * p.Wo, pix = (size_t)oy * p.Wo + ox;
+        yp[((size_t)n * p.Cout) * hw + pix] = v[0];
+        if (p.Cout > 1) yp[((size_t)n * p.Cout + 1) * hw + pix] = v[1];
+      }
+    }
+  }
+#endif
+}
+
 constexpr int kDmaBKB = FT_DMA_BKB;        // dma kernel: bytes of K per tile row per step (64 -> 32 fp16 / 16 fp32 channels)
 constexpr int kDmaStages = FT_DMA_STAGES;  // dma kernel: LDS ring depth
 
@@ -2547,6 +2705,24 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   if (!no_pflow && !d->transposed && d->Cout <= 2 && d->dtype == FT_F16 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
       d->pad == 1 && !d->has_residual && d->x_wpitch == 0 && d->x_cstride % 8 == 0 && d->x_coff % 8 == 0 && x_bytes < (1ull << 31)) {
     p.x_bytes = (unsigned)x_bytes;
+    {
+      // the matrix-pipe form (12 x 16 output tiles, input streamed once): FT_CONV_PFLOW_MFMA=0 keeps the dot-product kernel
+      static const bool no_mfma = getenv("FT_CONV_PFLOW_MFMA") && atoi(getenv("FT_CONV_PFLOW_MFMA")) == 0;
+      const int nchunks = ceil_div(g.cin_groups, 4);                 // 32-channel chunks
+      const int ty = ceil_div(d->Ho, 12), tx = ceil_div(d->Wo, 16);
+      const size_t lds = (size_t)4 * 16384 + (size_t)nchunks * 2048;
+      if (!no_mfma && (long long)d->N * ty * tx >= 256 && lds <= 160 * 1024 &&
+          (long long)ty * 12 * tx * 16 * 100 <= (long long)d->Ho * d->Wo * 125) {     // ragged edges waste < 25 % of the tiles
+        p.h_ty = ty;
+        p.h_tx = tx;
+        p.npt = d->N * ty * tx;
+        auto k = conv_pflow_mfma_kernel;
+        if (lds > 64 * 1024) FT_RAISE_LDS(k, 160 * 1024);
+        hipLaunchKernelGGL(k, dim3(p.npt), dim3(256), lds, s, p, nchunks);
+        FT_LAUNCH_CHECK("conv_pflow_mfma_kernel");
+        return FT_OK;
+      }
+    }
     const long long t16 = (long long)ceil_div(d->Ho, 8) * ceil_div(d->Wo, 16), t8 = (long long)ceil_div(d->Ho, 16) * ceil_div(d->Wo, 8);
     const int tw = t16 <= t8 ? 16 : 8, th = 128 / tw;
     p.h_ty = ceil_div(d->Ho, th);

@@ -41,6 +41,11 @@ CASES = [
     # >= 256 patches of 8x16: the LDS-patch predict_flow kernel (conv_pflow_kernel), 3.03 chunks of 64 channels / ragged, Cout 1
     ("predict_flow_patch_cin194", 4, 194, 64, 128, 2, 3, 1, 1, False, True, False, None, False),
     ("predict_flow_patch_ragged_cout1", 3, 40, 70, 150, 1, 3, 1, 1, False, True, False, "leaky", False),
+    # >= 256 tiles of 12x16: the matrix-pipe predict_flow kernel (conv_pflow_mfma_kernel): 7 chunks of 32 channels with a ragged
+    # last one, ragged image edges + Cout 1 + activation, and predict_flow3's 386 channels (13 chunks: ring wraps three times)
+    ("predict_flow_mfma_cin194", 6, 194, 64, 128, 2, 3, 1, 1, False, True, False, None, False),
+    ("predict_flow_mfma_ragged_cout1", 5, 40, 70, 150, 1, 3, 1, 1, False, True, False, "leaky", False),
+    ("predict_flow_mfma_cin386", 16, 386, 48, 64, 2, 3, 1, 1, False, True, False, None, False),
     ("fewout_cout3_5x5_s2", 1, 40, 11, 9, 3, 5, 2, 2, False, True, False, "leaky", False),
     ("fewout_cout4_1x1_res", 2, 64, 7, 5, 4, 1, 1, 0, False, False, True, "relu", True),
 ]

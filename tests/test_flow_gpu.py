@@ -156,33 +156,35 @@ def test_upsample_and_normalise(hip_lib, oracle_lib):
     want = torch.nn.functional.interpolate(torch.from_numpy(x) * 20.0, scale_factor=4, mode="bilinear", align_corners=False).numpy()
     assert np.abs(y.cpu().numpy() - want).max() <= 1e-5
     assert np.abs(y.cpu().numpy() - ops_ref.upsample4x_c(x, 20.0)).max() <= 1e-5
-    # rgb mean + (x - mean) / rgb_max, both packings
-    B, H, W = 2, 64, 64
-    pair = synth.frame_pairs(6, B, H, W)
-    gp = pair.cuda()
-    partial = torch.empty(B * 3 * _lib.FT_RGB_MEAN_SPLITS, device="cuda")
-    mean = torch.empty(B * 3, device="cuda")
-    check(hip_lib.ft_flow_rgb_mean(gp.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(), _stream()))
-    want_mean = pair.view(B, 3, -1).mean(-1)
-    torch.cuda.synchronize()
-    assert (mean.cpu().view(B, 3) - want_mean).abs().max() <= 1e-3
-    xn = flow_ref._normalise(pair, 255.0)
-    for mode in (0, 1):
-        for lpad, wpitch in ((0, W), (3, W + 6)):          # plain NHWC and the row-packed stem layout
-            n, cp = (B, 8) if mode == 0 else (2 * B, 4)
-            buf = torch.full((n, H, wpitch, cp), 3.0, device="cuda")
-            check(hip_lib.ft_flow_pack_pair(gp.data_ptr(), mean.data_ptr(), 255.0, buf.data_ptr(), B, H, W, mode, lpad, wpitch,
-                                            _lib.FT_F32, _stream()))
-            torch.cuda.synchronize()
-            got = buf.cpu()
-            live = got[:, :, lpad:lpad + W]
-            if mode == 0:
-                want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 1).permute(0, 2, 3, 1)
-                assert (live[..., :6] - want).abs().max() <= 1e-5 and torch.all(live[..., 6:] == 0)
-            else:
-                want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 0).permute(0, 2, 3, 1)
-                assert (live[..., :3] - want).abs().max() <= 1e-5 and torch.all(live[..., 3:] == 0)
-            assert torch.all(got[:, :, :lpad] == 0) and torch.all(got[:, :, lpad + W:] == 0)
+    # rgb mean + (x - mean) / rgb_max, both packings; W % 4 == 0 takes the 4-pixels-per-thread kernels, W = 62 the scalar ones
+    for W in (64, 62):
+        B, H = 2, 64
+        pair = synth.frame_pairs(6, B, H, W)
+        gp = pair.cuda()
+        partial = torch.empty(B * 3 * _lib.FT_RGB_MEAN_SPLITS, device="cuda")
+        mean = torch.empty(B * 3, device="cuda")
+        check(hip_lib.ft_flow_rgb_mean(gp.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(), _stream()))
+        want_mean = pair.view(B, 3, -1).mean(-1)
+        torch.cuda.synchronize()
+        assert (mean.cpu().view(B, 3) - want_mean).abs().max() <= 1e-3
+        xn = flow_ref._normalise(pair, 255.0)
+        for dtype, code, tol in ((torch.float32, _lib.FT_F32, 1e-5), (torch.float16, _lib.FT_F16, 1e-3)):
+            for mode in (0, 1):
+                for lpad, wpitch in ((0, W), (3, W + 6)):          # plain NHWC and the row-packed stem layout
+                    n, cp = (B, 8) if mode == 0 else (2 * B, 4)
+                    buf = torch.full((n, H, wpitch, cp), 3.0, device="cuda", dtype=dtype)
+                    check(hip_lib.ft_flow_pack_pair(gp.data_ptr(), mean.data_ptr(), 255.0, buf.data_ptr(), B, H, W, mode, lpad, wpitch,
+                                                    code, _stream()))
+                    torch.cuda.synchronize()
+                    got = buf.cpu().float()
+                    live = got[:, :, lpad:lpad + W]
+                    if mode == 0:
+                        want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 1).permute(0, 2, 3, 1)
+                        assert (live[..., :6] - want).abs().max() <= tol and torch.all(live[..., 6:] == 0)
+                    else:
+                        want = torch.cat((xn[:, :, 0], xn[:, :, 1]), 0).permute(0, 2, 3, 1)
+                        assert (live[..., :3] - want).abs().max() <= tol and torch.all(live[..., 3:] == 0)
+                    assert torch.all(got[:, :, :lpad] == 0) and torch.all(got[:, :, lpad + W:] == 0)
 
 
 # ---- networks -------------------------------------------------------------------------------------
