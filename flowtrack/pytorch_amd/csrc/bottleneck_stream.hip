@@ -40,7 +40,8 @@ struct BnsParams {
   const char* ws;    // packed weight stream (ft_bottleneck_stream_pack)
   const char* tab;   // float [6][2P]: {s1 b1} {s2 b2} {s3 b3 of quarter 0} .. {quarter 3}
   int H, W, TH;      // image size, output rows per strip
-  int ppi, total;    // strips per image, workgroups
+  int ppi, total;    // strips per image (x column parts), workgroups
+  int TWc, csplit;   // column-split form of the direct kernel: output columns per workgroup, parts per row of strips
   int x_cstride, x_coff, y_cstride, y_coff;
   unsigned x_bytes, y_bytes, ws_bytes;
   int dbg;
@@ -68,6 +69,9 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 #endif
 #ifndef FT_BNS_OVL
 #define FT_BNS_OVL 0    // dev A/B: phase 3 of the direct kernel hides a quarter's epilogue inside the next quarter's weight steps
+#endif
+#ifndef FT_BNS_L2_TOUCH
+#define FT_BNS_L2_TOUCH 1   // the direct kernel's first round of workgroups pulls the weight stream into its XCD's L2 (one touch per line)
 #endif
 #ifndef FT_BNS_PIN
 #define FT_BNS_PIN 3    // dev A/B: bit 0 = pinned issue order in phase 1 of the direct kernel, bit 1 = in its weight steps (dstep)
@@ -570,7 +574,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 // step on the 2 x 2 micro-tile at 256 workgroups (30 vs 20 B/clk/CU of weights beside the matrix pipe).
 // LDS: [0, 48 K) x-chunk buffers / [0, 60 K) T1 then T2, zero row at 60 K, all six folded-BN tables at 64 K (loaded
 // once), two output staging tiles from 80 K.
-template <int MT1, int MT2>
+// XH = column-split form for small batches (R101 384x288 at 16 crops per GPU gives 128 full-width strips for 256 CUs): a
+// workgroup takes TWc of the W columns of its rows and carries its own x-halo — the T1 patch is (TH + 2) x (TWc + 2) with
+// out-of-image columns zeroed like out-of-image rows, so every 3x3 tap is a plain shift inside the patch (no lane masks)
+// and twice as many, half as long workgroups fill the chip.  conv1 is recomputed on the halo columns as on the halo rows.
+// NS = weight-step register slots (prefetch distance NS - 1 steps of 8 KiB per wave): inside a network every block's 2.2 MB
+// of weights arrive cold (from the MALL, not the XCD's L2); the column-split form has the registers for a deeper ring.
+template <int MT1, int MT2, bool XH, int NS>
 __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const BnsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 256;
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   constexpr int NCT = G::NCT, NC1 = G::NC1, KC = G::KC, WSTEP = G::WSTEP, ROWB = G::ROWB;
   constexpr int XROWS = MT1 * 32, LX = MT1;                  // one pixel group: 4 wave columns
   constexpr int NOUT = MT2 * 32;
-  constexpr int ZROW = 61440, TABS = 65536, STG = 81920, STGB = NOUT * ROWB;
+  constexpr int ZROW = 61440, TABS = 65536, STG = 81920, STGB = NOUT * ROWB;   // [76 K, 77 K): scratch of the L2 touch loads
   constexpr int LDS_BYTES = STG + 2 * STGB;
   static_assert(XROWS * 128 <= G::XSTRIDE && NOUT * ROWB <= 61440 && LDS_BYTES <= 163840, "LDS map");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -597,11 +607,24 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int n = logical / p.ppi;
-  const int y0 = (logical - n * p.ppi) * p.TH;
   const int W = p.W;
+  const int TWc = XH ? p.TWc : W;             // output columns of this workgroup; output pixel m = r * TWc + c
+  const int PW = XH ? TWc + 2 : W;            // row pitch of the x-chunk / T1 patch
+  int y0, x0 = 0;
+  {
+    const int li = logical - n * p.ppi;
+    if constexpr (XH) {
+      const int st = li / p.csplit;
+      x0 = (li - st * p.csplit) * TWc;
+      y0 = st * p.TH;
+    } else {
+      y0 = li * p.TH;
+    }
+  }
   const int rows_out = p.H - y0 < p.TH ? p.H - y0 : p.TH;
-  const int npix_out = rows_out * W;
-  const int npix_halo = (p.TH + 2) * W;
+  const int cols_out = W - x0 < TWc ? W - x0 : TWc;
+  const int npix_out = rows_out * TWc;
+  const int npix_halo = (p.TH + 2) * PW;
 
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
@@ -613,11 +636,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
   for (int t = 0; t < LX; ++t) {
     const int hp = (t * 4 + wave) * 8 + (lane >> 3);
-    const int hr = hp / W, hc = hp - hr * W;
-    const int iy = y0 - 1 + hr;
+    const int hr = hp / PW, hc = hp - hr * PW;
+    const int iy = y0 - 1 + hr, ix = XH ? x0 - 1 + hc : hc;
     unsigned v = kOOB;
-    if (hp < npix_halo && (unsigned)iy < (unsigned)p.H)
-      v = (unsigned)((((n * p.H + iy) * W + hc) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ BNS_XKEY(hp)) << 4));
+    if (hp < npix_halo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
+      v = (unsigned)((((n * p.H + iy) * W + ix) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ BNS_XKEY(hp)) << 4));
     x_voff[t] = v;
   }
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -628,7 +651,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x_voff[t], c * 128, 0, 0);
   };
   // the weight fragments of step g for this wave: (kk, tile 2*wcol + i) at g * WSTEP + (kk * NCT + 2*wcol + i) KiB
-  uint4_t areg[3][4][2];
+  static_assert(NS >= 3 && 12 % NS == 0, "ring phase of the unrolled phase-2 body (12 steps per kernel row)");
+  constexpr int D = NS - 1;
+  uint4_t areg[NS][4][2];
   auto load_a = [&](auto slotc, int g) {        // past the end of the stream: out of range, zeros, never multiplied
     constexpr int SL = decltype(slotc)::value;
 #pragma unroll
@@ -649,6 +674,24 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BNSD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
   BNSD_TS(0);
+#if FT_BNS_L2_TOUCH
+  // Inside a network the block's weights are not in this XCD's L2 when the kernel starts, and every workgroup of the XCD
+  // asks for the same lines at the same moment: the stream then costs 17 us of a 46-us block (FT_BNS_DBG=64 in situ).  The
+  // first round of workgroups on an XCD therefore TOUCHES the whole stream once, each its own 1/n-th (one dword per
+  // 128-byte line, results discarded): the lines are on their way into the L2 before the lock-step demand loads reach them.
+  if (blockIdx.x < 256 && !(p.dbg & 512)) {
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int first = p.total < 256 ? p.total : 256;
+    const int nloc = (first - xcd + 7) >> 3;                       // workgroups of the first round on this XCD
+    const unsigned lines = (p.ws_bytes + 127u) >> 7;
+    const unsigned per = (lines + nloc - 1) / nloc;
+    const unsigned lo = loc * per, hi = lo + per < lines ? lo + per : lines;
+    // (as LDS-DMA into a scratch corner: no destination register whose reuse the compiler would have to guard; issued
+    // before the prologue's loads, so the hand-counted vmcnt waits below still see the order they assume)
+    for (unsigned l = lo + tid; l < hi; l += 256)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + 77824 + wave * 256), 4, l << 7, 0, 0, 0);
+  }
+#endif
   // prologue: all six tables (12 KiB, 3 x 256-byte pieces per wave ... 48 pieces), x chunks 0..2, weights of steps 0 and 1, zero row
 #pragma unroll
   for (int t = 0; t < 12; ++t)
@@ -656,14 +699,21 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   issue_x(0, 0);
   issue_x(1, 1);
   issue_x(2, 2);
-  load_a(c0{}, 0);
-  load_a(c1{}, 1);
+  bns_unroll<D>([&](auto sc) { load_a(sc, decltype(sc)::value); });
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
 
   uint4_t res[4][2][MT2][2];
-  int m_out[MT2];
+  int m_out[MT2], hp_out[MT2];          // output pixel of the lane in tile j, and its index in the halo patch
 #pragma unroll
-  for (int j = 0; j < MT2; ++j) m_out[j] = j * 32 + l31;
+  for (int j = 0; j < MT2; ++j) {
+    m_out[j] = j * 32 + l31;
+    if constexpr (XH) {
+      const int r = m_out[j] / TWc;
+      hp_out[j] = (r + 1) * PW + (m_out[j] - r * TWc) + 1;
+    } else {
+      hp_out[j] = m_out[j] + W;
+    }
+  }
 
   // ================= phase 1 ============================================================================================
   float16_t acc1[2][MT1];
@@ -697,17 +747,17 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
                                                               __builtin_bit_cast(half8_t, fx[S][j]), acc1[i][j], 0, 0, 0);
     };
     // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight steps (8 loads each) may fly
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 16) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 8 * D) : "memory");
     BNS_BARRIER();
     ldx(c0{}, 0, 0);
     bns_unroll<NC1>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       constexpr int buf = c % 3;
-      using slot = std::integral_constant<int, c % 3>;
+      using slot = std::integral_constant<int, c % NS>;
       // The wave-uniform branch below (residual pick-up) splits the chunk into two scheduling regions; each gets half of the
       // step's weight loads and a pinned issue order (see dstep): one vector-memory load and the LDS reads behind every two
       // MFMAs instead of hipcc's clusters of 6-8 loads with the matrix pipe drained behind them.
-      load_a_half(std::integral_constant<int, (c + 2) % 3>{}, c + 2, c0{});
+      load_a_half(std::integral_constant<int, (c + D) % NS>{}, c + D, c0{});
       ldx(c1{}, buf, 1);
       mma1(c0{}, slot{}, std::integral_constant<int, 0>{});
       ldx(c0{}, buf, 2);
@@ -732,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         const char* xb = smem + buf * G::XSTRIDE;
 #pragma unroll
         for (int j = 0; j < MT2; ++j) {
-          const int hp = m_out[j] + W;
+          const int hp = hp_out[j];
           const char* rowp = xb + hp * 128;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -742,7 +792,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         }
       }
       mma1(c1{}, slot{}, std::integral_constant<int, 1>{});
-      load_a_half(std::integral_constant<int, (c + 2) % 3>{}, c + 2, c1{});
+      load_a_half(std::integral_constant<int, (c + D) % NS>{}, c + D, c1{});
       ldx(c1{}, buf, 3);
       mma1(c0{}, slot{}, std::integral_constant<int, 2>{});
       if constexpr (FT_BNS_PIN & 1) {
@@ -758,8 +808,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       if constexpr (c + 1 < NC1) {
         // x chunk c+1 has landed and every read of chunk c's buffer is complete: refill it with chunk c+3.  Younger than x
         // chunk c+1 are the weights of step c+1 (needed next anyway), x chunk c+2 and the weights of step c+2.
-        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + 8) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8) : "memory");
+        // (with a prefetch distance of three or more steps the weights of step c+1 are OLDER than x chunk c+1: two weight
+        // steps may stay in flight)
+        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + (D == 2 ? 8 : 16)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D == 2 ? 8 : 16) : "memory");
         BNS_BARRIER();
         if constexpr (c + 3 < NC1) issue_x(c + 3, buf);
         ldx(c0{}, (c + 1) % 3, 0);
@@ -784,9 +836,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
       for (int j = 0; j < MT1; ++j) {
         const int hp = j * 32 + l31;
-        const int hr = hp / W;
-        const int iy = y0 - 1 + hr;
-        const bool inside = (unsigned)iy < (unsigned)p.H;
+        const int hr = hp / PW;
+        const int iy = y0 - 1 + hr, ix = XH ? x0 - 1 + (hp - hr * PW) : 0;
+        const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
         half8_t h8[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -822,16 +874,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
   for (int j = 0; j < MT2; ++j) {
     const int ox = m_out[j] % W;
-    edge[j] = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+    edge[j] = XH ? 0 : (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
   }
-  auto row_bases = [&](int off, int kc, int bad, int (&rb)[MT2]) {
+  // T1 / T2 row of the pixel operand: `off` relative to the lane's own row; full-width strips mask the two x-border taps
+  // (bad), the column-split form reads its zeroed halo columns instead
+  auto row_bases = [&](int off, int kc, int bad, int (&rb)[MT2], bool t1) {
 #pragma unroll
     for (int j = 0; j < MT2; ++j) {
-      const int row = m_out[j] + off;
+      const int row = ((XH && t1) ? hp_out[j] - PW - 1 : m_out[j]) + off;
       const int v = row * ROWB + (((row & 15) ^ lhi) << 4);
       rb[j] = ((edge[j] & bad) ? ZROW + (lhi << 4) : v) ^ (kc << 7);
     }
   };
+  auto tap_off = [&](int ky, int kx) { return XH ? ky * PW + kx : ky * W + kx - 1; };
   uint4_t fb[2][MT2];
   auto ldb = [&](auto setc, int kk, const int (&rb)[MT2]) {
     constexpr int S = decltype(setc)::value;
@@ -854,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
                    auto&& extra) {
     constexpr int SL = decltype(slotc)::value, NX = decltype(nxc)::value;
     using slot = std::integral_constant<int, SL>;
-    load_a(std::integral_constant<int, (SL + 2) % 3>{}, g + 2);
+    load_a(std::integral_constant<int, (SL + D) % NS>{}, g + D);
     ldb(c1{}, 1, rb);
     mma2(c0{}, slot{}, std::integral_constant<int, 0>{}, A);
     extra();
@@ -886,9 +941,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 
   // ---- phase 2: nine taps x KC chunks, three taps per loop trip (12 steps: a multiple of the register ring period) -------
   {
-    static_assert((3 * KC) % 3 == 0, "ring phase of the unrolled body");
+    static_assert((3 * KC) % NS == 0, "ring phase of the unrolled body");
     int rb[MT2], rbn[MT2];
-    row_bases(-1, 0, 1, rb);
+    row_bases(tap_off(0, 0), 0, 1, rb, true);
     ldb(c0{}, 0, rb);
     for (int ky = 0; ky < 3; ++ky) {
       bns_unroll<3 * KC>([&](auto sc) {
@@ -896,8 +951,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         constexpr int kx = s / KC, kc = s % KC;
         constexpr int nkc = (kc + 1) % KC, nkx = kc + 1 == KC ? (kx + 1) % 3 : kx;
         const int nky = (kc + 1 == KC && kx == 2) ? ky + 1 : ky;
-        row_bases(nky * W + nkx - 1, nkc, nkx == 0 ? 1 : (nkx == 2 ? 2 : 0), rbn);
-        dstep(std::integral_constant<int, (G::G2 + s) % 3>{}, G::G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn, acc, nx0{}, no_extra);
+        row_bases(tap_off(nky, nkx), nkc, nkx == 0 ? 1 : (nkx == 2 ? 2 : 0), rbn, true);
+        dstep(std::integral_constant<int, (G::G2 + s) % NS>{}, G::G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn, acc, nx0{}, no_extra);
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
@@ -944,11 +999,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
       const int idx = tid + 256 * k, m = idx / CPR, ch = idx % CPR;
-      s_voff[k] = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
+      const int r = m / TWc, c = m - r * TWc;
+      s_voff[k] = (m < npix_out && c < cols_out) ? (unsigned)((((n * p.H + y0 + r) * W + x0 + c) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
       s_off[k] = m * ROWB + ((ch ^ (m & 15)) << 4);
     }
     int rb[MT2], rbn[MT2];
-    row_bases(0, 0, 0, rb);
+    row_bases(0, 0, 0, rb, false);
     ldb(c0{}, 0, rb);
     // epilogue of quarter q, tile (i, j): folded BN + residual + ReLU -> fp16 -> staging tile q & 1
     auto epi_piece = [&](auto qc, int i, int j, float16_t (&A)[2][MT2]) {
@@ -976,7 +1032,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
 #else
         // straight from the accumulator layout: the lane's 16 consecutive channels = two adjacent 16-byte stores
-        const unsigned vo = m < npix_out ? (unsigned)((((n * p.H + y0) * W + m) * p.y_cstride + p.y_coff + ch + 8 * h) * 2) : kOOB;
+        const int orow = m / TWc, ocol = m - orow * TWc;
+        const unsigned vo = (m < npix_out && ocol < cols_out) ? (unsigned)((((n * p.H + y0 + orow) * W + x0 + ocol) * p.y_cstride + p.y_coff + ch + 8 * h) * 2) : kOOB;
         if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo + (unsigned)(q * P * 2), 0, FT_BNS_DIRECT_AUX);
 #endif
       }
@@ -1016,12 +1073,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       bns_unroll<KC>([&](auto kcc) {
         constexpr int kc = decltype(kcc)::value;
         constexpr int g = G::G3 + q * KC + kc;
-        row_bases(0, (kc + 1) % KC, 0, rbn);
+        row_bases(0, (kc + 1) % KC, 0, rbn, false);
         if constexpr (q > 0) {
-          dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn, A, std::integral_constant<int, 12>{},
+          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < G::GEND, rbn, A, std::integral_constant<int, 12>{},
                 [&] { epi_piece(std::integral_constant<int, q - 1>{}, kc / MT2, kc % MT2, Aprev); });
         } else {
-          dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn, A, nx0{}, no_extra);
+          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < G::GEND, rbn, A, nx0{}, no_extra);
         }
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
@@ -1047,8 +1104,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       bns_unroll<KC>([&](auto kcc) {
         constexpr int kc = decltype(kcc)::value;
         constexpr int g = G::G3 + q * KC + kc;
-        row_bases(0, (kc + 1) % KC, 0, rbn);
-        dstep(std::integral_constant<int, g % 3>{}, g, rb, g + 1 < G::GEND, rbn, acc, nx0{}, no_extra);
+        row_bases(0, (kc + 1) % KC, 0, rbn, false);
+        dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < G::GEND, rbn, acc, nx0{}, no_extra);
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
@@ -1109,8 +1166,9 @@ __global__ __launch_bounds__(256) void bns_pack_kernel(const half_t* __restrict_
 }
 
 struct BnsPlan {
-  int variant;   // 0: <128,4,3>  1: <256,4,3>  2: <256,3,2>
+  int variant;   // 0: <128,4,3>  1: <256,4,3>  2: <256,3,2>  3: <256,2,1> column-split (direct kernel only)
   int TH, ppi;
+  int TWc, csplit;
 };
 
 static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
@@ -1129,17 +1187,30 @@ static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
     th = th < d->H ? th : d->H;
     return ceil_div(d->H, ceil_div(d->H, th));     // same strip count, balanced rows
   };
-  static const int force = getenv("FT_BNS_VARIANT") ? atoi(getenv("FT_BNS_VARIANT")) : -1;
+  const int force = getenv("FT_BNS_VARIANT") ? atoi(getenv("FT_BNS_VARIANT")) : -1;   // dev / tests: 1, 2 or 3 (read per call)
   if (d->P == 128) {
     const int th = rows(192, 256);
     if (th < 1) return FT_ERR_UNSUPPORTED;
-    *out = BnsPlan{0, th, ceil_div(d->H, th)};
+    *out = BnsPlan{0, th, ceil_div(d->H, th), d->W, 1};
     return FT_OK;
   }
   const int th_big = rows(96, 120), th_small = rows(64, 96);
-  if (th_big < 1 && th_small < 1) return FT_ERR_UNSUPPORTED;
+  // column-split form: <= 32 output pixels on a <= 64-pixel patch with its own x-halo; the fewest parts that fit
+  int xs = 0, x_tw = 0, x_th = 0;
+  for (int cs = 2; cs <= 4 && !xs; ++cs) {
+    const int tw = ceil_div(d->W, cs);
+    int th = 32 / tw;
+    const int th2 = 64 / (tw + 2) - 2;
+    th = th < th2 ? th : th2;
+    if (th < 1 || tw * (cs - 1) >= d->W) continue;
+    th = th < d->H ? th : d->H;
+    xs = cs; x_tw = tw; x_th = ceil_div(d->H, ceil_div(d->H, th));
+  }
+  static const bool no_direct_k = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;
+  if (no_direct_k) xs = 0;
+  if (th_big < 1 && th_small < 1 && !xs) return FT_ERR_UNSUPPORTED;
   int pick;
-  if (force == 1 || force == 2) pick = force;
+  if (force == 1 || force == 2 || (force == 3 && xs)) pick = force;
   else {
     // Both variants run one workgroup per CU at the matrix pipe's pace (the FT_BNS_DBG=64/128 ablation: same phase times
     // with every load out of range), so the cost of a launch is rounds of 256 workgroups x MFMAs per workgroup:
@@ -1151,11 +1222,24 @@ static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
     if (th_big < 1) pick = 2;
     else if (th_small < 1) pick = 1;
     else pick = cost(th_big, 4, 3) <= cost(th_small, 3, 2) ? 1 : 2;
+    if (pick == 1 && th_big < 1) pick = 2;
+    if (pick == 2 && th_small < 1) pick = th_big >= 1 ? 1 : 3;
+    if (xs && pick != 3) {
+      // the column-split form only where it needs no more rounds of 256 workgroups than it saves in work per workgroup
+      const long long wgx = (long long)d->N * ceil_div(d->H, x_th) * xs;
+      const long long cx = ((wgx + 255) / 256) * (long long)(64 * 2 + 208 * 1);
+      const long long cf = pick == 1 ? cost(th_big, 4, 3) : cost(th_small, 3, 2);
+      if (cx < cf) pick = 3;
+    }
   }
   if (pick == 1 && th_big < 1) pick = 2;
-  if (pick == 2 && th_small < 1) pick = 1;
+  if (pick == 2 && th_small < 1) pick = th_big >= 1 ? 1 : 3;
+  if (pick == 3) {
+    *out = BnsPlan{3, x_th, ceil_div(d->H, x_th) * xs, x_tw, xs};
+    return FT_OK;
+  }
   const int th = pick == 1 ? th_big : th_small;
-  *out = BnsPlan{pick, th, ceil_div(d->H, th)};
+  *out = BnsPlan{pick, th, ceil_div(d->H, th), d->W, 1};
   return FT_OK;
 }
 
@@ -1174,9 +1258,12 @@ static int bns_launch(const BnsParams& p, hipStream_t s) {
   return FT_OK;
 }
 
-template <int MT1, int MT2>
+#ifndef FT_BNS_XH_SLOTS
+#define FT_BNS_XH_SLOTS 3
+#endif
+template <int MT1, int MT2, bool XH>
 static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
-  auto k = bottleneck_stream_direct_kernel<MT1, MT2>;
+  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : 3>;
   constexpr int lds = 81920 + 2 * MT2 * 32 * 512;
   static bool attr_done[64] = {};          // the LDS opt-in is per device
   int dev = 0;
@@ -1237,6 +1324,7 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   p.ws = static_cast<const char*>(wstream);
   p.tab = reinterpret_cast<const char*>(tables);
   p.H = d->H; p.W = d->W; p.TH = pl.TH; p.ppi = pl.ppi;
+  p.TWc = pl.TWc; p.csplit = pl.csplit;
   p.total = d->N * pl.ppi;
   p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
   p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->x_cstride * 2);
@@ -1250,10 +1338,11 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   switch (pl.variant) {
     case 0: return bns_launch<128, 4, 3>(p, s);
     case 1: return bns_launch<256, 4, 3>(p, s);
+    case 3: return bns_launch_direct<2, 1, true>(p, s);
     default: {
       // 64-pixel strips at 256 planes: weights straight to registers (FT_BNS_DIRECT=0: through the LDS ring, dev A/B)
       static const bool no_direct = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;
-      return no_direct ? bns_launch<256, 3, 2>(p, s) : bns_launch_direct<3, 2>(p, s);
+      return no_direct ? bns_launch<256, 3, 2>(p, s) : bns_launch_direct<3, 2, false>(p, s);
     }
   }
 }

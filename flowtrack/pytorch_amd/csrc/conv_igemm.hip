@@ -1180,8 +1180,11 @@ __global__ __launch_bounds__(256, (CCH == 32 ? 3 : 2)) void conv_halo_kernel(con
 // from it (the taps of one kernel row ARE contiguous in a row-packed row).  Only the weight rows stream (one K-step
 // per kernel row).  The layer becomes HBM-bound (read the frame once, write the 64-channel map once) instead of
 // re-reading each input row kh times through L2 -> LDS.
+#ifndef FT_STEM_WGS
+#define FT_STEM_WGS 2   // workgroups per CU the register budget is set for (dev A/B)
+#endif
 template <int KH, int STRIDE, int RUNB, int NT>
-__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, FT_STEM_WGS) void conv_stem_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = half_t;
   constexpr int BP = 128, BC = 64, TW = 16, TH = 8, NW = 4, WGP = 2, WGC = 2;

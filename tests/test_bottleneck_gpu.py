@@ -105,6 +105,62 @@ def test_fused_bottleneck_matches_oracle_and_the_three_launches(hip_lib, case):
     assert torch.equal(view_to_nchw(y_fused), got)
 
 
+S256 = [c for c in STREAM_CASES if c[6] == 256] + [
+    ("s256_r101_b16_24x18", 16, 24, 18, 1024, 0, 256),   # configs[2] per-GPU shape: 128 full-width strips -> 256 column halves
+    ("s256_odd_width_11x9", 3, 11, 9, 1024, 0, 256),     # 9 columns = 5 + 4: the second half is ragged in x
+    ("s256_wide_6x40", 2, 6, 40, 1024, 0, 256),          # 40 columns: four parts of 10
+]
+
+
+@pytest.mark.parametrize("variant", [2, 3], ids=["full_width_strips", "column_split"])
+@pytest.mark.parametrize("case", S256, ids=[c[0] for c in S256])
+def test_stream_256_variants_match_oracle_and_each_other(hip_lib, case, variant, monkeypatch):
+    """Both forms of the 256-plane fused kernel on every 256-plane shape, whatever the library's cost model would pick:
+    FT_BNS_VARIANT = 2 (full-width strips of <= 64 pixels) / 3 (column parts with their own x-halo, <= 32 pixels).  Same
+    weights, same fp16 roundings of t1 / t2: the two must agree with the oracle and, almost everywhere, with each other."""
+    name, N, H, W, xcs, xoff, P = case
+    if variant == 2 and (H * W > 64 and W > 32):
+        pytest.skip("full-width strips need a row of <= 32 pixels at 256 planes")
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 23
+    C = 4 * P
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+    t2 = F.relu(_bnf(F.conv2d(t1, w2, padding=1), bn2))
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + x)
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    c3 = FusedConv(w3, bn=bn3, label="conv3", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    outs = {}
+    for v in (variant, 5 - variant):
+        if v == 2 and (H * W > 64 and W > 32):
+            continue
+        monkeypatch.setenv("FT_BNS_VARIANT", str(v))
+        y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
+        prog = make_program()
+        record_bottleneck(prog, c1, c2, c3, xv, y, name)
+        assert prog.calls[0][0] == "ft_bottleneck_stream_fwd"
+        run_program(prog)
+        got = view_to_nchw(y)
+        y.t.fill_(5.0)
+        run_program(prog)
+        assert torch.equal(view_to_nchw(y), got), f"{name} variant {v}: two runs differ"
+        assert torch.all(y.t[..., :32] == 5.0), "channels outside the output slice were written"
+        outs[v] = got
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[variant] - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name} variant {variant}: vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    if len(outs) == 2:
+        diff = (outs[2] - outs[3]).abs()
+        assert diff.max().item() <= 1e-2 * scale
+        assert (diff > 0).float().mean().item() < 0.05, "the two forms should agree bit for bit almost everywhere"
+
+
 HEAD_CASES = [("r50_64x48", 2, 64, 48), ("r101_96x72", 1, 96, 72), ("ragged_13x20", 3, 13, 20), ("recycle", 24, 64, 48)]
 
 
