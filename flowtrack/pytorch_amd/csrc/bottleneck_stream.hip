@@ -149,6 +149,22 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 6 * G::TABB, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
+#if FT_BNS_L2_TOUCH
+  // the first round of workgroups on an XCD pulls the block's weight stream into that XCD's L2, each its own 1/n-th, one
+  // dword per 128-byte line (see the direct kernel); the scratch corner sits between the zero row and the weight ring
+  if (blockIdx.x < 256 && !(p.dbg & (512 | 1024))) {
+    constexpr int SCR = P == 256 ? 64000 : 102400;
+    static_assert(SCR >= G::ZROW + ROWB && SCR + 1024 <= G::WBASE, "scratch of the L2 touch loads");
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int first = p.total < 256 ? p.total : 256;
+    const int nloc = (first - xcd + 7) >> 3;
+    const unsigned lines = (p.ws_bytes + 127u) >> 7;
+    const unsigned per = (lines + nloc - 1) / nloc;
+    const unsigned lo = loc * per, hi = lo + per < lines ? lo + per : lines;
+    for (unsigned l = lo + tid; l < hi; l += 256)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + SCR + wave * 256), 4, l << 7, 0, 0, 0);
+  }
+#endif
   // ---- loaders -------------------------------------------------------------------------------------------------------
   // x chunk: row = halo pixel, 128 bytes (64 channels); a 1-KiB wave load covers 8 rows, lane -> (row = lane / 8,
   // 16-byte position lane % 8), the XOR swizzle (position ^= row & 7) is applied to the SOURCE position

@@ -20,6 +20,7 @@ for _ in range(3): m(x)
 torch.cuda.synchronize()
 plan = next(iter(m._plans.values()))
 times = plan.prog.time_calls(iters=5)
+hot = dict(enumerate(t for _, t in plan.prog.time_calls(iters=5, repeat_hot=True))) if os.environ.get("NB_HOT") else {}
 labels = {idx: lab for lab, idx, _, _ in plan.prog.conv_records}
 labels.update({r[1]: r[0] for r in plan.prog.fused_records})
 flops = {r[1]: r[2] for r in list(plan.prog.conv_records) + list(plan.prog.fused_records)}
@@ -27,7 +28,8 @@ tot = 0.0
 for i, (nm, ms) in enumerate(times):
     tot += ms
     if nm.startswith("__"): continue
-    print(f"{i:3d} {nm:28s} {labels.get(i, ''):28s} {ms*1e3:9.1f} us" + (f"  {flops[i] / ms * 1e-9:7.1f} TF/s" if i in flops else ""))
+    print(f"{i:3d} {nm:28s} {labels.get(i, ''):28s} {ms*1e3:9.1f} us" + (f"  {flops[i] / ms * 1e-9:7.1f} TF/s" if i in flops else "")
+          + (f"   hot {hot[i]*1e3:7.1f} us  (cold - hot {1e3 * (ms - hot[i]):+6.1f})" if hot else ""))
 print(f"sum of launches {tot:.3f} ms  -> {B/tot*1e3:.0f} units/s (eager, event-timed)")
 import time
 torch.cuda.synchronize(); t0 = time.perf_counter()
