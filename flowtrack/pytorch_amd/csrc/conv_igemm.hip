@@ -1342,6 +1342,204 @@ __global__ __launch_bounds__(256, FT_STEM_WGS) void conv_stem_kernel(const ConvP
 #endif
 }
 
+// ---- persistent, weight-stationary form of the stem (round 3) -------------------------------------------------------
+// conv_stem_kernel re-streams the layer's whole weight set (KH x 64 x RUNB bytes: 56 KiB for FlowNet's 7x7 on a frame pair)
+// for every 128-pixel tile and pays a full vector-memory wait + barrier per kernel row: 79-91 us on FlowNet2S's conv1 for
+// 150 MB of HBM traffic and 18 us of MFMA.  Here one workgroup per CU keeps ALL kernel rows' weights in LDS for its
+// lifetime and walks a contiguous range of 8 x 16 output tiles: the next tile's input patch is DMA'd into the other patch
+// buffer while the current one is multiplied (no wait, no barrier inside the 7-row K walk), the output tile leaves through
+// its own LDS transposition buffer with a FIXED number of buffer stores per lane (out-of-image pixels are out-of-range
+// stores), so the single counted wait per tile — `vmcnt(stores of the previous tile)` — is exact: vector-memory operations
+// complete in issue order on this counter.
+template <int KH, int STRIDE, int RUNB>
+__global__ __launch_bounds__(512, 1) void conv_stem_persist_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BP = 128, BC = 64, TW = 16, TH = 8, NW = 4, WGP = 2;
+  constexpr int WT_P = BP / WGP, MT_P = WT_P / 32;
+  constexpr int A_STAGE = BC * RUNB;
+  constexpr int CH = RUNB / 16, SWZ_DIV = 256 / RUNB >= 1 ? 256 / RUNB : 1, RPI = 64 / CH;
+  constexpr int NIA = BC / RPI / NW;          // weight wave-loads per wave per kernel row
+  constexpr int G = RUNB / 32;                // MFMA k-groups (16 halfs) per kernel row
+  constexpr int PH = (TH - 1) * STRIDE + KH;  // input rows of the patch
+  constexpr int NPLW_MAX = 12;
+  constexpr int WTS = KH * A_STAGE;           // [0, WTS): the weights; then two patch buffers of p.h_pb bytes; then the output tile
+  constexpr int NCHO = BC / 8, OROWB = BC * 2;
+  constexpr int NST = BP * NCHO / 256;        // 16-byte stores per lane per tile (4)
+  static_assert(RUNB == 64 || RUNB == 128 || RUNB == 256, "bytes of one packed kernel row");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // eight waves = two independent quartets (`sub`), each walking its own tiles with its own patch buffers and output tile and
+  // sharing the weights: two waves per SIMD hide each other's LDS latency (one quartet per CU ran at 4.2 us per tile)
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = wave8 >> 2, wave = wave8 & 3;
+  const int wp = wave % WGP, wc = wave / WGP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // contiguous tile range of this workgroup, XCD by XCD (neighbouring tiles share halo rows / columns in that XCD's L2)
+  int t_lo, t_hi;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int per = p.npt / nwg, rem = p.npt - per * nwg;
+    t_lo = logical * per + (logical < rem ? logical : rem);
+    t_hi = t_lo + per + (logical < rem ? 1 : 0);
+  }
+  const int tiles_per_img = p.h_ty * p.h_tx;
+  const int cpb = p.x_cstride * 2;                       // bytes per input pixel
+  const int CPR = p.h_pw;                                // 16-byte chunks per patch row
+  const int RBp = CPR * 16;
+  const int nchunks = PH * CPR;
+  // Stride 2 on 16-byte pixels: a fragment read takes every other chunk of a patch row, and the sixteen lanes one
+  // ds_read_b128 cycle serves ({0-3, 12-15, 20-27} ...) sit on two output rows = patch rows pr and pr + 2, both on the same
+  // chunk parity: 2-way conflicts on every pixel-operand read.  Chunk c of patch row pr therefore lives at c ^ ((pr >> 1) & 1)
+  // (applied on the SOURCE side of the DMA; the host keeps CPR even): the two rows of a cycle take opposite parities.  (The
+  // same swizzle changed nothing in conv_stem_kernel, which is not LDS-bound; this form is.)
+  const int swz = (STRIDE == 2 && cpb == 16) ? 1 : 0;
+  char* const patch0 = smem + WTS + sub * (2 * p.h_pb + BP * OROWB);
+  char* const otile = patch0 + 2 * p.h_pb;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, BC * p.Kpad * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- all kernel rows' weights, once: [ky][64 co][RUNB] tiles, XOR-swizzled on the source side as in conv_stem_kernel ----
+  if (sub == 0) {
+    const int lrow = lane / CH, pos = lane % CH;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t) {
+      const int r = (wave + NW * t) * RPI + lrow;
+      const int lc = pos ^ ((r / SWZ_DIV) % CH);
+      const unsigned voff = (unsigned)(r * p.Kpad * 2 + lc * 16);
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(smem + ky * A_STAGE + (wave + NW * t) * 1024), 16, voff, ky * RUNB, 0, 0);
+    }
+  }
+  // the input patch of tile t -> patch buffer `buf`: PH rows of CPR 16-byte chunks, lane-linear (always NPLW wave-loads).
+  // A lane's (row, chunk) inside the patch does not depend on the tile: the divisions are done once, here.
+  int p_row[NPLW_MAX], p_off[NPLW_MAX];
+#pragma unroll
+  for (int u = 0; u < NPLW_MAX; ++u) {
+    const int gci = (u * NW + wave) * 64 + lane;
+    const int row = gci / CPR, ch = (gci - row * CPR) ^ (swz & (row >> 1));
+    p_row[u] = (u < p.h_npww && gci < nchunks) ? row : 0x40000000;      // never inside the image
+    p_off[u] = row * p.Wi * cpb + ch * 16;
+  }
+  auto load_patch = [&](int t, int buf) {
+    const bool live = t < t_hi && !(p.dbg & 2);      // FT_CONV_DBG (dev ablation): 2 = no patch loads, 1 = no K walk, 4 = no stores
+    const int n = t / tiles_per_img, trem = t - n * tiles_per_img;
+    const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+    const int iy_org = tyi * TH * STRIDE - p.pad, col0 = txi * TW * STRIDE - p.pad_x;
+    const int base = ((n * p.Hi + iy_org) * p.Wi + col0) * cpb;
+    char* dst = patch0 + buf * p.h_pb;
+#pragma unroll
+    for (int u = 0; u < NPLW_MAX; ++u) {
+      if (u < p.h_npww) {
+        const unsigned v = (live && (unsigned)(iy_org + p_row[u]) < (unsigned)p.Hi) ? (unsigned)(base + p_off[u]) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(dst + (u * NW + wave) * 1024), 16, v, 0, 0, 0);
+      }
+    }
+  };
+  load_patch(t_lo + sub, 0);
+
+  // fragment offsets (tile-independent)
+  const int r_a = wc * 32 + l31;
+  const int a_off = r_a * RUNB + ((lhi ^ ((r_a / SWZ_DIV) % CH)) << 4);
+  int b_off[2][MT_P];           // [kpar]: kernel rows with (ky >> 1) & 1 == kpar
+#pragma unroll
+  for (int j = 0; j < MT_P; ++j) {
+    const int m = wp * WT_P + j * 32 + l31;
+    const int base = (m / TW) * STRIDE * RBp + (m % TW) * STRIDE * cpb;
+    const int key = swz & (m / TW);          // patch row = (m / TW) * 2 + ky: its chunk key is ((m / TW) + (ky >> 1)) & 1
+    b_off[0][j] = base + ((lhi ^ key) << 4);
+    b_off[1][j] = base + ((lhi ^ key ^ swz) << 4);
+  }
+  // folded BN / bias of this lane's channels: register r of lane (pixel, half) is channel 8 * (r / 4) + 4 * half + r % 4 of the wave's 32
+  float4_t sc[4], sh[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int co = wc * 32 + g4 * 8 + lhi * 4;
+    sc[g4] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + co) : float4_t{1.f, 1.f, 1.f, 1.f};
+    sh[g4] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + co) : float4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // weights + first patch (this wave's pieces), the table loads
+
+  const int nit = (t_hi - t_lo + 1) >> 1;     // both quartets run the same number of rounds (the last tile of an odd range is a dummy)
+  // (Running the quartets half a round apart — one multiplies while the other transposes and stores — was measured: 100 vs 73
+  // us.  In lock-step the two waves of a SIMD hide each other's LDS latency during the K walk; half a round apart each
+  // quartet is alone on the matrix pipe again.)
+  for (int it = 0; it < nit; ++it) {
+    const int t = t_lo + 2 * it + sub;
+    const int buf = it & 1;
+    // patch(t) was issued before the previous tile's NST stores: it has landed once at most NST operations are outstanding
+    if (it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    FT_LDS_BARRIER();            // everyone's pieces of patch(t); every read of the other patch buffer and of the output tile is done
+    load_patch(t + 2, buf ^ 1);
+
+    float16_t acc[MT_P];
+#pragma unroll
+    for (int j = 0; j < MT_P; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const char* pbase = patch0 + buf * p.h_pb;
+    if (!(p.dbg & 1)) static_for<KH>([&](auto ky_c) {
+      constexpr int ky = decltype(ky_c)::value;
+      const char* sa = smem + ky * A_STAGE;
+      const char* pb = pbase + ky * RBp;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint4_t fa = *reinterpret_cast<const uint4_t*>(sa + (a_off ^ (g << 5)));
+        uint4_t fb[MT_P];
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j) fb[j] = *reinterpret_cast<const uint4_t*>(pb + b_off[(ky >> 1) & 1][j] + g * 32);
+#pragma unroll
+        for (int j = 0; j < MT_P; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa), __builtin_bit_cast(half8_t, fb[j]), acc[j], 0, 0, 0);
+      }
+    });
+
+    // ---- bn / bias + activation -> fp16 output tile [128 px][64 co] (128-byte rows, 16-byte chunk ^= row & 7) ----------
+    {
+#pragma clang fp contract(off)   // scale, then shift, each rounded — as conv_epilogue does
+#pragma unroll
+      for (int j = 0; j < MT_P; ++j) {
+        const int pl = wp * WT_P + j * 32 + l31;
+        char* rowp = otile + pl * OROWB + lhi * 8;
+        const int msw = (pl & 7) << 4;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          half4_t hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (half_t)apply_act(acc[j][g4 * 4 + e] * sc[g4][e] + sh[g4][e], p.act, p.slope);
+          *reinterpret_cast<half4_t*>(rowp + (((wc * 4 + g4) << 4) ^ msw)) = hv;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    FT_LDS_BARRIER();
+    {
+      const int n = t / tiles_per_img, trem = t - n * tiles_per_img;
+      const int tyi = trem / p.h_tx, txi = trem - tyi * p.h_tx;
+      const int oy0 = tyi * TH, ox0 = txi * TW;
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const int idx = tid + k * 256, pl = idx / NCHO, ch = idx % NCHO;
+        const int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
+        const uint4_t v = *reinterpret_cast<const uint4_t*>(otile + pl * OROWB + ((ch ^ (pl & 7)) << 4));
+        const unsigned vo = (t < t_hi && oy < p.Ho && ox < p.Wo && !(p.dbg & 4)) ? (unsigned)((((n * p.Ho + oy) * p.Wo + ox) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, FT_YSTORE_BUF_AUX);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead patch loads must not outlive the workgroup's LDS
+#endif
+}
+
 // ---- stem + max-pool (fp16): 7x7/s2 row-packed stem conv + bn + relu with the 3x3/s2/p1 max-pool behind it -----
 // (resnet.py:19-23 = conv1 -> bn1 -> relu -> maxpool).  The workgroup owns an 8x8 patch of POOLED pixels: it computes the
 // 17x17 stem outputs those windows cover (1.13x recompute of a cheap layer) with the stem kernel's K-loop, parks them as
@@ -2139,6 +2337,36 @@ static int launch_stem(ConvParams p, const ft_conv_desc* d, const Geometry& g, h
   int nt = force_nt == 1 || force_nt == 2 ? force_nt : (runb >= 128 ? 2 : 1);
   if (nt == 2 && ((ceil_div(d->Wo, 32) * 32 - d->Wo) * 100 / d->Wo >= 10 || ph * round_up(31 * d->stride * cpb + runb, 16) > 56 * 1024))
     nt = 1;
+  {
+    // persistent weight-stationary form (one workgroup per CU walks many 8 x 16 tiles): FT_STEM_PERSIST=0 keeps the per-tile kernel
+    static const bool no_persist = getenv("FT_STEM_PERSIST") && atoi(getenv("FT_STEM_PERSIST")) == 0;
+    const int rb1 = 15 * d->stride * cpb + runb;
+    const int pw = (d->stride == 2 && cpb == 16) ? round_up(ceil_div(rb1, 16), 2) : ceil_div(rb1, 16);   // the kernel's parity swizzle pairs chunks
+    const int npww = ceil_div(ceil_div(ph * pw, 64), 4);
+    const size_t lds = (size_t)d->kh * 64 * runb + 2 * (2 * (size_t)npww * 4096 + 16384);   // weights + two quartets' patch pair and output tile
+    const long long ybytes = (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2;
+    const int ntiles = d->N * ceil_div(d->Ho, 8) * ceil_div(d->Wo, 16);
+    if (!no_persist && d->kh == 7 && npww <= 12 && lds <= 160 * 1024 && ybytes < (1LL << 31) && ntiles >= 512) {
+      p.h_pw = pw;
+      p.h_npww = npww;
+      p.h_pb = npww * 4 * 1024;
+      p.h_ty = ceil_div(d->Ho, 8);
+      p.h_tx = ceil_div(d->Wo, 16);
+      p.npt = ntiles;
+      p.nct = 1;
+      p.y_bytes = (unsigned)ybytes;
+      int dev = 0, ncu = 256;
+      FT_HIP_CHECK(hipGetDevice(&dev));
+      FT_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+      const int pairs = (ntiles + 1) / 2;
+      dim3 grid(ncu < pairs ? ncu : pairs);
+      if (runb == 64) { auto k = conv_stem_persist_kernel<7, 2, 64>; FT_RAISE_LDS(k, 160 * 1024); hipLaunchKernelGGL(k, grid, dim3(512), lds, s, p); }
+      else if (runb == 128) { auto k = conv_stem_persist_kernel<7, 2, 128>; FT_RAISE_LDS(k, 160 * 1024); hipLaunchKernelGGL(k, grid, dim3(512), lds, s, p); }
+      else { auto k = conv_stem_persist_kernel<7, 2, 256>; FT_RAISE_LDS(k, 160 * 1024); hipLaunchKernelGGL(k, grid, dim3(512), lds, s, p); }
+      FT_LAUNCH_CHECK("conv_stem_persist_kernel");
+      return FT_OK;
+    }
+  }
   const int tws = 16 * nt;
   const int rb = (tws - 1) * d->stride * cpb + runb;     // bytes of one patch row
   p.h_pw = ceil_div(rb, 16);

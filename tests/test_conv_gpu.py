@@ -128,6 +128,11 @@ ROWPACK = [
     ("pose_stem_3", 2, 3, 64, 48, 64, 7, 2, 3, False, True, "relu"),
     ("flow_conv1_6", 1, 6, 64, 64, 64, 7, 2, 3, True, False, "leaky"),
     ("flow_conv1_12", 1, 12, 32, 64, 64, 7, 2, 3, True, False, "leaky"),
+    # >= 512 tiles of 8 x 16: the persistent weight-stationary stem (conv_stem_persist_kernel), every row width (64 / 128 / 256
+    # bytes per kernel row), ragged right / bottom edges, 2-3 tiles per workgroup and a batch that wraps images inside a range
+    ("persist_pose_stem_3", 8, 3, 256, 192, 64, 7, 2, 3, False, True, "relu"),
+    ("persist_flow_conv1_6_ragged", 3, 6, 250, 500, 64, 7, 2, 3, True, False, "leaky"),
+    ("persist_flow_conv1_12_ragged", 4, 12, 250, 260, 64, 7, 2, 3, True, False, "leaky"),
     ("ragged_5x5_s1", 2, 3, 9, 11, 128, 5, 1, 2, True, False, None),
     ("stem_3x3_s2_cin4", 1, 4, 10, 14, 40, 3, 2, 1, False, True, "relu"),
 ]
