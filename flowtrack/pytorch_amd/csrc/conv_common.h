@@ -68,10 +68,12 @@ template <typename T> struct Elem;
 template <> struct Elem<half_t> { static constexpr int VEC = 8; };
 template <> struct Elem<float> { static constexpr int VEC = 4; };
 
+// act(v) = k * min(v, 0) + max(v, 0) with k = 0 (ReLU), slope (LeakyReLU) or 1 (none): the values of
+// `v > 0 ? v : v * k`, in three vector instructions.  The branchy form compiled to two scalar compare-and-branch pairs PER
+// ELEMENT inside the unrolled epilogues (64 s_cbranch per 128-pixel tile in the stem kernel): k is loop-invariant scalar work.
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  if (act == FT_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == FT_ACT_LEAKY) return v > 0.f ? v : v * slope;
-  return v;
+  const float k = act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f);
+  return __builtin_fmaf(k, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
 }
 
 template <int N, int I = 0, typename F>
@@ -200,38 +202,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, float16_t (&a
         }
         __syncthreads();
       }
-#pragma unroll
-      for (int j = 0; j < MT_P; ++j) {
-        const int pl = wp * WT_P + j * 32 + l31;
+      {
+        // channel groups outside, pixel tiles inside: the folded-BN vectors of a group are loaded (and the `scale` / `shift`
+        // pointers tested) once per group instead of once per (group, pixel tile); an absent scale / shift is 1 / 0.  Scale,
+        // then shift, each rounded (no contraction): the fused stem + pool kernel reproduces these bits.
+#pragma clang fp contract(off)
+        const float4_t one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MT_C; ++i) {
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int cl = wc * WT_C + i * 32 + 8 * rg + 4 * lhi;  // channel inside the tile
             const int cb = co0 + cl;
-            float v[4];
+            const float4_t sc = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + cb) : one4;
+            const float4_t sh = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + cb) : zero4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-            if (p.scale) {
-              const float4_t sc = *reinterpret_cast<const float4_t*>(p.scale + cb);
+            for (int j = 0; j < MT_P; ++j) {
+              const int pl = wp * WT_P + j * 32 + l31;
+              float v[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= sc[e];
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] * sc[e];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] + sh[e];
+              half_t* sp = reinterpret_cast<half_t*>(s_tile + pl * ROWB + (((cl >> 3) ^ (pl & (NCH - 1))) << 4) + lhi * 8);
+              if (p.res) {
+                float r4[4];
+                load4(sp, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+              store4(sp, v);
             }
-            if (p.shift) {
-              const float4_t sh = *reinterpret_cast<const float4_t*>(p.shift + cb);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += sh[e];
-            }
-            half_t* sp = reinterpret_cast<half_t*>(s_tile + pl * ROWB + (((cl >> 3) ^ (pl & (NCH - 1))) << 4) + lhi * 8);
-            if (p.res) {
-              float r4[4];
-              load4(sp, r4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += r4[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
-            store4(sp, v);
           }
         }
       }
