@@ -401,7 +401,8 @@ def test_patch_kernels_are_deterministic_when_workgroups_are_recycled(hip_lib, c
 
 
 # ---- ResNet stem with the max-pool fused (ft_conv_desc.pool): conv1 -> bn1 -> relu -> maxpool, resnet.py:19-23 ----------
-STEM_POOL_CASES = [("r50_crop", 2, 256, 192), ("small_ragged_x", 2, 64, 48), ("ragged_xy", 3, 40, 56), ("recycle", 40, 256, 192)]
+STEM_POOL_CASES = [("r50_crop", 2, 256, 192), ("small_ragged_x", 2, 64, 48), ("ragged_xy", 3, 40, 56), ("recycle", 40, 256, 192),
+                   ("ragged_big", 24, 200, 168)]      # 1008 tiles, ragged both ways
 
 
 @pytest.mark.parametrize("case", STEM_POOL_CASES, ids=[c[0] for c in STEM_POOL_CASES])
