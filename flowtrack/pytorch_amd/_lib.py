@@ -44,7 +44,8 @@ class BottleneckDesc(ctypes.Structure):
     """Mirror of `ft_bottleneck_desc`."""
 
     _fields_ = [("dtype", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("P", c_int),
-                ("x_cstride", c_int), ("x_coff", c_int), ("y_cstride", c_int), ("y_coff", c_int), ("head_only", c_int), ("projection", c_int)]
+                ("x_cstride", c_int), ("x_coff", c_int), ("y_cstride", c_int), ("y_coff", c_int), ("head_only", c_int), ("projection", c_int),
+                ("stride", c_int)]
 
 
 class ConvGeometry(ctypes.Structure):

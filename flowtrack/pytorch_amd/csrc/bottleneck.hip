@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 static int supported(const ft_bottleneck_desc* d) {
   if (!d) return FT_ERR_INVALID_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
-  if (d->dtype != FT_F16 || d->P != kP) return FT_ERR_UNSUPPORTED;
+  if (d->dtype != FT_F16 || d->P != kP || d->stride > 1) return FT_ERR_UNSUPPORTED;
   if (d->head_only && d->projection) return FT_ERR_INVALID_ARG;
   if (d->head_only || d->projection ? d->C != 64 : d->C != kC) return FT_ERR_UNSUPPORTED;   // (256-wide head-only: no caller, not instantiated)
   const int yc = d->head_only ? d->P : kC;
@@ -527,6 +527,8 @@ extern "C" int ft_bottleneck_supported(const ft_bottleneck_desc* d) { return ft:
 extern "C" double ft_bottleneck_flops(const ft_bottleneck_desc* d) {
   if (!d) return 0.0;
   const double cout = 4.0 * d->P;
+  if (d->head_only && d->stride == 2)     // conv1 on the input map, conv2 on the halved one
+    return 2.0 * d->N * ((double)d->H * d->W * d->C * d->P + (double)(d->H / 2) * (d->W / 2) * 9.0 * d->P * d->P);
   return 2.0 * d->N * d->H * d->W * ((double)d->C * d->P + 9.0 * d->P * d->P + (d->head_only ? 0.0 : (double)d->P * cout) +
                                      (d->projection ? (double)d->C * cout : 0.0));
 }

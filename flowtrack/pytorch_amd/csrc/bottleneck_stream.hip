@@ -42,6 +42,7 @@ struct BnsParams {
   int H, W, TH;      // image size, output rows per strip
   int ppi, total;    // strips per image (x column parts), workgroups
   int TWc, csplit;   // column-split form of the direct kernel: output columns per workgroup, parts per row of strips
+  int Ho, Wo;        // stride-2 head form (conv1 + conv2 of a stage's entry block): output map; H, W are the INPUT map
   int x_cstride, x_coff, y_cstride, y_coff;
   unsigned x_bytes, y_bytes, ws_bytes;
   int dbg;
@@ -596,12 +597,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 // and twice as many, half as long workgroups fill the chip.  conv1 is recomputed on the halo columns as on the halo rows.
 // NS = weight-step register slots (prefetch distance NS - 1 steps of 8 KiB per wave): inside a network every block's 2.2 MB
 // of weights arrive cold (from the MALL, not the XCD's L2); the column-split form has the registers for a deeper ring.
-template <int MT1, int MT2, bool XH, int NS>
+// HEADC > 0 = the stride-2 HEAD of a stage's entry block (conv1 1x1 + bn1 + relu -> conv2 3x3 / stride 2 + bn2 + relu,
+// blocks.py:105-112 with stride on conv2, resnet.py:44-49): x has 64 * HEADC channels, the strip's t1 is kept at full input
+// resolution (2 TH + 1 rows), the taps of output pixel (r, c) sit at T1 row (2r + ky) W + 2c - 1 + kx (only the left border
+// needs the zero row: W is even), and the kernel ends behind conv2: t2 [N, H/2, W/2, P] leaves through the T2 tile.
+template <int MT1, int MT2, bool XH, int NS, int HEADC = 0>
 __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const BnsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 256;
   using G = BnsGeom<P>;
-  constexpr int NCT = G::NCT, NC1 = G::NC1, KC = G::KC, WSTEP = G::WSTEP, ROWB = G::ROWB;
+  constexpr bool HEAD = HEADC > 0;
+  static_assert(!(HEAD && XH), "the head form uses full-width strips");
+  constexpr int NCT = G::NCT, NC1 = HEAD ? HEADC : G::NC1, KC = G::KC, WSTEP = G::WSTEP, ROWB = G::ROWB;
+  constexpr int G2 = NC1, G3 = G2 + 9 * KC, GEND = HEAD ? G3 : G3 + 4 * KC;
   constexpr int XROWS = MT1 * 32, LX = MT1;                  // one pixel group: 4 wave columns
   constexpr int NOUT = MT2 * 32;
   constexpr int ZROW = 61440, TABS = 65536, STG = 81920, STGB = NOUT * ROWB;   // [76 K, 77 K): scratch of the L2 touch loads
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   }
   const int n = logical / p.ppi;
   const int W = p.W;
-  const int TWc = XH ? p.TWc : W;             // output columns of this workgroup; output pixel m = r * TWc + c
+  const int TWc = XH ? p.TWc : (HEAD ? p.Wo : W);   // output columns of this workgroup; output pixel m = r * TWc + c
   const int PW = XH ? TWc + 2 : W;            // row pitch of the x-chunk / T1 patch
   int y0, x0 = 0;
   {
@@ -637,10 +645,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       y0 = li * p.TH;
     }
   }
-  const int rows_out = p.H - y0 < p.TH ? p.H - y0 : p.TH;
-  const int cols_out = W - x0 < TWc ? W - x0 : TWc;
+  const int Hout = HEAD ? p.Ho : p.H;
+  const int rows_out = Hout - y0 < p.TH ? Hout - y0 : p.TH;
+  const int cols_out = HEAD ? TWc : (W - x0 < TWc ? W - x0 : TWc);
   const int npix_out = rows_out * TWc;
-  const int npix_halo = (p.TH + 2) * PW;
+  const int npix_halo = (HEAD ? 2 * p.TH + 1 : p.TH + 2) * PW;
+  const int iy0 = HEAD ? 2 * y0 - 1 : y0 - 1;          // input row of the patch's first row
 
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   for (int t = 0; t < LX; ++t) {
     const int hp = (t * 4 + wave) * 8 + (lane >> 3);
     const int hr = hp / PW, hc = hp - hr * PW;
-    const int iy = y0 - 1 + hr, ix = XH ? x0 - 1 + hc : hc;
+    const int iy = iy0 + hr, ix = XH ? x0 - 1 + hc : hc;
     unsigned v = kOOB;
     if (hp < npix_halo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
       v = (unsigned)((((n * p.H + iy) * W + ix) * p.x_cstride + p.x_coff) * 2 + (((lane & 7) ^ BNS_XKEY(hp)) << 4));
@@ -726,6 +736,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     if constexpr (XH) {
       const int r = m_out[j] / TWc;
       hp_out[j] = (r + 1) * PW + (m_out[j] - r * TWc) + 1;
+    } else if constexpr (HEAD) {
+      const int r = m_out[j] / TWc;
+      hp_out[j] = (2 * r + 1) * W + 2 * (m_out[j] - r * TWc);      // the pixel's centre tap in the T1 patch
     } else {
       hp_out[j] = m_out[j] + W;
     }
@@ -793,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
           __builtin_amdgcn_sched_group_barrier(0x100, (MT1 + 2) / 3, 0);
         });
       }
-      if (c % 4 == wcol) {           // this chunk holds the channels of this wave column for quarter c / 4
+      if (!HEAD && c % 4 == wcol) {  // this chunk holds the channels of this wave column for quarter c / 4
         constexpr int q = c / 4;
         const char* xb = smem + buf * G::XSTRIDE;
 #pragma unroll
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       for (int j = 0; j < MT1; ++j) {
         const int hp = j * 32 + l31;
         const int hr = hp / PW;
-        const int iy = y0 - 1 + hr, ix = XH ? x0 - 1 + (hp - hr * PW) : 0;
+        const int iy = iy0 + hr, ix = XH ? x0 - 1 + (hp - hr * PW) : 0;
         const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
         half8_t h8[2];
 #pragma unroll
@@ -889,20 +902,20 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   int edge[MT2];
 #pragma unroll
   for (int j = 0; j < MT2; ++j) {
-    const int ox = m_out[j] % W;
-    edge[j] = XH ? 0 : (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+    const int ox = m_out[j] % TWc;
+    edge[j] = XH ? 0 : (HEAD ? (ox == 0 ? 1 : 0) : (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0));
   }
   // T1 / T2 row of the pixel operand: `off` relative to the lane's own row; full-width strips mask the two x-border taps
   // (bad), the column-split form reads its zeroed halo columns instead
   auto row_bases = [&](int off, int kc, int bad, int (&rb)[MT2], bool t1) {
 #pragma unroll
     for (int j = 0; j < MT2; ++j) {
-      const int row = ((XH && t1) ? hp_out[j] - PW - 1 : m_out[j]) + off;
+      const int row = ((XH && t1) ? hp_out[j] - PW - 1 : ((HEAD && t1) ? hp_out[j] - W - 1 : m_out[j])) + off;
       const int v = row * ROWB + (((row & 15) ^ lhi) << 4);
       rb[j] = ((edge[j] & bad) ? ZROW + (lhi << 4) : v) ^ (kc << 7);
     }
   };
-  auto tap_off = [&](int ky, int kx) { return XH ? ky * PW + kx : ky * W + kx - 1; };
+  auto tap_off = [&](int ky, int kx) { return (XH || HEAD) ? ky * PW + kx : ky * W + kx - 1; };
   uint4_t fb[2][MT2];
   auto ldb = [&](auto setc, int kk, const int (&rb)[MT2]) {
     constexpr int S = decltype(setc)::value;
@@ -968,7 +981,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         constexpr int nkc = (kc + 1) % KC, nkx = kc + 1 == KC ? (kx + 1) % 3 : kx;
         const int nky = (kc + 1 == KC && kx == 2) ? ky + 1 : ky;
         row_bases(tap_off(nky, nkx), nkc, nkx == 0 ? 1 : (nkx == 2 ? 2 : 0), rbn, true);
-        dstep(std::integral_constant<int, (G::G2 + s) % NS>{}, G::G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn, acc, nx0{}, no_extra);
+        dstep(std::integral_constant<int, (G2 + s) % NS>{}, G2 + 3 * KC * ky + s, rb, !(ky == 2 && s == 3 * KC - 1), rbn, acc, nx0{}, no_extra);
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
@@ -1006,6 +1019,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNS_BARRIER();          // T2 complete
   BNSD_TS(4);
+  if constexpr (HEAD) {
+    // the head form ends here: the T2 tile (rows = output pixels, 16-byte chunk ^= row & 15) leaves as whole lines
+    constexpr int CPRH = ROWB / 16, NSTH = NOUT * CPRH / 256;
+#pragma unroll
+    for (int k = 0; k < NSTH; ++k) {
+      const int idx = tid + 256 * k, m = idx / CPRH, ch = idx % CPRH;
+      const int r = m / TWc, c = m - r * TWc;
+      const unsigned vo = m < npix_out ? (unsigned)((((n * p.Ho + y0 + r) * p.Wo + c) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
+      const uint4_t v = *reinterpret_cast<const uint4_t*>(smem + m * ROWB + ((ch ^ (m & 15)) << 4));
+      if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, FT_YSTORE_BUF_AUX);
+    }
+    return;
+  }
 
   // ---- phase 3: four quarters of P output channels; the tile of a quarter leaves through one of two LDS staging tiles ----
   {
@@ -1088,13 +1114,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       float16_t (&Aprev)[2][MT2] = (q & 1) ? acc : acc_b;
       bns_unroll<KC>([&](auto kcc) {
         constexpr int kc = decltype(kcc)::value;
-        constexpr int g = G::G3 + q * KC + kc;
+        constexpr int g = G3 + q * KC + kc;
         row_bases(0, (kc + 1) % KC, 0, rbn, false);
         if constexpr (q > 0) {
-          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < G::GEND, rbn, A, std::integral_constant<int, 12>{},
+          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < GEND, rbn, A, std::integral_constant<int, 12>{},
                 [&] { epi_piece(std::integral_constant<int, q - 1>{}, kc / MT2, kc % MT2, Aprev); });
         } else {
-          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < G::GEND, rbn, A, nx0{}, no_extra);
+          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < GEND, rbn, A, nx0{}, no_extra);
         }
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
@@ -1119,9 +1145,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       constexpr int q = decltype(qc)::value;
       bns_unroll<KC>([&](auto kcc) {
         constexpr int kc = decltype(kcc)::value;
-        constexpr int g = G::G3 + q * KC + kc;
+        constexpr int g = G3 + q * KC + kc;
         row_bases(0, (kc + 1) % KC, 0, rbn, false);
-        dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < G::GEND, rbn, acc, nx0{}, no_extra);
+        dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < GEND, rbn, acc, nx0{}, no_extra);
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
@@ -1181,8 +1207,32 @@ __global__ __launch_bounds__(256) void bns_pack_kernel(const half_t* __restrict_
   out[idx] = *reinterpret_cast<const uint4_t*>(src);
 }
 
+// the head form's stream (P = 256): NC1 = C / 64 steps of w1 [P][C], then nine taps x KC steps of w2; same piece order
+__global__ __launch_bounds__(256) void bns_pack_head_kernel(const half_t* __restrict__ w1, const half_t* __restrict__ w2,
+                                                            uint4_t* __restrict__ out, int C) {
+  using G = BnsGeom<256>;
+  const int nc1 = C / 64, gend = nc1 + 9 * G::KC;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= gend * G::WSTEP / 16) return;
+  const int lane = idx & 63, frag = idx >> 6;
+  const int per_step = 4 * G::NCT;
+  const int g = frag / per_step, f = frag - g * per_step;
+  const int kk = f / G::NCT, i = f - kk * G::NCT;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int co_t = 32 * i + bns_sigma(l31);
+  const int k_t = 16 * kk + 8 * lhi;
+  const half_t* src;
+  if (g < nc1) {
+    src = w1 + (size_t)co_t * C + 64 * g + k_t;
+  } else {
+    const int sft = g - nc1, tap = sft / G::KC, kc = sft - tap * G::KC;
+    src = w2 + (size_t)co_t * (9 * 256) + tap * 256 + 64 * kc + k_t;
+  }
+  out[idx] = *reinterpret_cast<const uint4_t*>(src);
+}
+
 struct BnsPlan {
-  int variant;   // 0: <128,4,3>  1: <256,4,3>  2: <256,3,2>  3: <256,2,1> column-split (direct kernel only)
+  int variant;   // 0: <128,4,3>  1: <256,4,3>  2: <256,3,2>  3: <256,2,1> column-split (direct kernel only)  4: stride-2 head <4,1>
   int TH, ppi;
   int TWc, csplit;
 };
@@ -1190,7 +1240,24 @@ struct BnsPlan {
 static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
   if (!d) return FT_ERR_INVALID_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
-  if (d->dtype != FT_F16 || d->head_only || d->projection || (d->P != 128 && d->P != 256) || d->C != 4 * d->P) return FT_ERR_UNSUPPORTED;
+  if (d->head_only) {
+    // conv1 + conv2 / stride 2 of a 256-plane entry block (layer3.0): 512 input channels, even map, <= 120 T1 rows per strip
+    if (d->dtype != FT_F16 || d->projection || d->P != 256 || d->C != 512 || d->stride != 2 || (d->H & 1) || (d->W & 1)) return FT_ERR_UNSUPPORTED;
+    if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
+    const int Ho = d->H / 2, Wo = d->W / 2;
+    if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + d->P) return FT_ERR_INVALID_ARG;
+    if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * Ho * Wo * d->y_cstride * 2 >= (1LL << 31))
+      return FT_ERR_UNSUPPORTED;
+    int th = (120 / d->W - 1) / 2;
+    const int th2 = 32 / Wo;
+    th = th < th2 ? th : th2;
+    if (th < 1) return FT_ERR_UNSUPPORTED;
+    th = th < Ho ? th : Ho;
+    th = ceil_div(Ho, ceil_div(Ho, th));
+    *out = BnsPlan{4, th, ceil_div(Ho, th), d->W, 1};
+    return FT_OK;
+  }
+  if (d->dtype != FT_F16 || d->projection || (d->P != 128 && d->P != 256) || d->C != 4 * d->P || d->stride > 1) return FT_ERR_UNSUPPORTED;
   if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
   if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + d->C) return FT_ERR_INVALID_ARG;
   if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->H * d->W * d->y_cstride * 2 >= (1LL << 31))
@@ -1277,9 +1344,9 @@ static int bns_launch(const BnsParams& p, hipStream_t s) {
 #ifndef FT_BNS_XH_SLOTS
 #define FT_BNS_XH_SLOTS 3
 #endif
-template <int MT1, int MT2, bool XH>
+template <int MT1, int MT2, bool XH, int HEADC = 0>
 static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
-  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : 3>;
+  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : 3, HEADC>;
   constexpr int lds = 81920 + 2 * MT2 * 32 * 512;
   static bool attr_done[64] = {};          // the LDS opt-in is per device
   int dev = 0;
@@ -1304,6 +1371,7 @@ extern "C" int ft_bottleneck_stream_supported(const ft_bottleneck_desc* d) {
 extern "C" long long ft_bottleneck_stream_weight_bytes(const ft_bottleneck_desc* d) {
   ft::BnsPlan pl;
   if (ft::bns_plan(d, &pl) != FT_OK) return 0;
+  if (pl.variant == 4) return (long long)(d->C / 64 + 9 * ft::BnsGeom<256>::KC) * ft::BnsGeom<256>::WSTEP;
   return d->P == 128 ? (long long)ft::BnsGeom<128>::GEND * ft::BnsGeom<128>::WSTEP : (long long)ft::BnsGeom<256>::GEND * ft::BnsGeom<256>::WSTEP;
 }
 
@@ -1313,9 +1381,15 @@ extern "C" int ft_bottleneck_stream_pack(const ft_bottleneck_desc* d, const void
   BnsPlan pl;
   const int st = bns_plan(d, &pl);
   if (st != FT_OK) return st;
-  if (!w1 || !w2 || !w3 || !wstream) return FT_ERR_INVALID_ARG;
+  if (!w1 || !w2 || (!w3 && pl.variant != 4) || !wstream) return FT_ERR_INVALID_ARG;
   hipStream_t s = as_stream(stream);
   const half_t *a = static_cast<const half_t*>(w1), *b = static_cast<const half_t*>(w2), *c = static_cast<const half_t*>(w3);
+  if (pl.variant == 4) {
+    const int n16 = (int)(ft_bottleneck_stream_weight_bytes(d) / 16);
+    hipLaunchKernelGGL(bns_pack_head_kernel, dim3(ceil_div(n16, 256)), dim3(256), 0, s, a, b, static_cast<uint4_t*>(wstream), d->C);
+    FT_LAUNCH_CHECK("bns_pack_head_kernel");
+    return FT_OK;
+  }
   if (d->P == 128) {
     const int n16 = BnsGeom<128>::GEND * BnsGeom<128>::WSTEP / 16;
     hipLaunchKernelGGL(bns_pack_kernel<128>, dim3(ceil_div(n16, 256)), dim3(256), 0, s, a, b, c, static_cast<uint4_t*>(wstream));
@@ -1341,11 +1415,13 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   p.tab = reinterpret_cast<const char*>(tables);
   p.H = d->H; p.W = d->W; p.TH = pl.TH; p.ppi = pl.ppi;
   p.TWc = pl.TWc; p.csplit = pl.csplit;
+  if (pl.variant == 4) { p.Ho = d->H / 2; p.Wo = d->W / 2; }
   p.total = d->N * pl.ppi;
   p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
   p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->x_cstride * 2);
   p.y_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->y_cstride * 2);
   p.ws_bytes = (unsigned)ft_bottleneck_stream_weight_bytes(d);
+  if (pl.variant == 4) p.y_bytes = (unsigned)((size_t)d->N * p.Ho * p.Wo * d->y_cstride * 2);
   static const int dbg = getenv("FT_BNS_DBG") ? atoi(getenv("FT_BNS_DBG")) : 0;
   p.dbg = dbg;
   if (dbg & 64) p.ws_bytes = 0;     // dev: every weight load out of range (returns 0, no L2 access): the kernel's time without its weight stream
@@ -1355,6 +1431,7 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
     case 0: return bns_launch<128, 4, 3>(p, s);
     case 1: return bns_launch<256, 4, 3>(p, s);
     case 3: return bns_launch_direct<2, 1, true>(p, s);
+    case 4: return bns_launch_direct<4, 1, false, 8>(p, s);
     default: {
       // 64-pixel strips at 256 planes: weights straight to registers (FT_BNS_DIRECT=0: through the LDS ring, dev A/B)
       static const bool no_direct = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;

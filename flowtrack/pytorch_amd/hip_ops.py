@@ -1029,6 +1029,54 @@ def record_bottleneck_head(prog: Program, c1: "FusedConv", c2: "FusedConv", x: A
              t2.t.data_ptr(), keep=(d, x.t, t2.t, w1, w2, table))
 
 
+def bottleneck_head_stream_fusable(c1: "FusedConv", c2: "FusedConv", x: ActView, t2: ActView) -> bool:
+    """True when ft_bottleneck_stream_fwd(head_only, stride 2) covers conv1 + conv2 of a stage's entry block (fp16, 512 -> 256
+    -> 256 with the stride on conv2: layer3.0, resnet.py:44-49)."""
+    if not FUSE_BOTTLENECK_STREAM or x.t.dtype != torch.float16 or x.rowpacked or (x.N, x.H // 2, x.W // 2) != (t2.N, t2.H, t2.W):
+        return False
+    if (c1.k, c2.k) != (1, 3) or (c1.stride, c2.stride, c2.pad) != (1, 2, 1):
+        return False
+    if (c1.cin, c1.cout, c2.cin, c2.cout, t2.C) != (x.C, c2.cin, c2.cin, c2.cin, c2.cin):
+        return False
+    if any(c.transposed or c.tail_cout or c.act != ACT_CODES["relu"] or c._bn is None for c in (c1, c2)):
+        return False
+    d = _bottleneck_desc(x, t2, c2.cin, head_only=True)
+    d.stride = 2
+    return _lib.load().ft_bottleneck_stream_supported(ctypes.byref(d)) == 0
+
+
+def record_bottleneck_head_stream(prog: Program, c1: "FusedConv", c2: "FusedConv", x: ActView, t2: ActView, label: str) -> None:
+    """conv1 + bn1 + relu -> conv2 (stride 2) + bn2 + relu of a 256-plane entry block as one launch: t1 stays in LDS at the
+    input resolution, the weights stream from L2 (ft_bottleneck_stream_fwd, head_only + stride 2)."""
+    lib = _lib.load()
+    planes = c2.cin
+    w1, s1, b1 = _bottleneck_packed(c1, x, (planes, x.C, 1), label)
+    w2, s2, b2 = _bottleneck_packed(c2, x, (planes, 9 * planes, 1), label)
+    d = _bottleneck_desc(x, t2, planes, head_only=True)
+    d.stride = 2
+    check(lib.ft_bottleneck_stream_supported(ctypes.byref(d)), "ft_bottleneck_stream_supported")
+    key = ("bns_head_stream", x.N, x.H, x.W)
+    cached = c1._packed.get(key) if hasattr(c1, "_packed") else None
+    if cached is None:
+        nbytes = int(lib.ft_bottleneck_stream_weight_bytes(ctypes.byref(d)))
+        wstream = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
+        check(lib.ft_bottleneck_stream_pack(ctypes.byref(d), w1.data_ptr(), w2.data_ptr(), None, wstream.data_ptr(),
+                                            current_stream_handle(x.t.device)), "ft_bottleneck_stream_pack")
+        torch.cuda.current_stream(x.t.device).synchronize()
+        P = planes
+        tables = torch.zeros(6 * 2 * P, dtype=torch.float32, device=x.t.device)          # the kernel's descriptor spans six tables
+        tables[:4 * P] = torch.cat([s1.flatten()[:P], b1.flatten()[:P], s2.flatten()[:P], b2.flatten()[:P]]).float()
+        cached = (wstream, tables)
+        if hasattr(c1, "_packed"):
+            c1._packed[key] = cached
+    wstream, tables = cached
+    flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
+    prog.flops += flops
+    prog.fused_records.append((label, len(prog.calls), flops))
+    prog.add("ft_bottleneck_stream_fwd", ctypes.byref(d), x.t.data_ptr(), wstream.data_ptr(), tables.data_ptr(), t2.t.data_ptr(),
+             keep=(d, x.t, t2.t, wstream, tables))
+
+
 def bottleneck_entry_fusable(c1: "FusedConv", c2: "FusedConv", sc: "FusedShortcutConv", x: ActView, y: ActView) -> bool:
     """True when ft_bottleneck_fwd(projection) covers a stage's WHOLE entry block (fp16, 64 -> 64 -> 64 -> 256, stride 1,
     projection shortcut K-concatenated with conv3)."""

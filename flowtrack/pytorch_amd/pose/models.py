@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ..engine import HipModule
 from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable,
-                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head,
+                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_head_stream_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head, record_bottleneck_head_stream,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -212,9 +212,19 @@ class DeconvResnet(HipModule):
                 if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
                     record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
                 else:
+                    head2 = self.fuse_bottleneck and s == 2 and bottleneck_head_stream_fusable(c1, c2, cur, t2)
+                    if head2:
+                        # the 256-plane entry block's conv1 + stride-2 conv2 as one streamed-weights launch, or as two launches:
+                        # both recorded, the first-call benchmark keeps one (the recorder's first choice: two launches)
+                        prog.begin_choice(f"head2|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{t2.cstride}")
+                        prog.option("convs")
                     t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
                     c1.record(prog, cur, t1)
                     c2.record(prog, t1, t2)
+                    if head2:
+                        prog.option("fused")
+                        record_bottleneck_head_stream(prog, c1, c2, cur, t2, name + ".conv1+conv2")
+                        prog.end_choice()
                 if fused is not None:
                     # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
                     # the shortcut tensor never exists in HBM

@@ -235,6 +235,11 @@ typedef struct ft_bottleneck_desc {
                              y = relu(bn3(conv3(t2)) + bn_d(conv_d(x))) [N,H,W,4P]; w3 = [4P][P | C] fp16, the two 1x1
                              convs K-concatenated with their BatchNorm scales folded in (the layout ft_conv2d_fwd's x2_*
                              path takes), scale_shift = float[4P + 8P]: {s1 b1 s2 b2} then scale3 = 1, shift3 = b3 + b_d */
+  int stride;             /* stride of conv2 (0 / 1 = 1).  2 only with head_only in the streamed-weights form
+                             (ft_bottleneck_stream_*: P = 256, C = 512, even H and W: layer3.0 of the ResNets, resnet.py:44-49):
+                             y = t2 [N, H/2, W/2, P]; weight stream = w1 [P][C] then w2 [P][9P]; tables = float[6][2P] of
+                             which {scale1, shift1} {scale2, shift2} are read.  (Appended in round 3: zero-initialised
+                             descriptors of older callers keep their meaning.) */
 } ft_bottleneck_desc;
 int ft_bottleneck_supported(const ft_bottleneck_desc* d);   /* FT_OK or FT_ERR_UNSUPPORTED / FT_ERR_INVALID_ARG */
 int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,

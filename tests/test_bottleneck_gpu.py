@@ -161,6 +161,53 @@ def test_stream_256_variants_match_oracle_and_each_other(hip_lib, case, variant,
         assert (diff > 0).float().mean().item() < 0.05, "the two forms should agree bit for bit almost everywhere"
 
 
+# ft_bottleneck_stream_fwd(head_only, stride 2): conv1 + stride-2 conv2 of the 256-plane entry block (layer3.0): (name, N, H, W, x stride, x offset)
+HEAD2_CASES = [("h2_r50_32x24", 3, 32, 24, 512, 0), ("h2_r101_48x36", 2, 48, 36, 512, 0), ("h2_tiny_4x2", 1, 4, 2, 512, 0),
+               ("h2_ragged_rows_10x8", 2, 10, 8, 544, 32), ("h2_ragged_last_30x24", 2, 30, 24, 512, 0), ("h2_recycle", 70, 32, 24, 512, 0)]
+
+
+@pytest.mark.parametrize("case", HEAD2_CASES, ids=[c[0] for c in HEAD2_CASES])
+def test_stream_head_stride2_matches_oracle_and_the_two_launches(hip_lib, case):
+    from flowtrack.pytorch_amd.hip_ops import bottleneck_head_stream_fusable, record_bottleneck_head_stream
+    name, N, H, W, xcs, xoff = case
+    dev, dtype, seed, P, C = torch.device("cuda:0"), torch.float16, 27, 256, 512
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    bn1, bn2 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+    want = F.relu(_bnf(F.conv2d(t1, w2, stride=2, padding=1), bn2))
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, stride=2, pad=1, bn=bn2, label="conv2", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    if xoff:
+        xv.t[..., :xoff] = 7.0
+    Ho, Wo = H // 2, W // 2
+    y = ActView(torch.full((N, Ho, Wo, P + 32), 3.0, dtype=dtype, device=dev), P, 32)
+    assert bottleneck_head_stream_fusable(c1, c2, xv, y)
+    prog = make_program()
+    record_bottleneck_head_stream(prog, c1, c2, xv, y, name)
+    run_program(prog)
+    got = view_to_nchw(y)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: fused head vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    assert torch.all(y.t[..., :32] == 3.0), "channels outside the output slice were written"
+    t1v = ActView(torch.zeros((N, H, W, act_stride(P)), dtype=dtype, device=dev), P, 0)
+    y2 = ActView(torch.zeros((N, Ho, Wo, P), dtype=dtype, device=dev), P, 0)
+    prog2 = make_program()
+    c1.record(prog2, xv, t1v)
+    c2.record(prog2, t1v, y2)
+    run_program(prog2)
+    diff = (got - view_to_nchw(y2)).abs()
+    assert diff.max().item() <= 1e-2 * scale
+    assert (diff > 0).float().mean().item() < 0.05, "fused and separate launches should agree bit for bit almost everywhere"
+    y.t.fill_(5.0)
+    run_program(prog)
+    assert torch.equal(view_to_nchw(y), got)
+
+
 HEAD_CASES = [("r50_64x48", 2, 64, 48), ("r101_96x72", 1, 96, 72), ("ragged_13x20", 3, 13, 20), ("recycle", 24, 64, 48)]
 
 

@@ -177,7 +177,8 @@ def test_plan_alternatives_are_resolved_and_equivalent(hip_lib, monkeypatch):
         monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
         monkeypatch.setattr(hip_ops, "_TILE_CACHE_LOADED", True)
         if flip:      # pre-seed the cache with the OTHER form of every choice the first model benchmarked (picks are names)
-            forms = {"conv": ("direct", "igemm"), "bottleneck": ("fused", "convs"), "entry": ("fused", "head+exit")}
+            forms = {"conv": ("direct", "igemm"), "bottleneck": ("fused", "convs"), "entry": ("fused", "head+exit"),
+                     "head2": ("convs", "fused")}
             for k, picked in seen.items():
                 a, b = forms[k.split("|")[1]]
                 hip_ops._TILE_CACHE[k] = b if picked == a else a
