@@ -357,33 +357,60 @@ __global__ __launch_bounds__(256) void flow_pack_pair4_kernel(const float* __res
 
 // ---- nn.Upsample(scale_factor=4, mode='bilinear'), align_corners=False, times `mul` -------------
 __global__ __launch_bounds__(256) void upsample_bilinear4x_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                  int h, int w, size_t total4, float mul) {
-  // one thread = 4 consecutive outputs of a row (one 16-byte store): they blend the same three source columns
-  const int H = 4 * h;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-    const int jx = (int)(i % w);                 // source column the 4 outputs straddle
+                                                                  int h, int w, size_t total, float mul) {
+  // one thread = the 4 x 4 outputs over one source cell: output rows 4 iy + {0, 1} blend source rows (iy - 1, iy), rows
+  // 4 iy + {2, 3} blend (iy, iy + 1) (clamped at the borders exactly as the per-output formulas below clamp them), all
+  // four share three source columns: 12 loads for 16 outputs and four 16-byte stores, one per output row (lanes = consecutive
+  // cells: 1 KiB per wave-store).  The per-output arithmetic is the one-output-row-per-thread kernel's, term for term.
+  const int W = 4 * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int jx = (int)(i % w);                 // source column the 4 output columns straddle
     const size_t t = i / w;
-    const int oy = (int)(t % H);
-    const size_t nc = t / H;
-    float sy = ((float)oy + 0.5f) * 0.25f - 0.5f;
-    sy = sy < 0.f ? 0.f : sy;
-    const int y0 = (int)sy;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, hy = 1.f - ly;
-    const float* p0 = x + nc * (size_t)h * w + (size_t)y0 * w;
-    const float* p1 = x + nc * (size_t)h * w + (size_t)y1 * w;
-    float4_t out;
+    const int iy = (int)(t % h);
+    const size_t nc = t / h;
+    const float* px = x + nc * (size_t)h * w;
+    int x0[4], x1[4];
+    float lx[4], hx[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float sx = ((float)(4 * jx + e) + 0.5f) * 0.25f - 0.5f;
       sx = sx < 0.f ? 0.f : sx;
-      const int x0 = (int)sx;
-      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-      const float lx = sx - (float)x0, hx = 1.f - lx;
-      const float v00 = p0[x0] * mul, v01 = p0[x1] * mul, v10 = p1[x0] * mul, v11 = p1[x1] * mul;
-      out[e] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      x0[e] = (int)sx;
+      x1[e] = x0[e] + (x0[e] < w - 1 ? 1 : 0);
+      lx[e] = sx - (float)x0[e];
+      hx[e] = 1.f - lx[e];
     }
-    *reinterpret_cast<float4_t*>(y + i * 4) = out;
+    // the three source columns the four outputs of a row touch: x0[0] = x0[1], x1[0] = x1[1] = x0[2] = x0[3], x1[2] = x1[3]
+    const int ca = x0[0], cb = x0[2], cc = x1[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int oy = 4 * iy + 2 * half;
+      float sy = ((float)oy + 0.5f) * 0.25f - 0.5f;
+      sy = sy < 0.f ? 0.f : sy;
+      const int y0 = (int)sy;                     // the same for output row oy + 1
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+      const float* p0 = px + (size_t)y0 * w;
+      const float* p1 = px + (size_t)y1 * w;
+      const float r0[3] = {p0[ca] * mul, p0[cb] * mul, p0[cc] * mul};
+      const float r1[3] = {p1[ca] * mul, p1[cb] * mul, p1[cc] * mul};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float syk = ((float)(oy + k) + 0.5f) * 0.25f - 0.5f;
+        syk = syk < 0.f ? 0.f : syk;
+        const float ly = syk - (float)y0, hy = 1.f - ly;
+        float4_t out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // x0[e] / x1[e] among (ca, cb, cc), picked by VALUE: at the left / right border the clamped columns repeat
+          const float v00 = x0[e] == ca ? r0[0] : (x0[e] == cb ? r0[1] : r0[2]);
+          const float v01 = x1[e] == cb ? r0[1] : (x1[e] == cc ? r0[2] : r0[0]);
+          const float v10 = x0[e] == ca ? r1[0] : (x0[e] == cb ? r1[1] : r1[2]);
+          const float v11 = x1[e] == cb ? r1[1] : (x1[e] == cc ? r1[2] : r1[0]);
+          out[e] = hy * (hx[e] * v00 + lx[e] * v01) + ly * (hx[e] * v10 + lx[e] * v11);
+        }
+        *reinterpret_cast<float4_t*>(y + (nc * (size_t)(4 * h) + (size_t)(oy + k)) * W + 4 * jx) = out;
+      }
+    }
   }
 }
 
@@ -571,9 +598,9 @@ extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float r
 extern "C" int ft_upsample_bilinear4x(const float* x, float* y, int N, int C, int h, int w, float mul,
                                       ft_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0) return FT_ERR_INVALID_ARG;
-  const size_t total4 = (size_t)N * C * 4 * h * w;    // 16 h w outputs per plane, 4 per thread
-  hipLaunchKernelGGL(upsample_bilinear4x_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, y, h, w,
-                     total4, mul);
+  const size_t cells = (size_t)N * C * h * w;         // 16 outputs per source cell, one cell per thread
+  hipLaunchKernelGGL(upsample_bilinear4x_kernel, dim3(grid_for(cells)), dim3(256), 0, as_stream(stream), x, y, h, w,
+                     cells, mul);
   FT_LAUNCH_CHECK("upsample_bilinear4x_kernel");
   return FT_OK;
 }
