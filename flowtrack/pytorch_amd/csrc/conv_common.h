@@ -73,7 +73,8 @@ template <> struct Elem<float> { static constexpr int VEC = 4; };
 // ELEMENT inside the unrolled epilogues (64 s_cbranch per 128-pixel tile in the stem kernel): k is loop-invariant scalar work.
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   const float k = act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f);
-  return __builtin_fmaf(k, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+  const float r = __builtin_fmaf(k, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+  return act == FT_ACT_NONE ? v : r;      // (a select on a uniform condition: layers without an activation keep NaN / -0 as they are)
 }
 
 template <int N, int I = 0, typename F>
