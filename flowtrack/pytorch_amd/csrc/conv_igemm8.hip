@@ -488,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvParams p)
     uint4_t w[3][2];                                              // [slot][hi, lo]
     auto issue = [&](auto slotc, auto stepc) __attribute__((always_inline)) {
       constexpr int sl = decltype(slotc)::value, st = decltype(stepc)::value;
-      if (!(p.dbg & 1024)) ld2x16_asm(w[sl][0], w[sl][1], lane16, wperm + st * 2048);
+      ld2x16_asm(w[sl][0], w[sl][1], lane16, wperm + st * 2048);
     };
     auto partial = [&](auto jc, float16_t& a2) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
@@ -503,14 +503,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvParams p)
         constexpr int i = st >> 1, pr = st & 1, sl = st % 3;
         // this step's four pieces have landed once at most the pieces of the later steps in flight are outstanding
         constexpr int later = (st + 2 < 8 ? 2 : 7 - st) * 2;
-        if (!(p.dbg & 1024)) wait_vm_asm<later>(w[sl][0], w[sl][1]);
+        wait_vm_asm<later>(w[sl][0], w[sl][1]);
         __builtin_amdgcn_sched_barrier(0);
         const int c0 = wc * 128 + i * 32 + 16 * pr + 4 * lhi;
         const uint2v_t ha = activated(i, j, 2 * pr, c0), hb = activated(i, j, 2 * pr + 1, c0 + 8);
         const uint4_t tb = {ha[0], ha[1], hb[0], hb[1]};
         a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, w[sl][0]), __builtin_bit_cast(half8_t, tb), a2, 0, 0, 0);
-        if (!(p.dbg & 128))
-          a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, w[sl][1]), __builtin_bit_cast(half8_t, tb), a2, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, w[sl][1]), __builtin_bit_cast(half8_t, tb), a2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (st + 3 < 8) issue(std::integral_constant<int, sl>{}, std::integral_constant<int, st + 3>{});   // (its slot is free again)
       });
