@@ -274,6 +274,25 @@ def test_flownet2c_cs_fp32_vs_oracle(hip_lib, oracle_lib, name):
     assert err <= 1e-3, f"{name}: max abs err {err:.3e} px"
 
 
+_C_FAMILY_GOLDEN = {"FlowNet2C": "c", "FlowNet2CS": "cs", "FlowNet2CSS": "css", "FlowNet2": "full"}
+
+
+@pytest.mark.parametrize("name", list(_C_FAMILY_GOLDEN))
+def test_flownet2_c_family_fp32_matches_reference_graph_golden(hip_lib, name):
+    """F3 / N4: the flows the IMPORTED reference graphs produced (FlowNetC.py:71-128, models.py:108-178,180-246,346-498)
+    with the restated operators injected at their FFI boundary (tests/golden/make_golden.py: inject_restated_cuda_ops).
+    Pins concat orders, div_flow handling, which frame is warped and the bilinear / nearest x4 of every stacked model."""
+    tag = _C_FAMILY_GOLDEN[name]
+    seed = int(G[f"synth_flow_{tag}_seed"])
+    m, sd = _build(getattr(models, name), seed, torch.float32)
+    B, H, W = (int(v) for v in G["synth_shape"])
+    flow = m(synth.frame_pairs(SEED, B, H, W).cuda()).cpu().numpy()
+    want = G[f"synth_flow_{tag}"]
+    err = np.abs(flow - want).max()
+    print(name, "flow range", want.min(), want.max(), "err", err)
+    assert err <= 1e-3, f"{name}: max abs err {err:.3e} px vs the imported reference graph"
+
+
 @pytest.mark.parametrize("name", ["FlowNet2S", "FlowNet2C", "FlowNet2CS", "FlowNet2SD", "FlowNet2CSS", "FlowNet2"])
 def test_flownet_fp16_vs_fp32_oracle(hip_lib, oracle_lib, name):
     """pseudo-fp16 mode (fp16 storage, fp32 accumulate; tools/flownet/demo.py --fp16): EPE vs the fp32 oracle."""

@@ -4,6 +4,7 @@ import os
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -171,6 +172,24 @@ def test_flownet2c_cs_oracle_runs_and_is_consistent(oracle_lib):
     assert c1.shape == (1, 12, 64, 64) and torch.allclose(c1[:, 9:11], parts["flowc"] / 20.0)
     assert torch.allclose(c1[:, 11:12], torch.sqrt(((c1[:, :3] - c1[:, 6:9]) ** 2).sum(1, keepdim=True)), atol=1e-6)
     assert out.shape == (1, 2, 64, 64) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("name,tag", [("FlowNet2C", "c"), ("FlowNet2CS", "cs"), ("FlowNet2CSS", "css"), ("FlowNet2", "full")])
+def test_flownet2_c_family_oracle_matches_reference_graph_golden(oracle_lib, name, tag):
+    """F3 / N4 pinned: oracle/flow_ref.py reproduces the flows of the IMPORTED reference graphs (restated ops injected at
+    the `_ext` FFI boundary by tests/golden/make_golden.py) — asserted at generation, re-checked here from the fixture."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "flow_golden.npz"))
+    seed = int(g[f"synth_flow_{tag}_seed"])
+    m = getattr(flow_models, name)(ARGS)
+    sd = synth.fill_flow_state_dict(m.state_dict(), seed)
+    B, H, W = (int(v) for v in g["synth_shape"])
+    pair = synth.frame_pairs(int(g["seed"]), B, H, W)
+    fwd = {"FlowNet2C": flow_ref.flownet2c_forward, "FlowNet2CS": flow_ref.flownet2cs_forward,
+           "FlowNet2CSS": flow_ref.flownet2css_forward, "FlowNet2": flow_ref.flownet2_forward}[name]
+    torch.set_num_threads(8)
+    err = float(np.abs(fwd(sd, pair).numpy() - g[f"synth_flow_{tag}"]).max())
+    assert err <= 1e-4, f"{name}: oracle vs imported reference graph {err:.3e}"
 
 
 def test_flownet2_css_oracle_wiring(oracle_lib):
