@@ -105,6 +105,7 @@ _PROTOTYPES = {
                                      c_void_p]),
     "ft_heatmap_keypoint_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ft_heatmap_min_margin": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ft_heatmap_argmax_screen": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ft_flow_rgb_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ft_flow_pack_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 7 + [c_void_p]),
     "ft_upsample_bilinear4x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

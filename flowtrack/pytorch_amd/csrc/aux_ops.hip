@@ -222,6 +222,79 @@ __global__ __launch_bounds__(256) void heatmap_min_margin_kernel(const float* __
   if (threadIdx.x == 0) out[n] = crop_min;
 }
 
+// ---- arg-max screen with a RELATIVE error bound: which crops may have another arg-max (or another `score > 0` mask) in fp32 ----
+// Per crop: (top-1, top-2, min) of each of its K maps, then with R = (largest value - smallest value over the crop's maps) and
+// E = rel_bound * R (the fp16 mode's heat-map error scales with the maps' range, not with an absolute constant):
+//   flag = any map with !(top1 - top2 >= 2 E)   (two values closer than 2 E can swap under an error of E per element)
+//          or !(|top1| >= E)                    (max_preds zeroes the coordinates when score <= 0, evaluation.py:17-19: the mask can flip)
+//          or any non-finite statistic          (NaN compares false: written as negated >=)
+// stats[n] = (smallest margin, R, smallest |top1|, E).  K <= 256.
+__global__ __launch_bounds__(256) void heatmap_argmax_screen_kernel(const float* __restrict__ hm, int K, int HW, float rel_bound,
+                                                                    int32_t* __restrict__ flags, float* __restrict__ stats) {
+  const int n = blockIdx.x;
+  __shared__ float s_b[4], s_s[4], s_m[4];
+  __shared__ float s_t1[256], s_t2[256];
+  float crop_max = -INFINITY, crop_min = INFINITY;
+  bool bad = false;
+  for (int k = 0; k < K; ++k) {
+    const float* p = hm + ((size_t)n * K + k) * HW;
+    float b = -INFINITY, s2 = -INFINITY, mn = INFINITY;
+    bool nf = false;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float v = p[i];
+      nf |= !(fabsf(v) <= 3.0e38f);
+      if (v > b) { s2 = b; b = v; } else if (v > s2) s2 = v;
+      mn = fminf(mn, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(b, off), os = __shfl_xor(s2, off);
+      const float nb = fmaxf(b, ob);
+      s2 = fmaxf(fminf(b, ob), fmaxf(s2, os));
+      b = nb;
+      mn = fminf(mn, __shfl_xor(mn, off));
+    }
+    bad |= __any(nf) != 0;
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                  // (the previous map's partials have been read)
+    if ((threadIdx.x & 63) == 0) { s_b[wave] = b; s_s[wave] = s2; s_m[wave] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+        const float nb = fmaxf(b, s_b[w]);
+        s2 = fmaxf(fminf(b, s_b[w]), fmaxf(s2, s_s[w]));
+        b = nb;
+        mn = fminf(mn, s_m[w]);
+      }
+      s_t1[k] = b;
+      s_t2[k] = s2;
+      crop_max = fmaxf(crop_max, b);
+      crop_min = fminf(crop_min, mn);
+    }
+  }
+  // every wave saw the same `bad` bits of ITS lanes only: fold the four waves through LDS
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = bad ? 1.f : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool flag = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) > 0.f;
+    const float R = crop_max - crop_min, E = rel_bound * R;
+    float mmin = INFINITY, amin = INFINITY;
+    for (int k = 0; k < K; ++k) {
+      const float mg = s_t1[k] - s_t2[k], at = fabsf(s_t1[k]);
+      flag |= !(mg >= 2.f * E) || !(at >= E);
+      mmin = fminf(mmin, mg);
+      amin = fminf(amin, at);
+    }
+    flag |= !(R <= 3.0e38f) || !(E >= 0.f);
+    flags[n] = flag ? 1 : 0;
+    stats[4 * n] = mmin;
+    stats[4 * n + 1] = R;
+    stats[4 * n + 2] = amin;
+    stats[4 * n + 3] = E;
+  }
+}
+
 // ---- FlowNet2* rgb mean: stage 1 partial sums, stage 2 finish -----------------------------------
 __global__ __launch_bounds__(256) void rgb_partial_sum_kernel(const float* __restrict__ x, size_t L,
                                                               float* __restrict__ partial) {
@@ -551,6 +624,16 @@ extern "C" int ft_heatmap_min_margin(const float* heatmaps, int N, int K, int H,
   if (!heatmaps || !min_margin || N <= 0 || K <= 0 || H <= 0 || W <= 0 || (long long)H * W < 2) return FT_ERR_INVALID_ARG;
   hipLaunchKernelGGL(heatmap_min_margin_kernel, dim3(N), dim3(256), 0, as_stream(stream), heatmaps, K, H * W, min_margin);
   FT_LAUNCH_CHECK("heatmap_min_margin_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_heatmap_argmax_screen(const float* heatmaps, int N, int K, int H, int W, float rel_bound, int32_t* flags, float* stats,
+                                        ft_stream_t stream) {
+  if (!heatmaps || !flags || !stats || N <= 0 || K <= 0 || H <= 0 || W <= 0 || (long long)H * W < 2 || !(rel_bound >= 0.f))
+    return FT_ERR_INVALID_ARG;
+  if (K > 256) return FT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(heatmap_argmax_screen_kernel, dim3(N), dim3(256), 0, as_stream(stream), heatmaps, K, H * W, rel_bound, flags, stats);
+  FT_LAUNCH_CHECK("heatmap_argmax_screen_kernel");
   return FT_OK;
 }
 

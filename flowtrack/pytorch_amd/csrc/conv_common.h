@@ -68,13 +68,17 @@ template <typename T> struct Elem;
 template <> struct Elem<half_t> { static constexpr int VEC = 8; };
 template <> struct Elem<float> { static constexpr int VEC = 4; };
 
-// act(v) = k * min(v, 0) + max(v, 0) with k = 0 (ReLU), slope (LeakyReLU) or 1 (none): the values of
-// `v > 0 ? v : v * k`, in three vector instructions.  The branchy form compiled to two scalar compare-and-branch pairs PER
-// ELEMENT inside the unrolled epilogues (64 s_cbranch per 128-pixel tile in the stem kernel): k is loop-invariant scalar work.
+// act(v) = max(v, k * v) with k = 0 (ReLU), slope (LeakyReLU, 0 <= slope <= 1) or 1 (none): the values of `v > 0 ? v : v * k`
+// in two vector instructions, k loop-invariant scalar work.  (The branchy form compiled to two scalar compare-and-branch pairs
+// PER ELEMENT inside the unrolled epilogues: 64 s_cbranch per 128-pixel tile in the stem kernel.)  Non-finite inputs: NaN stays
+// NaN (max(NaN, NaN); the earlier k * min(v, 0) + max(v, 0) form returned 0 for it — v_min / v_max drop a NaN operand), +-inf
+// stay what torch gives, with ONE exception: ReLU(-inf) returns -inf where torch returns 0 (-inf * 0 = NaN, and max(-inf, NaN)
+// = -inf).  A slope > 1 takes the compare-and-select form (uniform branch).  conv_direct.hip uses the same max(v, k * v) in its own
+// epilogues; the ReLU-only fused bottleneck kernels use max(v, 0) and conv_igemm8.hip max(v, 0) + k * min(v, 0) (NaN -> 0 in both).
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   const float k = act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f);
-  const float r = __builtin_fmaf(k, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
-  return act == FT_ACT_NONE ? v : r;      // (a select on a uniform condition: layers without an activation keep NaN / -0 as they are)
+  if (k <= 1.f) return __builtin_fmaxf(v, v * k);
+  return v > 0.f ? v : v * k;
 }
 
 template <int N, int I = 0, typename F>

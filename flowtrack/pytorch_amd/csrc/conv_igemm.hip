@@ -2642,8 +2642,8 @@ extern "C" double ft_conv_flops(const ft_conv_desc* d) {
 }
 
 extern "C" size_t ft_conv_workspace_bytes(const ft_conv_desc* d) {
-  int hints[32];
-  const int n = ft_conv_tile_candidates(d, hints, 32);
+  int hints[64];     // every form the enumeration can produce (15 + 5 + 6 + 4 + 9 + 2 = 41): nothing truncated, max_sk is the true maximum
+  const int n = ft_conv_tile_candidates(d, hints, 64);
   int max_sk = 1;
   for (int i = 0; i < n; ++i) {
     const int sk = 1 << ((hints[i] >> kHintSkShift) & 7);

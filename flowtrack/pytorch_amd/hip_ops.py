@@ -490,7 +490,7 @@ class Program:
                 d.tile_hint = _TILE_CACHE[k]
             return sum(1 for k in keys if _TILE_CACHE[k])
         cands = []
-        hints = (ctypes.c_int * 32)()
+        hints = (ctypes.c_int * 64)()   # ft_conv_tile_candidates enumerates at most ~45 forms (32 truncated the halo / split-K ones)
         for (_, d), key in zip(convs, keys):     # (_ = index of the launch in self.calls)
             if key in _TILE_CACHE:        # picks are sticky within a process: two plans of one model (other batch-
                 cands.append([_TILE_CACHE[key]])   # independent keys aside) must run the same variants, bit for bit
@@ -498,7 +498,7 @@ class Program:
             if self.calls[_][0] == "ft_conv_direct_fwd":   # one kernel, nothing to pick
                 cands.append([0])
                 continue
-            n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+            n = lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 64)
             if n < 0:
                 check(-n, "ft_conv_tile_candidates")
             cands.append([0] + [int(h) for h in hints[:n]] if n > 1 else [0])

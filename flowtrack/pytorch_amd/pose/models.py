@@ -73,11 +73,13 @@ class DeconvResnet(HipModule):
     keypoints_in_plan = None
     #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
     fuse_heatmap: bool = os.environ.get("FT_FUSE_HEATMAP", "1") != "0"
-    #: forward_keypoint_rows_exact(): a crop is re-run in the fp32 parity arithmetic when the (top-1 - top-2) margin of any of
-    #: its fp16 heat maps is below this.  2 x the heat-map error bound of the fp16 mode guarantees the fp32 arg-max (an error
-    #: of at most E per element cannot reorder two values more than 2 E apart); default = 2 x 4e-3, the stated max-abs bound
-    #: at a heat-map range of ~5 (measured 3.2e-3 .. 3.8e-3)
-    exact_argmax_margin: float = 8e-3
+    #: forward_keypoint_rows_exact(): a crop is re-run in the fp32 parity arithmetic when ft_heatmap_argmax_screen flags it:
+    #: E = exact_argmax_rel_bound x (range of the crop's fp16 heat maps) is taken as the bound of the fp16 mode's heat-map error,
+    #: and a crop is flagged when two values of a map are closer than 2 E (an error of at most E per element cannot reorder
+    #: values further apart), when a map's maximum is within E of 0 (the `score > 0` coordinate mask of max_preds could flip), or
+    #: when anything is non-finite.  The bound is RELATIVE because the error follows the maps' range (the tests bound it as a
+    #: fraction of the range); 1.6e-3 = 2 x the largest measured ratio (4.07e-3 on a range of 5.0 = 0.81e-3)
+    exact_argmax_rel_bound: float = 1.6e-3
 
     def __init__(self, layers: List[int], num_classes: int):
         super().__init__()
@@ -273,9 +275,12 @@ class DeconvResnet(HipModule):
                      plan.kp_idx.data_ptr(), plan.kp_rows.data_ptr(), keep=(plan.kp_idx, plan.kp_rows))
         return plan
 
-    def plan_for(self, B: int, H: int, W: int) -> _PosePlan:
+    def plan_for(self, B: int, H: int, W: int, replica: int = 0) -> _PosePlan:
+        """The plan (launch list + activation buffers + graph) of one input shape.  `replica` > 0 gives an independent copy
+        with its own buffers — same packed weights, same tile picks — for callers that keep several batches of one shape
+        in flight on different streams (tracking.PoseRunner per clip, tools/tracking/demo.run_clips)."""
         device, dtype = self._resolve()
-        key = (B, H, W, device, dtype, self.keypoints_in_plan)
+        key = (B, H, W, device, dtype, self.keypoints_in_plan) + ((replica,) if replica else ())
         plan = self._plans.get(key)
         if plan is None:
             with torch.no_grad():
@@ -338,12 +343,14 @@ class DeconvResnet(HipModule):
         """Key-point rows [B,K,3] with the arg-max of the fp32 parity mode at (mostly) fp16 speed — north_star's "keypoint
         argmax bit-exact vs CPU reference" for the fast mode (max_preds, lib/pose/utils/evaluation.py:11-20):
           1. the fp16 plan (heat maps + rows, as forward_keypoint_rows);
-          2. ft_heatmap_min_margin: per crop the smallest top-1 / top-2 margin over its K maps;
-          3. crops whose margin is below `exact_argmax_margin` go through the fp32 plan (buckets of 8 .. B crops), their rows
-             replace the fp16 ones.
-        A crop that is not re-run has margins above twice the fp16 error bound, so its arg-max cannot differ from fp32's
-        (its score and the +-0.25 px nudge come from the fp16 map).  Returns (rows [B,K,3] on the device — a buffer of this
-        call, not the plan's —, number of crops re-run).  One device -> host read of B floats per call sits between 2 and 3."""
+          2. ft_heatmap_argmax_screen: per crop a flag (see exact_argmax_rel_bound) and its statistics;
+          3. flagged crops go through the fp32 plan (buckets of 8 .. B crops), their rows replace the fp16 ones.
+        A crop that is not flagged has every top-1 / top-2 margin above twice the error bound and every maximum further than the
+        bound from 0, so neither its arg-max nor its coordinate mask can differ from fp32's (its score and the +-0.25 px nudge
+        come from the fp16 map).  What this costs depends on the heat maps: single-peak maps (a trained net) flag next to
+        nothing, noise-like maps (random weights) nearly every crop — then the mode runs at fp32 speed.  Returns (rows [B,K,3]
+        on the device — a buffer of this call, not the plan's —, number of crops re-run).  One device -> host read of B flags
+        per call sits between 2 and 3."""
         if self.keypoints_in_plan is None:
             raise FlowtrackHipError("set model.keypoints_in_plan = True / False (adjust_coords) before forward_keypoint_rows_exact()")
         want = self.compute_dtype
@@ -358,10 +365,13 @@ class DeconvResnet(HipModule):
             rows = self.forward_keypoint_rows(x).clone()
             plan = self._last_plan
             hm = plan.heatmaps
-            margin = torch.empty(B, dtype=torch.float32, device=x.device)
-            check(_lib.load().ft_heatmap_min_margin(hm.data_ptr(), B, hm.shape[1], hm.shape[2], hm.shape[3], margin.data_ptr(),
-                                                    current_stream_handle(x.device)), "ft_heatmap_min_margin")
-            todo = torch.nonzero(margin.cpu() < self.exact_argmax_margin).flatten()
+            flags = torch.empty(B, dtype=torch.int32, device=x.device)
+            stats = torch.empty((B, 4), dtype=torch.float32, device=x.device)
+            check(_lib.load().ft_heatmap_argmax_screen(hm.data_ptr(), B, hm.shape[1], hm.shape[2], hm.shape[3],
+                                                       ctypes.c_float(self.exact_argmax_rel_bound), flags.data_ptr(), stats.data_ptr(),
+                                                       current_stream_handle(x.device)), "ft_heatmap_argmax_screen")
+            self._last_screen_stats = stats
+            todo = torch.nonzero(flags.cpu()).flatten()
             n = int(todo.numel())
             if n:
                 self.compute_dtype = torch.float32

@@ -72,7 +72,7 @@ def pose_est(net, frame_dev: torch.Tensor, boxes: np.ndarray, inp_res=(256, 192)
     boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
     n = boxes.shape[0]
     if n == 0:
-        return np.zeros((0, 17, 3), dtype=np.float32)
+        return np.zeros((0, _num_joints(net), 3), dtype=np.float32)
     centers, scales = boxes_to_center_scale(boxes, inp_res)
     crops = crop_boxes(frame_dev, centers, scales, inp_res, normalize)
     out_c, out_s = [], []
@@ -89,6 +89,11 @@ def pose_est(net, frame_dev: torch.Tensor, boxes: np.ndarray, inp_res=(256, 192)
         out_c.append(c)
         out_s.append(s)
     return np.concatenate((np.concatenate(out_c), np.concatenate(out_s)), axis=2).astype(np.float32)
+
+
+def _num_joints(net) -> int:
+    """Key points per person of `net` (17 COCO / 16 MPII, tools/pose/main.py:22,57): the model API's num_classes."""
+    return int(getattr(net, "num_classes", 17))
 
 
 def heatmap_rows_to_image(rows: np.ndarray, centers: np.ndarray, scales: np.ndarray, hm_hw) -> np.ndarray:
@@ -111,14 +116,20 @@ class PoseRunner:
     kernel writes straight into the pose plan's input (zero-copy), the plan's graph ends in the key-point rows launch
     (arg-max + 0.25 px nudge on the device), the [bucket, K, 3] rows come back into a pinned buffer behind an event.
     `submit` returns at once; `result` waits for the event — whatever the host does in between overlaps the GPU.
-    One slot (parameter + row buffers) per bucket: call result() of a handle before the next submit of the same bucket size
-    (the tracking pass does: frame t + 1's boxes depend on frame t's rows).  The host side of a submit is on the critical
+    One slot (parameter + row buffers) per bucket: a submit that finds its bucket's slot still in flight (no result() yet)
+    first waits for that launch's event — the crop kernel reads the box parameters straight from the slot's pinned buffer and
+    the plan's input is shared, so rewriting either under a pending launch would corrupt it (the tracking pass never does:
+    frame t + 1's boxes depend on frame t's rows).  More boxes than the largest bucket are chunked.  The host side of a submit is on the critical
     path of that pass (the GPU idles while boxes are prepared), hence the numpy views of the pinned buffers and the single
     plan look-up per call (tools/dev/clip_profile.py: 0.21 -> ~0.1 ms per frame)."""
     BUCKETS = (4, 8, 16, 32, 64, 128, 256)
 
-    def __init__(self, net, inp_res=(256, 192), normalize=True):
+    def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None):
+        """replica / stream: a runner of its own plan copies (DeconvResnet.plan_for(..., replica)) whose launches go to
+        `stream` — several runners on one net then overlap on the GPU (one per clip, tools/tracking/demo.run_clips)."""
         self.net, self.inp_res = net, inp_res
+        self.replica, self.stream = int(replica), stream
+        self.K = _num_joints(net)
         self.dev = next(net.parameters()).device
         require_gpu(self.dev)
         self.lib = _lib.load()
@@ -137,9 +148,12 @@ class PoseRunner:
             # box parameters live in pinned host memory the crop kernel reads directly (host allocations are mapped into the
             # device's address space at the same address): no H2D copy op on the stream, no staging tensor
             ph = torch.zeros((bucket, 3), dtype=torch.float32).pin_memory()
-            rh = torch.zeros((bucket, 17, 3), dtype=torch.float32).pin_memory()
+            rh = torch.zeros((bucket, self.K, 3), dtype=torch.float32).pin_memory()
             sl = self.slots[bucket] = {"params_host": ph, "params_np": ph.numpy(), "rows_host": rh, "rows_np": rh.numpy(),
-                                       "event": torch.cuda.Event()}
+                                       "event": torch.cuda.Event(), "pending": False}
+        elif sl["pending"]:
+            sl["event"].synchronize()                      # slot-busy guard: the launch that reads this slot has not finished
+            sl["pending"] = False
         return sl
 
     def _fill_params(self, sl, centers, scales, n, bucket):
@@ -154,8 +168,12 @@ class PoseRunner:
         self.net.replay(plan)
         sl["rows_host"].copy_(plan.kp_rows, non_blocking=True)
         sl["event"].record()
+        sl["pending"] = True
 
     def submit(self, frame_dev: torch.Tensor, boxes: np.ndarray):
+        if self.stream is not None and torch.cuda.current_stream(self.dev) != self.stream:
+            with torch.cuda.stream(self.stream):
+                return self.submit(frame_dev, boxes)
         boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
         n = len(boxes)
         if n == 0:
@@ -163,13 +181,14 @@ class PoseRunner:
         if frame_dev.dtype != torch.uint8 or frame_dev.dim() != 3 or not frame_dev.is_contiguous():
             raise ValueError("frame must be a contiguous uint8 [H,W,C] device tensor")
         bucket = next((b for b in self.BUCKETS if b >= n), None)
-        if bucket is None:
-            raise ValueError(f"{n} boxes in one frame: more than the largest pose bucket ({self.BUCKETS[-1]})")
+        if bucket is None:                                  # more boxes than the largest plan: chunks, each waited for in turn
+            big = self.BUCKETS[-1]
+            return ("chunks", [self.result(self.submit(frame_dev, boxes[lo:lo + big])) for lo in range(0, n, big)])
         centers, scales = boxes_to_center_scale(boxes, self.inp_res)
         sl = self._slot(bucket)
         self._fill_params(sl, centers, scales, n, bucket)
         H, W, C = frame_dev.shape
-        plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1])
+        plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1], self.replica)
         check(self.lib.ft_crop_affine_fwd(frame_dev.data_ptr(), H, W, C, sl["params_host"].data_ptr(), bucket, self.inp_res[0],
                                           self.inp_res[1], self.mean.data_ptr() if self.mean is not None else None,
                                           self.inv_std.data_ptr() if self.inv_std is not None else None, self.pre,
@@ -181,18 +200,25 @@ class PoseRunner:
         """The boxes of SEVERAL frames in one network call (phase 2 of the clip pipeline: ~5 detector boxes per frame would
         otherwise pay one plan replay and one round trip per frame): one crop launch per frame, each writing its slice of the
         plan's input.  result() returns the rows of all boxes in order."""
+        if self.stream is not None and torch.cuda.current_stream(self.dev) != self.stream:
+            with torch.cuda.stream(self.stream):
+                return self.submit_frames(frames_dev, boxes_list)
         per = [np.asarray(b, dtype=np.float64).reshape(-1, 4) for b in boxes_list]
         total = sum(len(b) for b in per)
         if total == 0:
             return None
         bucket = next((b for b in self.BUCKETS if b >= total), None)
-        if bucket is None:
-            raise ValueError(f"{total} boxes in one call: more than the largest pose bucket ({self.BUCKETS[-1]})")
+        if bucket is None:                                  # split the frame list in halves until each fits a plan
+            if len(per) == 1:
+                return self.submit(frames_dev[0], per[0])
+            h = len(per) // 2
+            return ("chunks", [self.result(self.submit_frames(frames_dev[:h], per[:h])),
+                               self.result(self.submit_frames(frames_dev[h:], per[h:]))])
         allb = np.concatenate(per)
         centers, scales = boxes_to_center_scale(allb, self.inp_res)
         sl = self._slot(bucket)
         self._fill_params(sl, centers, scales, total, total)
-        plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1])
+        plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1], self.replica)
         x = plan.x_static
         if bucket > total:
             x[total:].zero_()
@@ -211,9 +237,12 @@ class PoseRunner:
 
     def result(self, handle) -> np.ndarray:
         if handle is None:
-            return np.zeros((0, 17, 3), dtype=np.float32)
+            return np.zeros((0, self.K, 3), dtype=np.float32)
+        if handle[0] == "chunks":
+            return np.concatenate(handle[1], axis=0)
         sl, n, centers, scales, hm_hw = handle
         sl["event"].synchronize()
+        sl["pending"] = False
         return heatmap_rows_to_image(sl["rows_np"][:n], centers, scales, hm_hw)
 
     def __call__(self, frame_dev: torch.Tensor, boxes: np.ndarray) -> np.ndarray:
@@ -228,7 +257,7 @@ def pose_est_frames(net, frames_dev, boxes_list, inp_res=(256, 192), normalize=T
     counts = [len(np.asarray(b).reshape(-1, 4)) for b in boxes_list]
     total = sum(counts)
     if total == 0:
-        return [np.zeros((0, 17, 3), dtype=np.float32) for _ in counts]
+        return [np.zeros((0, _num_joints(net), 3), dtype=np.float32) for _ in counts]
     crops, cs, ss = [], [], []
     for frame, boxes in zip(frames_dev, boxes_list):
         boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)

@@ -310,6 +310,14 @@ int ft_heatmap_keypoint_rows(const float* heatmaps, int N, int K, int H, int W,
  * ones a caller re-runs in fp32 (DeconvResnet.forward_keypoint_rows_exact).  heatmaps NCHW fp32 [N,K,H,W], min_margin fp32 [N]. */
 int ft_heatmap_min_margin(const float* heatmaps, int N, int K, int H, int W, float* min_margin, ft_stream_t stream);
 
+/* The same screen with a RELATIVE bound and the two cases the margin alone misses.  Per crop n: R = largest - smallest value
+ * over its K maps, E = rel_bound * R (the fp16 mode's heat-map error scales with the maps' range); flags[n] = 1 when some map
+ * has (top1 - top2) < 2 E (two values an error of E per element can reorder), or |top1| < E (max_preds zeroes the coordinates
+ * where score <= 0, lib/pose/utils/evaluation.py:17-19: that mask can flip), or any non-finite value (NaN compares false: the
+ * tests are written negated).  stats fp32 [N,4] = (smallest margin, R, smallest |top1|, E); flags int32 [N]; K <= 256. */
+int ft_heatmap_argmax_screen(const float* heatmaps, int N, int K, int H, int W, float rel_bound, int32_t* flags, float* stats,
+                             ft_stream_t stream);
+
 /* ---- F1: FlowNet2* input normalisation ------------------------------------
  * rgb_mean over (pair,H,W) per (b,colour) then (x - mean) / rgb_max
  * (lib/flownet/model/models.py:255-257).  inputs: fp32 [B,3,2,H,W].

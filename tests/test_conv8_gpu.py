@@ -21,8 +21,8 @@ WIDE8 = 3
 
 
 def hints8(hip_lib, d):
-    hints = (ctypes.c_int * 32)()
-    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+    hints = (ctypes.c_int * 64)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 64)
     assert n >= 0
     return [int(h) for h in hints[:n] if (int(h) >> 28) & 3 == WIDE8], [int(h) for h in hints[:n]]
 

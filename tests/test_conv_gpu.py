@@ -235,8 +235,8 @@ def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
     prog = make_program()
     layer.record(prog, xv, yv, residual=nchw_to_view(res, dtype, dev) if res is not None else None)
     d = prog.conv_records[0][3]
-    hints = (ctypes.c_int * 32)()
-    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+    hints = (ctypes.c_int * 64)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 64)
     assert n >= 2, f"{name}: only {n} tile variants offered"
     if "splitk" in name:
         assert any((int(v) >> 21) & 7 for v in hints[:n]), f"{name}: no split-K variant offered"
@@ -291,8 +291,8 @@ def test_fused_shortcut_conv_matches_oracle(hip_lib, case, dtype):
     prog = make_program()
     layer.record(prog, t2v, xv, yv)
     d = prog.conv_records[0][3]
-    hints = (ctypes.c_int * 32)()
-    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+    hints = (ctypes.c_int * 64)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 64)
     assert n >= 2
     # fp16: BatchNorm is folded into fp16 weights here (one more rounding than scale-after-accumulate)
     tol = 2e-4 if dtype == torch.float32 else 3e-2
@@ -381,8 +381,8 @@ def test_patch_kernels_are_deterministic_when_workgroups_are_recycled(hip_lib, c
     prog = make_program()
     layer.record(prog, xv, yv)
     d = prog.conv_records[0][3]
-    hints = (ctypes.c_int * 32)()
-    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 32)
+    hints = (ctypes.c_int * 64)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), hints, 64)
     halo = [int(h) for h in hints[:n] if (int(h) >> 30) & 1]
     assert halo, "no LDS-patch variant offered"
     d.tile_hint = next(int(h) for h in hints[:n] if not (int(h) >> 30) & 1)
@@ -462,3 +462,37 @@ def test_pack_input_rowpacked_layout(hip_lib, shape):
     want = torch.zeros_like(v.t)
     want[:, :, pad:pad + W, :C] = x.permute(0, 2, 3, 1).half()
     assert torch.equal(v.t, want)
+
+
+@pytest.mark.parametrize("act", [None, "relu", "leaky"])
+def test_epilogue_keeps_non_finite_values(hip_lib, act):
+    """conv_common.h: apply_act on NaN / +-inf: a NaN accumulator stays NaN through every activation (torch's
+    F.relu / F.leaky_relu do the same), +inf stays +inf, -inf follows torch except ReLU(-inf), which the two-instruction form
+    max(v, 0 * v) leaves at -inf (documented in the header) instead of 0."""
+    dev = torch.device("cuda:0")
+    N, C, H, W = 1, 32, 4, 8
+    w = torch.eye(C).reshape(C, C, 1, 1)
+    x = synth.normal(3, "nf.x", (N, C, H, W))
+    x[0, 1, 0, 0] = float("nan")
+    x[0, 2, 1, 1] = float("inf")
+    x[0, 3, 2, 2] = float("-inf")
+    layer = FusedConv(w, dtype=torch.float32, device=dev, act=act, slope=0.1, label="nonfinite")
+    xv = nchw_to_view(x, torch.float32, dev)
+    yv = ActView(torch.zeros((N, H, W, C), dtype=torch.float32, device=dev), C, 0)
+    prog = make_program()
+    layer.record(prog, xv, yv)
+    run_program(prog)
+    got = view_to_nchw(yv)
+    # an identity 1x1 conv: every output pixel whose 32 inputs are finite is act(x); the three poisoned PIXELS are non-finite in
+    # all channels of the GEMM row that touched them (0 * NaN = NaN, 0 * inf = NaN) — what torch's conv gives as well
+    want = _reference(x, w, None, None, 1, 0, False, act, None)
+    fin = torch.isfinite(want)
+    if act == "relu":
+        fin[0, 3, 2, 2] = False                     # the documented exception: ReLU(-inf) = -inf here, 0 in torch
+        assert got[0, 3, 2, 2] == float("-inf") and want[0, 3, 2, 2] == 0
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.allclose(got[fin], want[fin], atol=1e-6)
+    assert torch.isnan(got[0, 1, 0, 0]) and torch.isnan(got[0, 0, 0, 0])          # NaN in -> NaN out, under every activation
+    assert got[0, 2, 1, 1] == float("inf")
+    if act != "relu":
+        assert got[0, 3, 2, 2] == (float("-inf") if act is None else float("-inf") * 0.1)

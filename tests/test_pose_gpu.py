@@ -326,6 +326,48 @@ def test_min_margin_kernel_matches_topk(hip_lib):
     assert torch.equal(out, want) and out[2].item() == 0.0
 
 
+def test_argmax_screen_is_selective(hip_lib):
+    """ft_heatmap_argmax_screen on synthetic maps of the two regimes.  Single-peak maps (a Gaussian bump of sigma 2 px centred
+    on a pixel, amplitude ~1, plus noise of 1e-3: top-1 / top-2 margin ~0.1 of the range, what a trained pose net emits,
+    lib/pose/utils/evaluation.py:11-20 reads their arg-max): nothing is flagged.  The cases the screen exists for are each
+    flagged: a near-tie (margin < 2 E), a maximum within E of zero (the `score > 0` mask), a NaN, an Inf.  Noise-like maps:
+    (nearly) all flagged.  The statistics row is (smallest margin, range, smallest |top-1|, E)."""
+    import ctypes
+    from flowtrack.pytorch_amd.hip_ops import current_stream_handle
+    N, K, H, W = 40, 17, 64, 48
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    cy = (4 + (synth.uniform01(91, "cy", (N, K)) * (H - 8))).astype(np.int64)
+    cx = (4 + (synth.uniform01(91, "cx", (N, K)) * (W - 8))).astype(np.int64)
+    amp = torch.from_numpy(0.7 + 0.3 * synth.uniform01(91, "amp", (N, K)).astype(np.float32))
+    hm = amp[..., None, None] * torch.exp(-((yy - torch.from_numpy(cy)[..., None, None]) ** 2 + (xx - torch.from_numpy(cx)[..., None, None]) ** 2) / 8.0)
+    hm = (hm + 1e-3 * synth.normal(91, "noise", (N, K, H, W))).contiguous()
+    rel = 1.6e-3
+    special = {3: "tie", 7: "zero", 11: "nan", 13: "inf"}
+    hm[3, 2, cy[3, 2], cx[3, 2] + 1] = hm[3, 2, cy[3, 2], cx[3, 2]] - 1e-3         # a neighbour within 2 E of the peak
+    hm[7, 5] = hm[7, 5] - hm[7, 5].max() + 5e-4                                     # this map's maximum sits at +5e-4 < E
+    hm[11, 0, 1, 1] = float("nan")
+    hm[13, 16, 2, 2] = float("inf")
+    g = hm.cuda()
+    flags = torch.empty(N, dtype=torch.int32, device="cuda")
+    stats = torch.empty((N, 4), dtype=torch.float32, device="cuda")
+    assert hip_lib.ft_heatmap_argmax_screen(g.data_ptr(), N, K, H, W, ctypes.c_float(rel), flags.data_ptr(), stats.data_ptr(),
+                                            current_stream_handle()) == 0
+    f, st = flags.cpu().numpy(), stats.cpu().numpy()
+    assert sorted(np.nonzero(f)[0].tolist()) == sorted(special), f"flagged {np.nonzero(f)[0].tolist()}"
+    clean = [n for n in range(N) if n not in special]
+    top2 = hm[clean].flatten(2).topk(2, dim=2).values
+    assert np.allclose(st[clean, 0], (top2[..., 0] - top2[..., 1]).min(dim=1).values.numpy(), rtol=0, atol=1e-6)
+    rng = hm[clean].flatten(1).max(dim=1).values - hm[clean].flatten(1).min(dim=1).values
+    assert np.allclose(st[clean, 1], rng.numpy(), atol=1e-6) and np.allclose(st[clean, 3], rel * rng.numpy(), atol=1e-7)
+    assert (st[clean, 0] > 20 * st[clean, 3]).all(), "single-peak maps: margins are an order of magnitude above the bound"
+    noise = synth.normal(92, "noise.hm", (N, K, H, W)).cuda().contiguous()
+    assert hip_lib.ft_heatmap_argmax_screen(noise.data_ptr(), N, K, H, W, ctypes.c_float(rel), flags.data_ptr(), stats.data_ptr(),
+                                            current_stream_handle()) == 0
+    assert flags.float().mean().item() >= 0.5, "noise-like maps: the smallest of 17 top-1 / top-2 gaps is inside the bound for most crops"
+    assert hip_lib.ft_heatmap_argmax_screen(noise.data_ptr(), N, 257, 8, 6, ctypes.c_float(rel), flags.data_ptr(), stats.data_ptr(),
+                                            current_stream_handle()) != 0       # K > 256: unsupported, said so
+
+
 def test_fp16_exact_argmax_mode_has_the_fp32_argmax(hip_lib):
     """DeconvResnet.forward_keypoint_rows_exact: fp16 pass, margin screen, fp32 re-run of the screened crops — every key point's
     arg-max pixel equals the fp32 parity mode's (which equals the CPU reference's: test_pose_fp32_matches_reference_golden) on
@@ -347,5 +389,5 @@ def test_fp16_exact_argmax_mode_has_the_fp32_argmax(hip_lib):
         reran += n
         untouched = (rows == plain).flatten(1).all(dim=1)
         assert int((~untouched).sum()) <= n
-    assert 0 < reran < 192, f"{reran} of 192 crops re-run"
+    assert 0 < reran <= 192, f"{reran} of 192 crops re-run"       # noise-like maps (random weights): nearly all of them
     print("fp16 arg-max flips without the screen:", flips16, "of", 192 * 17, "- crops re-run:", reran)

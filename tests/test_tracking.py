@@ -358,3 +358,100 @@ def test_pose_runner_matches_pose_est(hip_lib):
     assert np.abs(got3[..., :2] - want3[..., :2]).max() <= 1e-3 and np.array_equal(got3[..., 2], want3[..., 2])
     both = runner.result(runner.submit_frames([frame, frame], [boxes[:2], boxes[2:]]))
     assert np.array_equal(both, got)
+
+
+def test_interleaved_passes_equal_the_passes_run_alone():
+    """run_clips' scheduler on the CPU: three clips' tracking_pass_steps() generators advanced round-robin (one frame of each
+    in turn) give, per clip, exactly what tracking_pass() gives alone — the passes share nothing but the host thread.  The
+    asynchronous runner is a stand-in whose result() checks that every submit is collected exactly once, in order."""
+    from tools.tracking import demo
+
+    class _Runner:
+        def __init__(self, gt):
+            self.gt, self.pending = gt, []
+        def submit(self, t, boxes):
+            self.pending.append(t)
+            return (t, np.array(boxes, dtype=np.float64))
+        def result(self, h):
+            assert self.pending.pop(0) == h[0]
+            return _gt_pose(self.gt[h[0]], h[1])
+
+    clips = []
+    for c in range(3):
+        T = 12 + 3 * c                                       # ragged lengths: a finished clip drops out of the rotation
+        gt, dets, flows = _separated_people(T)
+        dets = [d.copy() for d in dets]
+        for d in dets:
+            d[:, :4] += c                                    # three different clips
+        kp_det = [_gt_pose(gt[t], dets[t][:, :4]) for t in range(T)]
+        clips.append((gt, dets, kp_det, flows))
+    alone = [demo.tracking_pass(d, k, f, _Runner(g)) for g, d, k, f in clips]
+    gens = [demo.tracking_pass_steps(d, k, f, _Runner(g)) for g, d, k, f in clips]
+    got, live = [None] * 3, [0, 1, 2]
+    while live:
+        for i in list(live):
+            try:
+                next(gens[i])
+            except StopIteration as done:
+                got[i] = done.value
+                live.remove(i)
+    for a, b in zip(alone, got):
+        assert len(a) == len(b)
+        for fa, fb in zip(a, b):
+            assert np.array_equal(fa["boxes"], fb["boxes"]) and np.array_equal(fa["keypoints"], fb["keypoints"]) and list(fa["ids"]) == list(fb["ids"])
+
+
+@pytest.mark.gpu
+def test_run_clips_interleaved_equals_each_clip_alone(hip_lib):
+    """configs[4] as throughput: K clips interleaved on one GPU (own plan replicas, pinned slots and stream per clip,
+    tools/tracking/demo.run_clips) produce, clip by clip, the boxes / key points / ids of run_clip on that clip alone
+    (tools/tracking/demo.py:35-42 is one clip, one frame at a time)."""
+    import types
+    from tools.tracking import demo
+    args = types.SimpleNamespace(pose_backbone=50, pose_model="", flow_net="FlowNet2S", flow_model="", fp16=True)
+    dev = torch.device("cuda", 0)
+    pose, flow = demo.build_nets(args, dev)
+    clips = [demo.synthetic_clip(24 + 4 * c, seed=c) for c in range(3)]
+    alone = [demo.run_clip(f, d, pose, flow, max_boxes="2x")[0] for f, d in clips]
+    for mode in (True, False):
+        outs, tm = demo.run_clips(clips, pose, flow, max_boxes="2x", interleave=mode)
+        assert set(tm) >= {"flow_s", "pose_s", "track_s"} and len(outs) == 3
+        for a, b in zip(alone, outs):
+            assert len(a) == len(b)
+            for fa, fb in zip(a, b):
+                assert np.array_equal(fa["boxes"], fb["boxes"]) and list(fa["ids"]) == list(fb["ids"])
+                # a replica's plan runs the same kernels with the same tile picks on the same crops: bit-identical rows
+                assert np.array_equal(fa["keypoints"], fb["keypoints"])
+
+
+@pytest.mark.gpu
+def test_pose_runner_mpii_16_joints_slot_guard_and_chunks(hip_lib):
+    """num_classes is the model API's (MPII = 16 joints, tools/pose/main.py:22,57): the runner's row buffers follow it.  A second
+    submit on a bucket whose slot is still in flight waits for that launch instead of rewriting its pinned box parameters;
+    more boxes than the largest bucket are chunked."""
+    from flowtrack.pytorch_amd.pose import models as pose_models
+    from flowtrack.pytorch_amd.tracking import PoseRunner, pose_est
+    dev = torch.device("cuda", 0)
+    net = pose_models.deconv("resnet50", num_classes=16, pretrained=False)
+    net.load_state_dict(synth.fill_pose_state_dict(net.state_dict(), 12))
+    net = net.to(dev).eval()
+    net.compute_dtype = torch.float16
+    frame = torch.from_numpy((synth.uniform01(6, "frame", (384, 512, 3)) * 255).astype(np.uint8)).to(dev)
+    boxes = np.array([[30, 40, 130, 300], [200, 10, 330, 380], [400, 100, 500, 250], [5, 5, 60, 90], [250, 200, 300, 260]], dtype=np.float64)
+    runner = PoseRunner(net)
+    got = runner(frame, boxes)
+    want = pose_est(net, frame, boxes, max_batch=8)
+    assert got.shape == want.shape == (5, 16, 3)
+    assert np.abs(got[..., :2] - want[..., :2]).max() <= 1e-3 and np.array_equal(got[..., 2], want[..., 2])
+    assert runner.result(None).shape == (0, 16, 3)
+    # slot guard: two submits of one bucket without a result() in between — the first launch's rows are what its boxes give
+    h1 = runner.submit(frame, boxes)
+    h2 = runner.submit(frame, boxes[::-1].copy())
+    second = runner.result(h2)
+    assert np.array_equal(second, got[::-1])
+    assert h1[0]["pending"] is False
+    # chunking above the largest bucket
+    runner.BUCKETS = (4, 8)
+    many = np.concatenate([boxes, boxes + 1.0, boxes + 2.0])[:11]
+    chunked = runner(frame, many)
+    assert chunked.shape == (11, 16, 3) and np.array_equal(chunked[:5], got)

@@ -67,7 +67,7 @@ def synthetic_clip(n_frames, H=384, W=512, n_people=5, seed=0):
 
 
 def build_nets(args, device):
-    pose = pose_models.deconv("resnet%d" % args.pose_backbone, num_classes=17, pretrained=False)
+    pose = pose_models.deconv("resnet%d" % args.pose_backbone, num_classes=getattr(args, "pose_classes", 17), pretrained=False)
     if args.pose_model:
         pose.load_state_dict(torch.load(args.pose_model, map_location="cpu")["state_dict"])
     else:
@@ -89,11 +89,14 @@ def _sync(dev):
         torch.cuda.synchronize(dev)
 
 
-def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
-    """The sequential part of the method (one frame after the other, rank 0): propagate the previous frame's poses by the
+def tracking_pass_steps(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
+    """GENERATOR form of tracking_pass(): yields once per frame, between the submit of the frame's propagated boxes (GPU work
+    enqueued) and the wait for their key points — the point where run_clips() switches to another clip, so that clip's host
+    work and its small-batch GPU latency overlap this clip's replay.  The final value (StopIteration.value) is the frame list.
+    The sequential part of the method (one frame after the other, rank 0): propagate the previous frame's poses by the
     flow, union with the detector boxes + box NMS (process_frame, tools/tracking/demo.py:35-42), pose of the propagated
     boxes that survive, flow-based greedy id assignment.
-    dets[t]: [n,5] detector boxes; kp_det[t]: [n,17,3] their key points; flows: [T-1,2,H,W] (host array or anything
+    dets[t]: [n,5] detector boxes; kp_det[t]: [n,K,3] their key points (K = the pose net's num_classes); flows: [T-1,2,H,W] (host array or anything
     indexable by t giving a [2,H,W] numpy field); pose_boxes: either a callable (t, boxes[m,4]) -> [m,17,3] for the
     propagated-only boxes, or an object with submit(t, boxes) -> handle and result(handle) -> [m,17,3] (the GPU runner:
     frame t's id assignment — host work that nothing downstream of the next propagation depends on — then runs while the GPU
@@ -106,6 +109,7 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
     from flowtrack.pytorch_amd.tracking.flow_utils import nms
     tracker = FlowTracker()
     is_async = hasattr(pose_boxes, "submit")
+    K = next((np.asarray(k).shape[1] for k in kp_det if len(k)), 17)     # key points per person: the pose net's num_classes
     out, prev_kp, prev_dets = [], None, None
     deferred = None                                        # (frame index, kps, boxes, flow) whose ids are still to be assigned
     def assign(item):
@@ -124,7 +128,7 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
             if max_boxes is not None:
                 keep = keep[:max(2 * n_det, 4) if max_boxes == "2x" else int(max_boxes)]
             cur, src = allb[keep], keep
-        kps = np.zeros((len(cur), 17, 3), dtype=np.float32)
+        kps = np.zeros((len(cur), K, 3), dtype=np.float32)
         from_det = src < n_det
         kps[from_det] = np.asarray(kp_det[t])[src[from_det]]
         handle = None
@@ -135,6 +139,7 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
                 kps[~from_det] = pose_boxes(t, cur[~from_det, :4])
         if deferred is not None:                           # the previous frame's ids: while the GPU works on this frame
             assign(deferred)
+        yield t                                            # a scheduler may run other clips' frames here
         if handle is not None:
             kps[~from_det] = pose_boxes.result(handle)
         out.append({"boxes": cur, "keypoints": kps, "ids": None})
@@ -145,21 +150,22 @@ def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
     return out
 
 
-def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow_batch=16, pose_frames=6, pose_fn=None,
-             flow_fn=None, device=None, max_boxes=None):
-    """Returns (per-frame dict list on rank 0 | None elsewhere, timing dict).
-    pose_fn(frame [H,W,3] uint8 tensor, boxes [n,4]) -> [n,17,3] and flow_fn(ims [b,3,2,Hp,Wp]) -> [b,2,Hp,Wp] default to
-    the HIP networks (pose_est / flow_net); the CPU tests inject stand-ins to check the sharding (device="cpu")."""
+def tracking_pass(dets, kp_det, flows, pose_boxes, thresh=0.3, max_boxes=None):
+    """The sequential pass of ONE clip (see tracking_pass_steps for the arguments): drives the generator to its end."""
+    steps = tracking_pass_steps(dets, kp_det, flows, pose_boxes, thresh, max_boxes)
+    while True:
+        try:
+            next(steps)
+        except StopIteration as done:
+            return done.value
+
+
+def _batched_phases(frames, dets, pose_net, flow_net, rank, world, flow_batch, pose_frames, pose_fn, flow_fn, dev, runner):
+    """Phases 1 and 2 of a clip (both batch-parallel, sharded over ranks): the flow of every (t-1, t) pair and the pose of
+    every detector box.  Returns (frames on the device, flows as a pinned host tensor on rank 0 | None, key points [T,nmax,K,3]
+    numpy, timing dict)."""
     T = len(frames)
-    dev = torch.device(device) if device is not None else next(pose_net.parameters()).device
     batched_pose = pose_fn is None
-    # the HIP pose net: one device round trip per call, asynchronous (PoseRunner); any other module that maps crops to heat maps
-    # (the tests' stand-ins): the generic pose_est / pose_est_frames path
-    runner = PoseRunner(pose_net) if (batched_pose and hasattr(pose_net, "forward_keypoint_rows")) else None
-    if pose_fn is None and runner is None:
-        pose_fn = lambda frame, boxes: pose_est(pose_net, frame, boxes, max_batch=8)     # noqa: E731
-    if flow_fn is None:
-        flow_fn = flow_net
     fr = torch.from_numpy(frames).to(dev)                                     # clip resident in HBM
     tm = {}
     # ---- phase 1: flows of pairs (t-1, t), sharded by pair index ---------------------------------------
@@ -183,7 +189,8 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     t0 = time.perf_counter()
     lo, hi = parallel.shard_range(T, rank, world)
     nmax = max(len(d) for d in dets)
-    kp_local = torch.zeros((hi - lo, nmax, 17, 3), dtype=torch.float32, device=dev)
+    K = int(getattr(pose_net, "num_classes", 17))          # 17 COCO / 16 MPII (tools/pose/main.py:22,57)
+    kp_local = torch.zeros((hi - lo, nmax, K, 3), dtype=torch.float32, device=dev)
     if batched_pose:       # the HIP networks: several frames' crops per network call
         for t0_ in range(lo, hi, pose_frames):
             ts = range(t0_, min(hi, t0_ + pose_frames))
@@ -202,21 +209,99 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     kp_all = parallel.all_gather_rows(kp_local, T).cpu().numpy()
     _sync(dev)
     tm["pose_s"] = time.perf_counter() - t0
+    return fr, flows_host, kp_all, tm
+
+
+def _frame_runner(runner, fr):
+    """The PoseRunner addressed by frame index (what tracking_pass_steps calls)."""
+    class _Frames:
+        submit = staticmethod(lambda t, boxes: runner.submit(fr[t], boxes))
+        result = staticmethod(runner.result)
+    return _Frames
+
+
+def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow_batch=16, pose_frames=6, pose_fn=None,
+             flow_fn=None, device=None, max_boxes=None):
+    """Returns (per-frame dict list on rank 0 | None elsewhere, timing dict).
+    pose_fn(frame [H,W,3] uint8 tensor, boxes [n,4]) -> [n,K,3] and flow_fn(ims [b,3,2,Hp,Wp]) -> [b,2,Hp,Wp] default to
+    the HIP networks (pose_est / flow_net); the CPU tests inject stand-ins to check the sharding (device="cpu")."""
+    T = len(frames)
+    dev = torch.device(device) if device is not None else next(pose_net.parameters()).device
+    # the HIP pose net: one device round trip per call, asynchronous (PoseRunner); any other module that maps crops to heat maps
+    # (the tests' stand-ins): the generic pose_est / pose_est_frames path
+    runner = PoseRunner(pose_net) if (pose_fn is None and hasattr(pose_net, "forward_keypoint_rows")) else None
+    batched = pose_fn is None
+    if pose_fn is None and runner is None:
+        pose_fn = lambda frame, boxes: pose_est(pose_net, frame, boxes, max_batch=8)     # noqa: E731
+    if flow_fn is None:
+        flow_fn = flow_net
+    fr, flows_host, kp_all, tm = _batched_phases(frames, dets, pose_net, flow_net, rank, world, flow_batch, pose_frames,
+                                                 None if batched else pose_fn, flow_fn, dev, runner)
     if rank != 0:
         return None, tm
     # ---- phase 3: sequential tracking pass ----------------------------------------------------------------
     t0 = time.perf_counter()
     flows_np = flows_host.numpy()
     if runner is not None:
-        class _Frames:                                      # the runner, addressed by frame index
-            submit = staticmethod(lambda t, boxes: runner.submit(fr[t], boxes))
-            result = staticmethod(runner.result)
-        pose_boxes = _Frames
+        pose_boxes = _frame_runner(runner, fr)
     else:
         pose_boxes = lambda t, boxes: pose_fn(fr[t], boxes)  # noqa: E731
     out = tracking_pass(dets, [kp_all[t, :len(dets[t])] for t in range(T)], flows_np, pose_boxes, thresh, max_boxes)
     tm["track_s"] = time.perf_counter() - t0
     return out, tm
+
+
+def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=6, max_boxes=None, interleave=True):
+    """K INDEPENDENT clips on one GPU as a throughput workload (BASELINE configs[4] scaled out by clip: one process per GPU
+    x K clips, no exchange between clips or ranks).  clips: [(frames uint8 [T,H,W,3], dets list), ...].
+    One clip's wall time is 3/4 sequential pass (frame t's propagated boxes need frame t-1's key points), and that pass is
+    bound by the LATENCY of a small-batch pose replay plus the host's matching, not by throughput.  Here the K passes are
+    interleaved frame by frame on one host thread: every clip has its own PoseRunner — own plan replicas (activation buffers
+    + graph), own pinned slots, own stream — and tracking_pass_steps() hands control back between a frame's submit and
+    its result, so while clip A's replay runs, clip B's NMS / id assignment / submit happen on the host and B's kernels
+    overlap A's on the GPU (a bucket-8 replay occupies a fraction of the CUs).  The reference's loop is one clip, one frame
+    at a time (tools/tracking/demo.py:35-42, lib/tracking/net_utils.py:36-92).
+    Returns (list of per-frame dict lists, one per clip, identical to run_clip's for that clip; timing dict with
+    flow_s / pose_s summed over clips and track_s of the interleaved pass)."""
+    dev = next(pose_net.parameters()).device
+    K = len(clips)
+    shared = PoseRunner(pose_net)                            # phase 2 (batched, throughput-bound): one runner for all clips
+    tm = {"flow_s": 0.0, "pose_s": 0.0}
+    prepared = []
+    for frames, dets in clips:
+        fr, flows_host, kp_all, t_ = _batched_phases(frames, dets, pose_net, flow_net, 0, 1, flow_batch, pose_frames, None,
+                                                     flow_net, dev, shared)
+        tm["flow_s"] += t_["flow_s"]
+        tm["pose_s"] += t_["pose_s"]
+        prepared.append((fr, flows_host.numpy(), [kp_all[t, :len(dets[t])] for t in range(len(frames))], dets))
+    t0 = time.perf_counter()
+    if interleave and K > 1:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        cur = torch.cuda.current_stream(dev)
+        for st in streams:
+            st.wait_stream(cur)
+        runners = [PoseRunner(pose_net, replica=i + 1, stream=streams[i]) for i in range(K)]
+    else:
+        runners = [shared] * K
+    gens = [tracking_pass_steps(dets, kps, flows_np, _frame_runner(runners[i], fr), thresh, max_boxes)
+            for i, (fr, flows_np, kps, dets) in enumerate(prepared)]
+    results = [None] * K
+    live = list(range(K))
+    if not (interleave and K > 1):                            # one after the other (the A/B baseline of the interleave)
+        for i in live:
+            results[i] = tracking_pass(prepared[i][3], prepared[i][2], prepared[i][1], _frame_runner(runners[i], prepared[i][0]),
+                                       thresh, max_boxes)
+        live = []
+    while live:
+        for i in list(live):
+            try:
+                next(gens[i])
+            except StopIteration as done:
+                results[i] = done.value
+                live.remove(i)
+    _sync(dev)
+    tm["track_s"] = time.perf_counter() - t0
+    return results, tm
 
 
 def main(argv=None):
@@ -229,6 +314,8 @@ def main(argv=None):
     ap.add_argument("--flow_model", type=str, default="", help="optical flow checkpoint (ckpt['state_dict'])")
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--clips", type=int, default=1, help="K independent clips interleaved on this GPU (throughput mode, run_clips)")
+    ap.add_argument("--pose_classes", type=int, default=17, help="key points per person: 17 (COCO) or 16 (MPII)")
     ap.add_argument("--max_boxes", type=str, default="auto",
                     help="boxes kept per frame after NMS: 'none' (the reference: every survivor), an integer, '2x' = twice the "
                          "detector boxes; 'auto' = 'none' with --pose_model, '2x' with the synthetic (untrained) weights")
@@ -240,6 +327,20 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     pose_net, flow_net = build_nets(args, device)
+    if args.clips > 1:
+        if world != 1:
+            raise SystemExit("--clips is the per-GPU throughput mode: run one process per GPU, each with its own clips")
+        clips = [synthetic_clip(args.frames, n_people=args.people, seed=c) for c in range(args.clips)]
+        run_clips(clips, pose_net, flow_net, max_boxes=max_boxes)                      # warm-up: plans / graphs of every replica
+        for mode in (False, True):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            outs, tm = run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, interleave=mode)
+            dt = time.perf_counter() - t0
+            print("clips: {} x {} frames, {}: {:.2f} s = {:.1f} frames/s total (flow {:.2f} s, detector-box pose {:.2f} s, "
+                  "tracking passes {:.2f} s)".format(args.clips, args.frames, "interleaved" if mode else "one after the other", dt,
+                                                     args.clips * args.frames / dt, tm["flow_s"], tm["pose_s"], tm["track_s"]))
+        return 0
     frames, dets = synthetic_clip(args.frames, n_people=args.people)
     run_clip(frames, dets, pose_net, flow_net, rank, world, max_boxes=max_boxes)          # warm-up: every plan / graph the timed run replays
     parallel.barrier()
