@@ -2480,7 +2480,11 @@ static bool halo_ok(const ft_conv_desc* d, const Geometry& g) {
   return d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0;
 }
 
-constexpr int kHintSkShift = 21;     // tile_hint bits 21-23: log2 of the cross-workgroup K split (needs a workspace)
+constexpr int kHintSkShift = 21;     // tile_hint bits 21-23: the cross-workgroup K split (needs a workspace): codes 0..3 = 1, 2, 4, 8
+                                     // slices (log2, as before); 4..7 = 3, 5, 6, 7 slices (8-phase kernel only: 48 tiles x 5 = 240
+                                     // workgroups fill 256 CUs where x 4 leaves a quarter of them idle)
+__host__ __device__ constexpr int hint_sk(int code) { return code < 4 ? 1 << code : (code == 4 ? 3 : code + 0); }   // 5, 6, 7 are themselves
+constexpr int sk_code(int sk) { return sk == 1 ? 0 : sk == 2 ? 1 : sk == 4 ? 2 : sk == 8 ? 3 : sk == 3 ? 4 : sk; }
 
 constexpr int kWide8 = 3;           // tile_hint bits 28-29 == 3: the 256 x 256 tile on the 8-phase schedule (conv_igemm8.hip)
 
@@ -2502,7 +2506,7 @@ static bool tile_valid(const ft_conv_desc* d, const Geometry& g, int bp, int bc,
     if (!igemm8_ok(d, g) || bp != 256 || bc != 256 || ks != 1 || halo) return false;
     if (sk != 1) {     // every K slice = ceil(K-tiles / sk) but the last, which must still hold two K-tiles (the kernel's tile hand-over)
       const int nk8 = g.nk / 2, per = (nk8 + sk - 1) / sk;
-      if (!(sk == 2 || sk == 4 || sk == 8) || d->tail_cout > 0 || per < 4 || nk8 - (sk - 1) * per < 2) return false;
+      if (sk < 2 || sk > 8 || d->tail_cout > 0 || per < 4 || nk8 - (sk - 1) * per < 2) return false;
     }
     return true;
   }
@@ -2573,6 +2577,13 @@ extern "C" int ft_conv_tile_candidates(const ft_conv_desc* d, int* hints, int ma
     for (int lg = 1; lg <= 3; ++lg)
       if (n < max && nblk8 <= 160 && (nblk8 << lg) <= 640 && tile_valid(d, g, 256, 256, 1, kWide8, false, 1 << lg))
         hints[n++] = 256 | (256 << 12) | (1 << 24) | (kWide8 << kHintWideShift) | (lg << kHintSkShift);
+    // odd splits where they bring the workgroup count closer to one round of 256 CUs than the neighbouring powers of two
+    // (deconv.0 of the pose head at batch 64: 48 tiles x 5 slices = 240 workgroups; x 4 = 192, x 8 = 384)
+    for (int sk = 3; sk <= 7; ++sk) {
+      if (sk == 4) continue;
+      if (n < max && nblk8 <= 160 && nblk8 * sk > 160 && nblk8 * sk <= 272 && tile_valid(d, g, 256, 256, 1, kWide8, false, sk))
+        hints[n++] = 256 | (256 << 12) | (1 << 24) | (kWide8 << kHintWideShift) | (sk_code(sk) << kHintSkShift);
+    }
   }
   // cross-workgroup split-K where the layer has less than ~one workgroup per CU even on 64-wide tiles (long K, few
   // pixels: layer4 / FlowNet conv5..6 / every deep layer at small batch).  Needs ft_conv2d_fwd_ws.
@@ -2646,7 +2657,7 @@ extern "C" size_t ft_conv_workspace_bytes(const ft_conv_desc* d) {
   const int n = ft_conv_tile_candidates(d, hints, 64);
   int max_sk = 1;
   for (int i = 0; i < n; ++i) {
-    const int sk = 1 << ((hints[i] >> kHintSkShift) & 7);
+    const int sk = hint_sk((hints[i] >> kHintSkShift) & 7);
     if (sk > max_sk) max_sk = sk;
   }
   if (max_sk == 1) return 0;                 // no split-K variant is offered for this layer
@@ -2850,7 +2861,7 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
       const int hbp = hint & 0xfff, hbc = (hint >> 12) & 0x1ff, hks = (hint >> 24) & 0xf;
       const int hwide = (hint >> kHintWideShift) & 3;
       const bool hhalo = (hint & kHintHalo) != 0;
-      const int hsk = 1 << ((hint >> kHintSkShift) & 7);
+      const int hsk = hint_sk((hint >> kHintSkShift) & 7);
       const int nbp = hbp ? hbp : bp, nbc = hbc ? hbc : bc, nks = hks ? hks : (hbp || hbc ? 1 : ks);
       if (tile_valid(d, g, nbp, nbc, nks, hwide, hhalo, hsk)) { bp = nbp; bc = nbc; ks = nks; wide = hwide; halo = hhalo; sk = hsk; }
     }

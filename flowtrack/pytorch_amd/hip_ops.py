@@ -559,7 +559,7 @@ class Program:
                 h = cands[k][best]
                 print(f"[tile benchmark] {self.conv_records[k][0]:28s} heuristic {times[k][0] * 1e3:7.1f} us  best {times[k][best] * 1e3:7.1f} us"
                       f"  -> bp {h & 0xfff} bc {(h >> 12) & 0x1ff} ks {(h >> 24) & 0xf} wide {(h >> 28) & 3}{' halo' if (h >> 30) & 1 else ''}"
-                      f"{' splitK x%d' % (1 << ((h >> 21) & 7)) if (h >> 21) & 7 else ''}", file=sys.stderr)
+                      f"{' splitK x%d' % ((1, 2, 4, 8, 3, 5, 6, 7)[(h >> 21) & 7]) if (h >> 21) & 7 else ''}", file=sys.stderr)
         _save_tile_cache()
         return changed
 

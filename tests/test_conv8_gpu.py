@@ -74,6 +74,10 @@ def test_igemm8_matches_oracle(hip_lib, case):
     assert mine, f"{name}: the 8-phase tile is not offered"
     if wants_sk:
         assert any((h >> 21) & 7 for h in mine), f"{name}: no split-K form of the 8-phase tile offered"
+        # the odd K splits (codes 4..7 = 3, 5, 6, 7 slices: offered only where they fill one round of CUs better than a power of
+        # two, e.g. deconv.0 at batch 64 = 48 tiles x 5) forced onto these small cases as well
+        base = next(h for h in mine if not (h >> 21) & 7)
+        mine = mine + [base | (code << 21) for code in (4, 5, 6, 7)]
     scale = max(1.0, want.abs().max().item())
     for h in mine:
         d.tile_hint = h
@@ -84,7 +88,7 @@ def test_igemm8_matches_oracle(hip_lib, case):
             outs.append(yv.t.clone())
         assert all(torch.equal(outs[0], o) for o in outs[1:]), f"{name} hint {h:#x}: runs differ"
         err = (view_to_nchw(yv) - want).abs().max().item()
-        assert err <= 2e-2 * scale, f"{name} hint {h:#x} (split-K x{1 << ((h >> 21) & 7)}): max abs err {err:.3e} (scale {scale:.2f})"
+        assert err <= 2e-2 * scale, f"{name} hint {h:#x} (split-K code {(h >> 21) & 7}): max abs err {err:.3e} (scale {scale:.2f})"
     if "coff" in name:
         assert torch.all(yv.t[..., :24] == 3.0) and torch.all(yv.t[..., 24 + Cout:] == 3.0), "wrote outside its channel slice"
 

@@ -248,7 +248,7 @@ def test_every_tile_variant_matches_oracle(hip_lib, case, dtype):
         torch.cuda.synchronize()      # the fill runs on torch's stream, the program on its own
         run_program(prog)
         err = (view_to_nchw(yv) - want).abs().max().item()
-        assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0x1ff} splitK {1 << ((h >> 21) & 7)} ks {(h >> 24) & 0xf} "
+        assert err <= tol * scale, (f"{name} {dtype} tile bp {h & 0xfff} bc {(h >> 12) & 0x1ff} splitK {(1, 2, 4, 8, 3, 5, 6, 7)[(h >> 21) & 7]} ks {(h >> 24) & 0xf} "
                                     f"wide {(h >> 28) & 3} halo {(h >> 30) & 1}: max abs err {err:.3e}")
     assert torch.all(yv.t[..., Cout:] == 3.0) or act_stride(Cout) == Cout
 

@@ -169,14 +169,14 @@ def test_pose_config_parse_warns_on_unknown():
 
 
 def _hints(hip_lib, d):
-    buf = (ctypes.c_int * 32)()
-    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), buf, 32)
+    buf = (ctypes.c_int * 64)()
+    n = hip_lib.ft_conv_tile_candidates(ctypes.byref(d), buf, 64)
     assert n >= 0
     return [int(v) for v in buf[:n]]
 
 
 def _decode(h):
-    return dict(bp=h & 0xfff, bc=(h >> 12) & 0x1ff, sk=1 << ((h >> 21) & 7), ks=(h >> 24) & 0xf, wide=(h >> 28) & 3, halo=(h >> 30) & 1)
+    return dict(bp=h & 0xfff, bc=(h >> 12) & 0x1ff, sk=(1, 2, 4, 8, 3, 5, 6, 7)[(h >> 21) & 7], ks=(h >> 24) & 0xf, wide=(h >> 28) & 3, halo=(h >> 30) & 1)
 
 
 def test_tile_candidates_and_fusion_descriptors(hip_lib):

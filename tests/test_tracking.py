@@ -415,7 +415,7 @@ def test_run_clips_interleaved_equals_each_clip_alone(hip_lib):
     alone = [demo.run_clip(f, d, pose, flow, max_boxes="2x")[0] for f, d in clips]
     for mode in (True, False):
         outs, tm = demo.run_clips(clips, pose, flow, max_boxes="2x", interleave=mode)
-        assert set(tm) >= {"flow_s", "pose_s", "track_s"} and len(outs) == 3
+        assert tm["pass_frames"] == sum(len(f) for f, _ in clips) and len(outs) == 3
         for a, b in zip(alone, outs):
             assert len(a) == len(b)
             for fa, fb in zip(a, b):

@@ -49,7 +49,7 @@ def fmt(h):
     if (h >> 30) & 1:
         s += " halo"
     if (h >> 21) & 7:
-        s += f" sk{1 << ((h >> 21) & 7)}"
+        s += f" sk{(1, 2, 4, 8, 3, 5, 6, 7)[(h >> 21) & 7]}"
     return s
 
 

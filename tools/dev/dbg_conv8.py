@@ -25,7 +25,7 @@ def main():
         outs = []
         for _ in range(6):
             y.t.fill_(7.0); torch.cuda.synchronize(); prog.run_eager(); prog.stream.synchronize(); outs.append(y.t.float().clone())
-        print(f"hint {h:#x} sk {1 << ((h >> 21) & 7)}: max |out - default tile| = {(outs[0] - ref).abs().max().item():.4f}")
+        print(f"hint {h:#x} sk {(1, 2, 4, 8, 3, 5, 6, 7)[(h >> 21) & 7]}: max |out - default tile| = {(outs[0] - ref).abs().max().item():.4f}")
         for r, o in enumerate(outs[1:], 1):
             diff = (o != outs[0])
             if diff.any():

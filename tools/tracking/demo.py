@@ -251,56 +251,102 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
     return out, tm
 
 
+def _clip_pipeline(frames, dets, pose_net, flow_net, batch_runner, pass_runner, flow_batch, pose_frames, thresh, max_boxes):
+    """One clip's whole pipeline as a GENERATOR for run_clips(): yields "batched" after every enqueued chunk of the two
+    batch-parallel phases (flow of 16 pairs / pose of 6 frames' detector boxes: GPU-heavy, little host work) and "pass" once per
+    frame of the sequential pass (host-heavy, small GPU launches).  Nothing in it waits for the device except where a result
+    is needed: the flows travel to a pinned host buffer behind an event, the key points come back through the runners' pinned
+    slots.  Returns the frame list (StopIteration.value)."""
+    dev = next(pose_net.parameters()).device
+    T = len(frames)
+    H, W = frames.shape[1:3]
+    fr = torch.from_numpy(frames).to(dev)                                      # clip resident in HBM
+    yield "batched"
+    flows_host = torch.empty((T - 1, 2, H, W), dtype=torch.float32, pin_memory=True)
+    for b0 in range(0, T - 1, flow_batch):
+        b1 = min(T - 1, b0 + flow_batch)
+        ims = torch.stack((fr[b0:b1].flip(-1).permute(0, 3, 1, 2).float(),                # BGR -> RGB (net_utils.py:83-87)
+                           fr[b0 + 1:b1 + 1].flip(-1).permute(0, 3, 1, 2).float()), dim=2)
+        flows_host[b0:b1].copy_(flow_net(net_utils.pad_pairs_to_64(ims))[:, :, :H, :W], non_blocking=True)
+        yield "batched"
+    flows_ready = torch.cuda.Event()
+    flows_ready.record()
+    kp_det = [None] * T
+    for t0_ in range(0, T, pose_frames):
+        ts = range(t0_, min(T, t0_ + pose_frames))
+        h = batch_runner.submit_frames([fr[t] for t in ts], [dets[t][:, :4] for t in ts])
+        yield "batched"
+        flat = batch_runner.result(h)
+        cuts = np.cumsum([0] + [len(dets[t]) for t in ts])
+        for i, t in enumerate(ts):
+            kp_det[t] = flat[cuts[i]:cuts[i + 1]]
+    flows_ready.synchronize()
+    if pass_runner.stream is not None:
+        pass_runner.stream.wait_stream(torch.cuda.current_stream(dev))        # the clip's frames were uploaded on this stream
+    steps = tracking_pass_steps(dets, kp_det, flows_host.numpy(), _frame_runner(pass_runner, fr), thresh, max_boxes)
+    while True:
+        try:
+            next(steps)
+        except StopIteration as done:
+            return done.value
+        yield "pass"
+
+
 def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=6, max_boxes=None, interleave=True):
     """K INDEPENDENT clips on one GPU as a throughput workload (BASELINE configs[4] scaled out by clip: one process per GPU
     x K clips, no exchange between clips or ranks).  clips: [(frames uint8 [T,H,W,3], dets list), ...].
     One clip's wall time is 3/4 sequential pass (frame t's propagated boxes need frame t-1's key points), and that pass is
-    bound by the LATENCY of a small-batch pose replay plus the host's matching, not by throughput.  Here the K passes are
-    interleaved frame by frame on one host thread: every clip has its own PoseRunner — own plan replicas (activation buffers
-    + graph), own pinned slots, own stream — and tracking_pass_steps() hands control back between a frame's submit and
-    its result, so while clip A's replay runs, clip B's NMS / id assignment / submit happen on the host and B's kernels
-    overlap A's on the GPU (a bucket-8 replay occupies a fraction of the CUs).  The reference's loop is one clip, one frame
-    at a time (tools/tracking/demo.py:35-42, lib/tracking/net_utils.py:36-92).
-    Returns (list of per-frame dict lists, one per clip, identical to run_clip's for that clip; timing dict with
-    flow_s / pose_s summed over clips and track_s of the interleaved pass)."""
+    bound by the LATENCY of a small-batch pose replay plus the host's matching, not by throughput.  Here every clip is a
+    generator (_clip_pipeline) and one host thread advances them round-robin:
+      * the sequential passes of all clips that have reached theirs are interleaved frame by frame — each clip has its own
+        PoseRunner (own plan replicas = activation buffers + graph, own pinned slots, own stream), tracking_pass_steps() hands
+        control back between a frame's submit and its result, so while clip A's replay runs, clip B's NMS / id assignment /
+        submit happen on the host and B's kernels overlap A's on the GPU (a bucket-8 replay occupies a fraction of the CUs);
+      * at most ONE clip at a time is in its batch-parallel phases (flow of all pairs, pose of the detector boxes: the shared
+        flow plan and the shared batch runner), started when its predecessor enters its pass — the GPU-heavy phases of the next
+        clip fill the GPU under the host-bound passes of the others.
+    The reference's loop is one clip, one frame at a time (tools/tracking/demo.py:35-42, lib/tracking/net_utils.py:36-92).
+    interleave=False runs the same clips one after the other through the same code (the A/B baseline).
+    Returns (list of per-frame dict lists, one per clip, identical to run_clip's for that clip; timing dict)."""
     dev = next(pose_net.parameters()).device
     K = len(clips)
-    shared = PoseRunner(pose_net)                            # phase 2 (batched, throughput-bound): one runner for all clips
-    tm = {"flow_s": 0.0, "pose_s": 0.0}
-    prepared = []
-    for frames, dets in clips:
-        fr, flows_host, kp_all, t_ = _batched_phases(frames, dets, pose_net, flow_net, 0, 1, flow_batch, pose_frames, None,
-                                                     flow_net, dev, shared)
-        tm["flow_s"] += t_["flow_s"]
-        tm["pose_s"] += t_["pose_s"]
-        prepared.append((fr, flows_host.numpy(), [kp_all[t, :len(dets[t])] for t in range(len(frames))], dets))
+    shared = PoseRunner(pose_net)
     t0 = time.perf_counter()
     if interleave and K > 1:
-        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
-        cur = torch.cuda.current_stream(dev)
-        for st in streams:
-            st.wait_stream(cur)
-        runners = [PoseRunner(pose_net, replica=i + 1, stream=streams[i]) for i in range(K)]
+        runners = [PoseRunner(pose_net, replica=i + 1, stream=torch.cuda.Stream(device=dev)) for i in range(K)]
     else:
         runners = [shared] * K
-    gens = [tracking_pass_steps(dets, kps, flows_np, _frame_runner(runners[i], fr), thresh, max_boxes)
-            for i, (fr, flows_np, kps, dets) in enumerate(prepared)]
+    gens = [_clip_pipeline(f, d, pose_net, flow_net, shared, runners[i], flow_batch, pose_frames, thresh, max_boxes)
+            for i, (f, d) in enumerate(clips)]
     results = [None] * K
-    live = list(range(K))
-    if not (interleave and K > 1):                            # one after the other (the A/B baseline of the interleave)
-        for i in live:
-            results[i] = tracking_pass(prepared[i][3], prepared[i][2], prepared[i][1], _frame_runner(runners[i], prepared[i][0]),
-                                       thresh, max_boxes)
-        live = []
-    while live:
-        for i in list(live):
-            try:
-                next(gens[i])
-            except StopIteration as done:
-                results[i] = done.value
-                live.remove(i)
+    tm = {"pass_frames": 0, "batched_chunks": 0}
+    if not (interleave and K > 1):
+        for i, g in enumerate(gens):
+            while True:
+                try:
+                    tm["pass_frames" if next(g) == "pass" else "batched_chunks"] += 1
+                except StopIteration as done:
+                    results[i] = done.value
+                    break
+    else:
+        active, started = [0], 1
+        while active:
+            for i in list(active):
+                try:
+                    stage = next(gens[i])
+                except StopIteration as done:
+                    results[i] = done.value
+                    active.remove(i)
+                    if not active and started < K:          # (a clip shorter than its successor's batched phases)
+                        active.append(started)
+                        started += 1
+                    continue
+                tm["pass_frames" if stage == "pass" else "batched_chunks"] += 1
+                if stage == "pass" and i == started - 1 and started < K:
+                    active.append(started)                   # the newest clip is in its pass: the next one may start its batched phases
+                    started += 1
     _sync(dev)
-    tm["track_s"] = time.perf_counter() - t0
+    tm["wall_s"] = time.perf_counter() - t0
     return results, tm
 
 
@@ -337,9 +383,8 @@ def main(argv=None):
             t0 = time.perf_counter()
             outs, tm = run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, interleave=mode)
             dt = time.perf_counter() - t0
-            print("clips: {} x {} frames, {}: {:.2f} s = {:.1f} frames/s total (flow {:.2f} s, detector-box pose {:.2f} s, "
-                  "tracking passes {:.2f} s)".format(args.clips, args.frames, "interleaved" if mode else "one after the other", dt,
-                                                     args.clips * args.frames / dt, tm["flow_s"], tm["pose_s"], tm["track_s"]))
+            print("clips: {} x {} frames, {}: {:.3f} s = {:.1f} frames/s total".format(
+                args.clips, args.frames, "interleaved" if mode else "one after the other", dt, args.clips * args.frames / dt))
         return 0
     frames, dets = synthetic_clip(args.frames, n_people=args.people)
     run_clip(frames, dets, pose_net, flow_net, rank, world, max_boxes=max_boxes)          # warm-up: every plan / graph the timed run replays
