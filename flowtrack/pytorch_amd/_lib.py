@@ -75,6 +75,7 @@ _PROTOTYPES = {
     "ft_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "ft_event_destroy": (c_int, [c_void_p]),
     "ft_stream_synchronize": (c_int, [c_void_p]),
+    "ft_memcpy_async": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "ft_conv_pack_geometry": (c_int, [POINTER(ConvDesc), POINTER(ConvGeometry)]),
     "ft_conv_tile_candidates": (c_int, [POINTER(ConvDesc), POINTER(c_int), c_int]),
     "ft_conv_workspace_bytes": (ctypes.c_size_t, [POINTER(ConvDesc)]),

@@ -116,6 +116,13 @@ extern "C" int ft_event_destroy(void* event) {
   return FT_OK;
 }
 
+extern "C" int ft_memcpy_async(void* dst, const void* src, size_t bytes, ft_stream_t stream) {
+  if (!dst || !src) return FT_ERR_INVALID_ARG;
+  if (bytes == 0) return FT_OK;
+  FT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, as_stream(stream)));
+  return FT_OK;
+}
+
 extern "C" int ft_stream_synchronize(ft_stream_t stream) {
   FT_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
   return FT_OK;

@@ -74,6 +74,10 @@ int ft_event_synchronize(void* event);
 int ft_event_elapsed_ms(void* start, void* stop, float* ms_out);
 int ft_event_destroy(void* event);
 int ft_stream_synchronize(ft_stream_t stream);
+/* hipMemcpyAsync(hipMemcpyDefault) on `stream`: a host loop that drives launches through this ABI (the per-frame pose runner of
+ * the tracking glue, lib/tracking/net_utils.py:36-71) brings its few kB of results back without a framework call in between;
+ * a pinned host buffer makes the copy asynchronous. */
+int ft_memcpy_async(void* dst, const void* src, size_t bytes, ft_stream_t stream);
 
 /* ---- P1-P7 / F1-F3: fused conv / transposed-conv (implicit GEMM on MFMA) ---
  *

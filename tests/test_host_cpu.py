@@ -222,7 +222,7 @@ def test_tile_candidates_and_fusion_descriptors(hip_lib):
     d0 = _desc(dtype=_lib.FT_F16, N=64, Hi=8, Wi=6, Cin=2048, x_cstride=2048, Cout=256, y_cstride=256, kh=4, kw=4, stride=2, pad=1,
                transposed=1, Ho=16, Wo=12)
     h8 = [h for h in map(_decode, _hints(hip_lib, d0)) if h["wide"] == 3]
-    assert sorted(h["sk"] for h in h8) == [1, 2, 4, 8] and all((h["bp"], h["bc"], h["ks"], h["halo"]) == (256, 256, 1, 0) for h in h8)
+    assert sorted(h["sk"] for h in h8) == [1, 2, 4, 5, 8] and all((h["bp"], h["bc"], h["ks"], h["halo"]) == (256, 256, 1, 0) for h in h8)
     for bad in (dict(Cin=96, x_cstride=96), dict(Cout=128, y_cstride=128), dict(dtype=_lib.FT_F32)):
         kw = dict(dtype=_lib.FT_F16, N=8, Hi=32, Wi=24, Ho=32, Wo=24, Cin=128, x_cstride=128, Cout=256, y_cstride=256)
         kw.update(bad)
