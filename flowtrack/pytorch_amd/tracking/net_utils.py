@@ -281,6 +281,51 @@ class PoseRunner:
         return self.result(self.submit(frame_dev, boxes))
 
 
+class GroupPoseRunner(PoseRunner):
+    """One PoseRunner shared by a GROUP of clips (tools/tracking/demo.run_clips): the members' per-frame submits of one round
+    are collected and go through ONE plan replay when the scheduler calls flush() — the crops of, say, four clips' propagated
+    boxes as one 16- or 32-crop batch instead of four 4- or 8-crop batches.  A small-batch replay is bound by its launch
+    latencies (47 launches of 10-18 us at 8 crops) and replays on different streams barely overlap on the GPU, so batching
+    across clips is what raises the GPU's throughput in the sequential passes; the flushed batch is exactly submit_frames()
+    of the collected (frame, boxes) pairs, and a member's result() hands back its own rows.
+    Protocol per round: member submits (any subset of the members, each at most once) -> flush() -> ... -> results.  A
+    result() of a round that was not flushed yet flushes it (a member alone behaves like a plain runner)."""
+
+    def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None):
+        super().__init__(net, inp_res, normalize, replica, stream)
+        self._pending = []                                 # [frame_dev, boxes [n,4]] of the round being collected
+        self._round = {"handle": None, "cuts": None}       # the collecting round; replaced at flush
+
+    def submit(self, frame_dev: torch.Tensor, boxes: np.ndarray):
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+        if len(boxes) == 0:
+            return None
+        self._pending.append((frame_dev, boxes))
+        return ("member", self._round, len(self._pending) - 1)
+
+    def flush(self) -> None:
+        """Launch everything collected since the last flush as one batch (nothing collected: nothing happens)."""
+        if not self._pending:
+            return
+        rnd, pend = self._round, self._pending
+        self._pending, self._round = [], {"handle": None, "cuts": None}
+        rnd["cuts"] = np.cumsum([0] + [len(b) for _, b in pend])
+        rnd["handle"] = PoseRunner.submit_frames(self, [f for f, _ in pend], [b for _, b in pend])
+        rnd["rows"] = None
+
+    def result(self, handle) -> np.ndarray:
+        if handle is None or handle[0] != "member":
+            return PoseRunner.result(self, handle)
+        _, rnd, i = handle
+        if rnd["handle"] is None:
+            if rnd is not self._round:
+                raise RuntimeError("GroupPoseRunner: result() of a round that was dropped")
+            self.flush()
+        if rnd["rows"] is None:
+            rnd["rows"] = PoseRunner.result(self, rnd["handle"])
+        return rnd["rows"][rnd["cuts"][i]:rnd["cuts"][i + 1]]
+
+
 def pose_est_frames(net, frames_dev, boxes_list, inp_res=(256, 192), normalize=True):
     """pose_est for the boxes of SEVERAL frames in one network call: crops of every frame (one ft_crop_affine_fwd launch
     per frame) are stacked into one batch, padded to the plan bucket, and leave through one final_preds.  Returns a list of

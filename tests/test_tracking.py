@@ -401,27 +401,112 @@ def test_interleaved_passes_equal_the_passes_run_alone():
             assert np.array_equal(fa["boxes"], fb["boxes"]) and np.array_equal(fa["keypoints"], fb["keypoints"]) and list(fa["ids"]) == list(fb["ids"])
 
 
+class _StubPoseNet(torch.nn.Module):
+    """Stands in for DeconvResnet behind PoseRunner (plan_for / replay / kp_rows / x_static): the key-point rows of a crop are
+    a fixed function of ONE pixel of that crop, so they do not depend on the batch the crop ran in — which makes "K clips
+    grouped and interleaved" comparable bit for bit with "each clip alone" (the real nets' plans differ in fp16 rounding
+    between batch sizes)."""
+    num_classes = 17
+
+    def __init__(self):
+        super().__init__()
+        self.anchor = torch.nn.Parameter(torch.zeros(1))
+        self._plans = {}
+        self.keypoints_in_plan = True
+        self.replays = 0
+        self.crops = 0
+
+    def forward_keypoint_rows(self, x):                    # (run_clip picks the PoseRunner path by this attribute)
+        raise NotImplementedError
+
+    def plan_for(self, B, H, W, replica=0):
+        import types
+        key = (B, H, W, replica)
+        if key not in self._plans:
+            dev = self.anchor.device
+            self._plans[key] = types.SimpleNamespace(
+                x_static=torch.zeros((B, 3, H, W), dtype=torch.float32, device=dev), kp_rows=torch.zeros((B, 17, 3), device=dev),
+                heatmaps=torch.empty((1, 17, H // 4, W // 4)), prog=types.SimpleNamespace(graph_exec=None), runs=0)
+        return self._plans[key]
+
+    def replay(self, plan):
+        k = torch.arange(17, device=plan.x_static.device, dtype=torch.float32)
+        v = plan.x_static[:, 0, 100, 80][:, None] + 0.5 * plan.x_static[:, 2, 160, 120][:, None]        # [B,1]: this crop's own pixels
+        plan.kp_rows[:, :, 0] = 24.0 + 14.0 * torch.sin(0.7 * k[None] + 3.0 * v)
+        plan.kp_rows[:, :, 1] = 32.0 + 22.0 * torch.cos(0.9 * k[None] + 2.0 * v)
+        plan.kp_rows[:, :, 2] = 0.9
+        plan.runs += 1
+        self.replays += 1
+        self.crops += plan.x_static.shape[0]
+        return plan
+
+
 @pytest.mark.gpu
-def test_run_clips_interleaved_equals_each_clip_alone(hip_lib):
-    """configs[4] as throughput: K clips interleaved on one GPU (own plan replicas, pinned slots and stream per clip,
-    tools/tracking/demo.run_clips) produce, clip by clip, the boxes / key points / ids of run_clip on that clip alone
-    (tools/tracking/demo.py:35-42 is one clip, one frame at a time)."""
-    import types
+def test_run_clips_grouped_equals_each_clip_alone(hip_lib):
+    """configs[4] as throughput: K clips on one GPU (tools/tracking/demo.run_clips: passes interleaved, each group's per-frame
+    crops in one plan replay, the next clip's batched phases underneath) give, clip by clip, the boxes / key points / ids of
+    run_clip on that clip alone (tools/tracking/demo.py:35-42 is one clip, one frame at a time).  The crop kernel, the pinned
+    slots, the streams and the offsets into the grouped batch are the real ones; the pose plan is a stand-in whose rows depend
+    on the crop only, so the comparison is exact.  Grouping shows in the replay count: fewer, larger batches."""
     from tools.tracking import demo
-    args = types.SimpleNamespace(pose_backbone=50, pose_model="", flow_net="FlowNet2S", flow_model="", fp16=True)
     dev = torch.device("cuda", 0)
-    pose, flow = demo.build_nets(args, dev)
-    clips = [demo.synthetic_clip(24 + 4 * c, seed=c) for c in range(3)]
-    alone = [demo.run_clip(f, d, pose, flow, max_boxes="2x")[0] for f, d in clips]
-    for mode in (True, False):
-        outs, tm = demo.run_clips(clips, pose, flow, max_boxes="2x", interleave=mode)
-        assert tm["pass_frames"] == sum(len(f) for f, _ in clips) and len(outs) == 3
+    pose = _StubPoseNet().to(dev).eval()
+    flow = lambda ims: torch.full((ims.shape[0], 2, ims.shape[3], ims.shape[4]), 0.75, device=ims.device)   # noqa: E731
+    clips = [demo.synthetic_clip(20 + 5 * c, seed=c) for c in range(5)]
+    alone = [demo.run_clip(f, d, pose, None, flow_fn=flow, max_boxes="2x")[0] for f, d in clips]
+    replays_alone = pose.replays
+    for mode, groups in ((True, 2), (True, 1), (True, 5), (False, 2)):
+        pose.replays = 0
+        outs, tm = demo.run_clips(clips, pose, flow, max_boxes="2x", interleave=mode, groups=groups)
+        assert tm["pass_frames"] == sum(len(f) for f, _ in clips) and len(outs) == 5
         for a, b in zip(alone, outs):
             assert len(a) == len(b)
             for fa, fb in zip(a, b):
                 assert np.array_equal(fa["boxes"], fb["boxes"]) and list(fa["ids"]) == list(fb["ids"])
-                # a replica's plan runs the same kernels with the same tile picks on the same crops: bit-identical rows
                 assert np.array_equal(fa["keypoints"], fb["keypoints"])
+        if mode and groups < 5:
+            assert pose.replays < 0.8 * replays_alone, (pose.replays, replays_alone)
+
+
+@pytest.mark.gpu
+def test_group_runner_is_submit_frames_of_the_round_and_clips_are_deterministic(hip_lib):
+    """GroupPoseRunner with the real ResNet-50 (fp16): the members' submits of a round, flushed, are bit for bit
+    PoseRunner.submit_frames of the same (frame, boxes) list — same bucket, same plan arithmetic — and each member gets its own
+    rows; a member alone (result without flush) behaves like a plain runner.  Then run_clips on the real nets: finite, inside
+    the frame, ids unique per frame, and two runs identical."""
+    import types
+    from flowtrack.pytorch_amd.tracking import GroupPoseRunner, PoseRunner
+    from tools.tracking import demo
+    args = types.SimpleNamespace(pose_backbone=50, pose_model="", flow_net="FlowNet2S", flow_model="", fp16=True)
+    dev = torch.device("cuda", 0)
+    pose, flow = demo.build_nets(args, dev)
+    frames = [torch.from_numpy((synth.uniform01(20 + i, "frame", (384, 512, 3)) * 255).astype(np.uint8)).to(dev) for i in range(3)]
+    boxes = [np.array([[30, 40, 130, 300], [200, 10, 330, 380]], dtype=np.float64),
+             np.array([[400, 100, 500, 250], [5, 5, 60, 90], [250, 200, 300, 260]], dtype=np.float64),
+             np.array([[100, 50, 180, 330], [300, 120, 380, 360], [20, 200, 90, 370], [420, 20, 500, 200]], dtype=np.float64)]
+    grp = GroupPoseRunner(pose, replica=1, stream=torch.cuda.Stream(device=dev))
+    hs = [grp.submit(f, b) for f, b in zip(frames, boxes)]
+    assert grp.submit(frames[0], np.zeros((0, 4))) is None
+    grp.flush()
+    got = [grp.result(h) for h in hs]
+    ref = PoseRunner(pose)
+    assert ref.result(None).shape == (0, 17, 3)
+    flat = ref.result(ref.submit_frames(frames, boxes))
+    cuts = np.cumsum([0] + [len(b) for b in boxes])
+    for i, g in enumerate(got):
+        assert g.shape == (len(boxes[i]), 17, 3) and np.array_equal(g, flat[cuts[i]:cuts[i + 1]])
+    solo = grp.result(grp.submit(frames[1], boxes[1]))                          # no flush: result() flushes the round
+    assert np.array_equal(solo, ref(frames[1], boxes[1]))
+    clips = [demo.synthetic_clip(16 + 4 * c, seed=c) for c in range(4)]
+    runs = [demo.run_clips(clips, pose, flow, max_boxes="2x")[0] for _ in range(2)]
+    for out, (f, d) in zip(runs[0], clips):
+        assert len(out) == len(f)
+        for fr_, dt in zip(out, d):
+            assert 1 <= len(fr_["boxes"]) <= max(2 * len(dt), 4) and np.isfinite(fr_["boxes"]).all() and np.isfinite(fr_["keypoints"]).all()
+            assert len(set(fr_["ids"])) == len(fr_["ids"]) == len(fr_["boxes"])
+    for ra, rb in zip(*runs):
+        for a, b in zip(ra, rb):
+            assert np.array_equal(a["boxes"], b["boxes"]) and np.array_equal(a["keypoints"], b["keypoints"]) and list(a["ids"]) == list(b["ids"])
 
 
 @pytest.mark.gpu

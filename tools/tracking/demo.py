@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 from flowtrack.pytorch_amd import parallel, synth                                  # noqa: E402
 from flowtrack.pytorch_amd.flownet import models as flow_models                     # noqa: E402
 from flowtrack.pytorch_amd.pose import models as pose_models                        # noqa: E402
-from flowtrack.pytorch_amd.tracking import FlowTracker, PoseRunner, box_propagation, detect, flow_est, net_utils, pose_est, pose_est_frames  # noqa: E402
+from flowtrack.pytorch_amd.tracking import FlowTracker, GroupPoseRunner, PoseRunner, box_propagation, detect, flow_est, net_utils, pose_est, pose_est_frames  # noqa: E402
 
 
 def synthetic_clip(n_frames, H=384, W=512, n_people=5, seed=0):
@@ -292,35 +292,38 @@ def _clip_pipeline(frames, dets, pose_net, flow_net, batch_runner, pass_runner, 
         yield "pass"
 
 
-def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=6, max_boxes=None, interleave=True):
+def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=6, max_boxes=None, interleave=True, groups=2):
     """K INDEPENDENT clips on one GPU as a throughput workload (BASELINE configs[4] scaled out by clip: one process per GPU
     x K clips, no exchange between clips or ranks).  clips: [(frames uint8 [T,H,W,3], dets list), ...].
     One clip's wall time is 3/4 sequential pass (frame t's propagated boxes need frame t-1's key points), and that pass is
     bound by the LATENCY of a small-batch pose replay plus the host's matching, not by throughput.  Here every clip is a
     generator (_clip_pipeline) and one host thread advances them round-robin:
-      * the sequential passes of all clips that have reached theirs are interleaved frame by frame — each clip has its own
-        PoseRunner (own plan replicas = activation buffers + graph, own pinned slots, own stream), tracking_pass_steps() hands
-        control back between a frame's submit and its result, so while clip A's replay runs, clip B's NMS / id assignment /
-        submit happen on the host and B's kernels overlap A's on the GPU (a bucket-8 replay occupies a fraction of the CUs);
+      * the clips are split into `groups` groups; the sequential passes of a group's clips advance in lock-step, one frame of
+        each per round, and their propagated boxes of that round go through ONE plan replay (GroupPoseRunner: own plan
+        replicas, pinned slots and stream per group) — a 16- or 32-crop batch instead of four 4- or 8-crop ones (a small-batch
+        replay is 47 launches of 10-18 us whatever it holds, and replays on different streams barely overlap on the GPU);
+      * while one group's batch runs, the host does the other group's NMS / id assignment / submits: tracking_pass_steps()
+        hands control back between a frame's submit and its result;
       * at most ONE clip at a time is in its batch-parallel phases (flow of all pairs, pose of the detector boxes: the shared
         flow plan and the shared batch runner), started when its predecessor enters its pass — the GPU-heavy phases of the next
         clip fill the GPU under the host-bound passes of the others.
     The reference's loop is one clip, one frame at a time (tools/tracking/demo.py:35-42, lib/tracking/net_utils.py:36-92).
-    interleave=False runs the same clips one after the other through the same code (the A/B baseline).
-    Returns (list of per-frame dict lists, one per clip, identical to run_clip's for that clip; timing dict)."""
+    interleave=False runs the same clips one after the other through the same code (the A/B baseline).  A clip's result is
+    what run_clip gives for it up to the arithmetic of the plan its crops ran in (a 16-crop plan may use other tile variants
+    than an 8-crop one: fp16 rounding differences, as between any two batch sizes).
+    Returns (list of per-frame dict lists, one per clip; timing dict)."""
     dev = next(pose_net.parameters()).device
     K = len(clips)
     shared = PoseRunner(pose_net)
     t0 = time.perf_counter()
-    if interleave and K > 1:
-        runners = [PoseRunner(pose_net, replica=i + 1, stream=torch.cuda.Stream(device=dev)) for i in range(K)]
-    else:
-        runners = [shared] * K
+    G = max(1, min(groups, K)) if (interleave and K > 1) else 0
+    group_runners = [GroupPoseRunner(pose_net, replica=g + 1, stream=torch.cuda.Stream(device=dev)) for g in range(G)]
+    runners = [group_runners[i % G] for i in range(K)] if G else [shared] * K
     gens = [_clip_pipeline(f, d, pose_net, flow_net, shared, runners[i], flow_batch, pose_frames, thresh, max_boxes)
             for i, (f, d) in enumerate(clips)]
     results = [None] * K
     tm = {"pass_frames": 0, "batched_chunks": 0}
-    if not (interleave and K > 1):
+    if not G:
         for i, g in enumerate(gens):
             while True:
                 try:
@@ -331,20 +334,22 @@ def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=
     else:
         active, started = [0], 1
         while active:
-            for i in list(active):
-                try:
-                    stage = next(gens[i])
-                except StopIteration as done:
-                    results[i] = done.value
-                    active.remove(i)
-                    if not active and started < K:          # (a clip shorter than its successor's batched phases)
-                        active.append(started)
+            for g in range(G):
+                for i in [i for i in active if i % G == g]:
+                    try:
+                        stage = next(gens[i])
+                    except StopIteration as done:
+                        results[i] = done.value
+                        active.remove(i)
+                        if not active and started < K:      # (a clip shorter than its successor's batched phases)
+                            active.append(started)
+                            started += 1
+                        continue
+                    tm["pass_frames" if stage == "pass" else "batched_chunks"] += 1
+                    if stage == "pass" and i == started - 1 and started < K:
+                        active.append(started)               # the newest clip is in its pass: the next one may start its batched phases
                         started += 1
-                    continue
-                tm["pass_frames" if stage == "pass" else "batched_chunks"] += 1
-                if stage == "pass" and i == started - 1 and started < K:
-                    active.append(started)                   # the newest clip is in its pass: the next one may start its batched phases
-                    started += 1
+                group_runners[g].flush()                     # this group's submits of the round: one plan replay
     _sync(dev)
     tm["wall_s"] = time.perf_counter() - t0
     return results, tm
@@ -361,6 +366,7 @@ def main(argv=None):
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--save", type=str, default="")
     ap.add_argument("--clips", type=int, default=1, help="K independent clips interleaved on this GPU (throughput mode, run_clips)")
+    ap.add_argument("--groups", type=int, default=2, help="clip groups of run_clips (each group's per-frame crops share one plan replay)")
     ap.add_argument("--pose_classes", type=int, default=17, help="key points per person: 17 (COCO) or 16 (MPII)")
     ap.add_argument("--max_boxes", type=str, default="auto",
                     help="boxes kept per frame after NMS: 'none' (the reference: every survivor), an integer, '2x' = twice the "
@@ -377,11 +383,11 @@ def main(argv=None):
         if world != 1:
             raise SystemExit("--clips is the per-GPU throughput mode: run one process per GPU, each with its own clips")
         clips = [synthetic_clip(args.frames, n_people=args.people, seed=c) for c in range(args.clips)]
-        run_clips(clips, pose_net, flow_net, max_boxes=max_boxes)                      # warm-up: plans / graphs of every replica
+        run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, groups=args.groups)  # warm-up: plans / graphs of every replica
         for mode in (False, True):
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            outs, tm = run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, interleave=mode)
+            outs, tm = run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, interleave=mode, groups=args.groups)
             dt = time.perf_counter() - t0
             print("clips: {} x {} frames, {}: {:.3f} s = {:.1f} frames/s total".format(
                 args.clips, args.frames, "interleaved" if mode else "one after the other", dt, args.clips * args.frames / dt))
