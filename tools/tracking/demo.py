@@ -292,7 +292,8 @@ def _clip_pipeline(frames, dets, pose_net, flow_net, batch_runner, pass_runner, 
         yield "pass"
 
 
-def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=6, max_boxes=None, interleave=True, groups=2):
+def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=6, max_boxes=None, interleave=True, groups=2,
+              waves=1):
     """K INDEPENDENT clips on one GPU as a throughput workload (BASELINE configs[4] scaled out by clip: one process per GPU
     x K clips, no exchange between clips or ranks).  clips: [(frames uint8 [T,H,W,3], dets list), ...].
     One clip's wall time is 3/4 sequential pass (frame t's propagated boxes need frame t-1's key points), and that pass is
@@ -304,9 +305,10 @@ def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=
         replay is 47 launches of 10-18 us whatever it holds, and replays on different streams barely overlap on the GPU);
       * while one group's batch runs, the host does the other group's NMS / id assignment / submits: tracking_pass_steps()
         hands control back between a frame's submit and its result;
-      * at most ONE clip at a time is in its batch-parallel phases (flow of all pairs, pose of the detector boxes: the shared
-        flow plan and the shared batch runner), started when its predecessor enters its pass — the GPU-heavy phases of the next
-        clip fill the GPU under the host-bound passes of the others.
+      * the batch-parallel phases (flow of all pairs, pose of the detector boxes: the shared flow plan and batch runner,
+        GPU-bound) run one clip after the other ahead of the passes, so that every group is full from its first round; with
+        `waves` > 1 the clips go in waves and the next wave's batched phases advance one chunk per round under the current
+        wave's host-bound passes.
     The reference's loop is one clip, one frame at a time (tools/tracking/demo.py:35-42, lib/tracking/net_utils.py:36-92).
     interleave=False runs the same clips one after the other through the same code (the A/B baseline).  A clip's result is
     what run_clip gives for it up to the arithmetic of the plan its crops ran in (a 16-crop plan may use other tile variants
@@ -332,24 +334,50 @@ def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=
                     results[i] = done.value
                     break
     else:
-        active, started = [0], 1
-        while active:
+        # wave by wave: the batch-parallel phases of a wave's clips run one clip after the other (they share the flow plan and the
+        # batch runner, and are GPU-bound: nothing to interleave), then the wave's sequential passes advance in lock-step — all
+        # of a group's clips submit, the group flushes ONE replay, the next group's host work overlaps it.  The NEXT wave's batched
+        # phases advance by one chunk per round underneath (the host is the busy side of a pass round).
+        W = max(1, min(waves, K))
+        wave_of = [i * W // K for i in range(K)]
+        staged = {}                                          # clip -> True once its generator has yielded its first "pass"
+
+        def advance_batched(i):
+            """One chunk of clip i's batched phases; True when the clip has reached its pass (or ended)."""
+            try:
+                stage = next(gens[i])
+            except StopIteration as done:
+                results[i] = done.value
+                return True
+            tm["pass_frames" if stage == "pass" else "batched_chunks"] += 1
+            return stage == "pass"
+
+        for i in [i for i in range(K) if wave_of[i] == 0]:
+            while not advance_batched(i):
+                pass
+            staged[i] = True
+        for w in range(W):
+            active = [i for i in range(K) if wave_of[i] == w and results[i] is None]
+            nxt = [i for i in range(K) if wave_of[i] == w + 1]
+            while active:
+                for g in range(G):
+                    for i in [i for i in active if i % G == g]:
+                        try:
+                            next(gens[i])
+                        except StopIteration as done:
+                            results[i] = done.value
+                            active.remove(i)
+                            continue
+                        tm["pass_frames"] += 1
+                    group_runners[g].flush()                 # this group's submits of the round: one plan replay
+                if nxt and advance_batched(nxt[0]):          # the next wave's batched phases, one chunk per round
+                    staged[nxt.pop(0)] = True
+            for i in nxt:                                    # whatever of the next wave is not staged yet
+                while not advance_batched(i):
+                    pass
+                staged[i] = True
             for g in range(G):
-                for i in [i for i in active if i % G == g]:
-                    try:
-                        stage = next(gens[i])
-                    except StopIteration as done:
-                        results[i] = done.value
-                        active.remove(i)
-                        if not active and started < K:      # (a clip shorter than its successor's batched phases)
-                            active.append(started)
-                            started += 1
-                        continue
-                    tm["pass_frames" if stage == "pass" else "batched_chunks"] += 1
-                    if stage == "pass" and i == started - 1 and started < K:
-                        active.append(started)               # the newest clip is in its pass: the next one may start its batched phases
-                        started += 1
-                group_runners[g].flush()                     # this group's submits of the round: one plan replay
+                group_runners[g].flush()                     # (first-frame submits of the clips staged above)
     _sync(dev)
     tm["wall_s"] = time.perf_counter() - t0
     return results, tm
@@ -367,6 +395,7 @@ def main(argv=None):
     ap.add_argument("--save", type=str, default="")
     ap.add_argument("--clips", type=int, default=1, help="K independent clips interleaved on this GPU (throughput mode, run_clips)")
     ap.add_argument("--groups", type=int, default=2, help="clip groups of run_clips (each group's per-frame crops share one plan replay)")
+    ap.add_argument("--waves", type=int, default=1, help="waves of run_clips (the next wave's batched phases run under the current wave's passes)")
     ap.add_argument("--pose_classes", type=int, default=17, help="key points per person: 17 (COCO) or 16 (MPII)")
     ap.add_argument("--max_boxes", type=str, default="auto",
                     help="boxes kept per frame after NMS: 'none' (the reference: every survivor), an integer, '2x' = twice the "
@@ -383,11 +412,11 @@ def main(argv=None):
         if world != 1:
             raise SystemExit("--clips is the per-GPU throughput mode: run one process per GPU, each with its own clips")
         clips = [synthetic_clip(args.frames, n_people=args.people, seed=c) for c in range(args.clips)]
-        run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, groups=args.groups)  # warm-up: plans / graphs of every replica
+        run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, groups=args.groups, waves=args.waves)  # warm-up: plans / graphs of every replica
         for mode in (False, True):
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            outs, tm = run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, interleave=mode, groups=args.groups)
+            outs, tm = run_clips(clips, pose_net, flow_net, max_boxes=max_boxes, interleave=mode, groups=args.groups, waves=args.waves)
             dt = time.perf_counter() - t0
             print("clips: {} x {} frames, {}: {:.3f} s = {:.1f} frames/s total".format(
                 args.clips, args.frames, "interleaved" if mode else "one after the other", dt, args.clips * args.frames / dt))
