@@ -422,7 +422,8 @@ struct C3Params {
   const char* ws;
   const float* scale;
   const float* shift;
-  int M, HW, W, H, ipw;        // pixels, map size, images per workgroup
+  int M, HW, W, H, ipw;        // pixels, map size, images per workgroup (stride-2 form: the INPUT map; M = output pixels)
+  int Ho, Wo;                  // stride-2 form: output map (0 in the stride-1 form)
   int x_cstride, x_coff, y_cstride, y_coff;
   int Cout, act;
   float slope;
@@ -663,25 +664,309 @@ __global__ __launch_bounds__(256) void c3_pack_kernel(const half_t* __restrict__
   out[idx] = v;
 }
 
+
+// ---- 3x3 / stride 2 / pad 1 on whole small maps (the entry block's conv2 of the 512-plane stage: 16x12 -> 8x6 at 256x192,
+//      blocks.py:92-95 with stride on conv2; FlowNet conv6: 12x16 -> 6x8, FlowNetS.py:33) -----------------------------------
+// The stride-1 form above with two differences.  (1) The input map of ONE image (<= 256 pixels) is four times the output map, so
+// only 256 of its channels fit LDS at a time: the K walk is NH passes of 256 channels, each over all nine taps, the tile is
+// reloaded between passes (the weight ring keeps running across the reload).  (2) The pixel operand of output pixel (oy, ox) for
+// tap (ky, kx) is input row (2 oy + ky - 1) * Wi + 2 ox + kx - 1, again a per-lane row base (a zero row where the tap leaves the
+// map).  A workgroup = one image x 64 output channels; the four waves split a pass's 256 channels (64 each = one 4-slice step
+// per tap), partial accumulators meet in LDS as above.  Weight stream: [channel block][wave][step = pass * 9 + tap][kk][i].
+template <int MT, int NH>      // output pixel tiles (Ho * Wo <= MT * 32); 256-channel passes (Cin = NH * 256)
+__global__ __launch_bounds__(256, 1) void conv3x3s2_direct_kernel(const C3Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int ROWB = 512, BN = 64, NTILE = 2 * MT;
+  constexpr int TROWS = MT * 32, INROWS = 256;
+  constexpr int ZROW = 131072, TAB = ZROW + ROWB, STG = TAB + 2 * BN * 4, STG_ROWB = BN * 2;
+  constexpr int PART = 4 * NTILE * 4096;
+  constexpr int NSTEP = 9 * NH;
+  static_assert(INROWS * ROWB <= ZROW && PART <= ZROW && STG + TROWS * STG_ROWB <= 163840, "LDS map");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int logical;
+  {
+    const int total = p.npt * p.ncb;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int cb = logical % p.ncb, n = logical / p.ncb;
+  const int npix_in = p.HW;                         // input pixels of this workgroup's image
+  const int npix = p.Ho * p.Wo;                     // its output pixels
+  const int m0 = n * npix;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // ---- the input tile of one pass: row = input pixel, 256 channels = 32 16-byte positions; a 1-KiB wave load = 2 rows; XOR
+  //      swizzle (low 4 bits of the position ^= row & 15) on the source side
+  constexpr int NLOAD = INROWS * ROWB / 1024 / 4;      // 32 wave loads per wave
+  unsigned x_voff[NLOAD];
+#pragma unroll
+  for (int t = 0; t < NLOAD; ++t) {
+    const int piece = t * 4 + wave;
+    const int row = piece * 2 + (lane >> 5), pos = lane & 31;
+    x_voff[t] = row < npix_in ? (unsigned)(((n * npix_in + row) * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)) : kOOB;
+  }
+  // The tile travels THROUGH REGISTERS (32 x 16 bytes per lane), not by LDS-DMA: the DMA path delivers ~25 GB/s per CU (98 KiB =
+  // 3.9 us, exposed once per pass: 33 us for the layer on 512 workgroups), the register path several times that, and — the point —
+  // the NEXT pass's tile can be in flight in registers while this pass multiplies; at the pass boundary only the LDS writes remain.
+  uint4_t treg[NLOAD];
+  auto load_tile = [&](int pass) {
+#pragma unroll
+    for (int t = 0; t < NLOAD; ++t) treg[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, x_voff[t], pass * ROWB, 0);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int t = 0; t < NLOAD; ++t) *reinterpret_cast<uint4_t*>(smem + (t * 4 + wave) * 1024 + lane * 16) = treg[t];
+  };
+  const unsigned lane16 = (unsigned)lane * 16u;
+  uint4_t areg[3][4][2];
+  auto load_a = [&](auto slotc, int st) {            // step st of this wave's stream: 8 contiguous KiB; past the end: zeros
+    constexpr int SL = decltype(slotc)::value;
+    const int base = st < NSTEP ? ((cb * 4 + wave) * NSTEP + st) * 8192 : 0x7fff0000;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, base + (kk * 2 + i) * 1024, 0);
+  };
+  load_tile(0);
+  load_a(c0{}, 0);
+  load_a(c1{}, 1);
+  if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
+  if (tid < BN / 4) {
+    const float4_t one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const int ch = cb * BN + tid * 4;
+    reinterpret_cast<float4_t*>(smem + TAB)[tid] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + ch) : one;
+    reinterpret_cast<float4_t*>(smem + TAB + BN * 4)[tid] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + ch) : zero;
+  }
+  store_tile();                                      // (hipcc waits for the tile's loads here; the two weight steps stay in flight)
+  if constexpr (NH > 1) load_tile(1);                // the second pass's tile: in flight while the first pass multiplies
+  // per-lane geometry: the input pixel of tap (0, 0) of the lane's output pixel in each tile, and its 9-bit tap validity
+  int ibase[MT], tmask[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int pp = j * 32 + l31;
+    int mk = 0, ib = 0;
+    if (pp < npix) {
+      const int oy = pp / p.Wo, ox = pp - oy * p.Wo;
+      const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+      ib = iy0 * p.W + ix0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ny = iy0 + t / 3, nx = ix0 + t % 3;
+        if ((unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
+      }
+    }
+    ibase[j] = ib;
+    tmask[j] = mk;
+  }
+  float16_t acc[2][MT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // byte base of the lane's operand row for tap t: this wave's 64 channels = positions [8 * wave, 8 * wave + 8); slice s is one
+  // more XOR (s << 5)
+  auto row_bases = [&](int t, int (&rb)[MT]) {
+    const int off = (t / 3) * p.W + (t % 3);
+    const int wq = wave * 8;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = ibase[j] + off;
+      const int v = row * ROWB + ((wq & ~15) << 4) + (((((wq & 15) + lhi) ^ row) & 15) << 4);
+      rb[j] = ((tmask[j] >> t) & 1) ? v : ZROW + (lhi << 4);
+    }
+  };
+  uint4_t fb[2][MT];
+  auto ldb = [&](auto setc, int s, const int (&rb)[MT]) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (s << 5)));
+  };
+  auto mma = [&](auto setc, auto slotc, auto kkc) {
+    constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]), __builtin_bit_cast(half8_t, fb[S][j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+  // the first tile is in LDS (this wave's share), then everyone's
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  int rb[MT], rbn[MT];
+  row_bases(0, rb);
+  ldb(c0{}, 0, rb);
+  cd_unroll<NSTEP>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int tap = st % 9;
+    using slot = std::integral_constant<int, st % 3>;
+    load_a(std::integral_constant<int, (st + 2) % 3>{}, st + 2);
+    ldb(c1{}, 1, rb);
+    mma(c0{}, slot{}, std::integral_constant<int, 0>{});
+    ldb(c0{}, 2, rb);
+    mma(c1{}, slot{}, std::integral_constant<int, 1>{});
+    ldb(c1{}, 3, rb);
+    mma(c0{}, slot{}, std::integral_constant<int, 2>{});
+    if constexpr (st + 1 < NSTEP && tap != 8) {
+      row_bases(tap + 1, rbn);
+      ldb(c0{}, 0, rbn);
+    }
+    mma(c1{}, slot{}, std::integral_constant<int, 3>{});
+    if constexpr (st + 1 < NSTEP) {
+      if constexpr (tap != 8) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) rb[j] = rbn[j];
+      } else {
+        // pass boundary: every wave is past its last read of this pass's tile -> the next 256 channels, which have been
+        // sitting in registers since the previous boundary, go to LDS; the tile after that starts its flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CD_BARRIER();
+        store_tile();
+        if constexpr ((st + 1) / 9 + 1 < NH) load_tile((st + 1) / 9 + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CD_BARRIER();
+        row_bases(0, rb);
+        ldb(c0{}, 0, rb);
+      }
+    }
+  });
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();                                     // every wave is past its last read of the tile: the partials overwrite it
+
+  // ---- K quarters meet in LDS, then the epilogue (as the stride-1 form) ------------------------------------------------------
+  const float* tsc = reinterpret_cast<const float*>(smem + TAB);
+  const float* tsh = tsc + BN;
+  const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
+  char* stg = smem + STG;
+  float4_t* part = reinterpret_cast<float4_t*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4_t v = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+        part[((wave * NTILE + i * MT + j) * 4 + g4) * 64 + lane] = v;
+      }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+#pragma unroll
+  for (int k = 0; k < (NTILE + 3) / 4; ++k) {
+    const int tl = wave + 4 * k;
+    if (tl < NTILE) {
+      const int i = tl / MT, j = tl - i * MT;
+      const int ch = i * 32 + 16 * lhi, row = j * 32 + l31;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tsc + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tsh + ch + g4 * 4);
+      }
+      half8_t o[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float4_t v = part[((0 * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += part[((w * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = v[e] * sc[g4][e] + sh[g4][e];
+          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)__builtin_fmaxf(u, u * act_k);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<half8_t*>(stg + row * STG_ROWB + ((((ch >> 3) + h) ^ (row & 7)) << 4)) = o[h];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  constexpr int NST = TROWS * 8 / 256;
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int idx = tid + 256 * k, row = idx >> 3, ch = idx & 7;
+    const int m = m0 + row;
+    const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + row * STG_ROWB + ((ch ^ (row & 7)) << 4));
+    const unsigned voff = (row < npix && m < p.M && cb * BN + ch * 8 < p.Cout) ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + ch * 8) * 2) : kOOB;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, FT_YSTORE_BUF_AUX);
+  }
+#endif
+}
+
+// weight stream of the stride-2 form: [channel block][wave][step = pass * 9 + tap][kk][i]; K-major source, k = tap * Cin + ci
+template <int NH>
+__global__ __launch_bounds__(256) void c3s2_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int ncb, int kpad, int cout_pad) {
+  constexpr int C = NH * 256, NSTEP = 9 * NH;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncb * 4 * NSTEP * 512) return;
+  const int lane = idx & 63;
+  int f = idx >> 6;
+  const int i = f & 1; f >>= 1;
+  const int kk = f & 3; f >>= 2;
+  const int st = f % NSTEP; f /= NSTEP;
+  const int wv = f & 3, cb = f >> 2;
+  const int pass = st / 9, tap = st % 9;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int co = cb * 64 + i * 32 + cd_sigma(l31);
+  const int k = tap * C + pass * 256 + wv * 64 + kk * 16 + 8 * lhi;
+  uint4_t v = {0u, 0u, 0u, 0u};
+  if (co < cout_pad && k < kpad) v = *reinterpret_cast<const uint4_t*>(w + (size_t)co * kpad + k);
+  out[idx] = v;
+}
+
 struct C3Plan {
-  int mt, spt, ipw, npt, ncb;
+  int mt, spt, ipw, npt, ncb, stride;
 };
 
 static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
   if (!d) return FT_ERR_INVALID_ARG;
-  if (d->dtype != FT_F16 || d->transposed || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return FT_ERR_UNSUPPORTED;
+  if (d->dtype != FT_F16 || d->transposed || d->kh != 3 || d->kw != 3 || (d->stride != 1 && d->stride != 2) || d->pad != 1) return FT_ERR_UNSUPPORTED;
   if (d->tail_cout || d->pool || d->x_wpitch || d->x2_cin || d->has_residual || d->out_layout != FT_LAYOUT_NHWC) return FT_ERR_UNSUPPORTED;
-  if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
+  if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0) return FT_ERR_UNSUPPORTED;
   if (d->x_coff % 8 || d->x_cstride % 8 || d->y_coff % 8 || d->y_cstride % 8 || d->Cout % 64) return FT_ERR_UNSUPPORTED;
-  if (d->Cin != 512) return FT_ERR_UNSUPPORTED;                  // (instantiated for the 512-plane stage)
   if (d->x_cstride < d->x_coff + d->Cin || d->y_cstride < d->y_coff + d->Cout) return FT_ERR_INVALID_ARG;
   const int hw = d->Hi * d->Wi;
-  if (hw > 128) return FT_ERR_UNSUPPORTED;
+  if (d->stride == 2) {
+    // one image per workgroup, its whole INPUT map (<= 256 pixels) resident 256 channels at a time (conv3x3s2_direct_kernel)
+    static const bool no_s2 = getenv("FT_CD_NO_S2") != nullptr;                                   // dev A/B
+    if (no_s2 || d->Ho != (d->Hi + 1) / 2 || d->Wo != (d->Wi + 1) / 2 || hw > 256 || d->Ho * d->Wo > 64) return FT_ERR_UNSUPPORTED;
+    if (d->Cin != 512) return FT_ERR_UNSUPPORTED;                // (instantiated for two 256-channel passes)
+    if ((long long)d->N * hw * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2 >= (1LL << 31))
+      return FT_ERR_UNSUPPORTED;
+    *out = C3Plan{(d->Ho * d->Wo + 31) / 32, d->Cin / 256, 1, d->N, d->Cout / 64, 2};
+    return FT_OK;
+  }
+  if (d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
+  if (d->Cin != 512 && d->Cin != 1024) return FT_ERR_UNSUPPORTED;   // (instantiated for the 512-plane stage and FlowNet's conv6_1)
+  if (hw > (d->Cin == 512 ? 128 : 64)) return FT_ERR_UNSUPPORTED;  // the tile (every channel of the workgroup's images) must fit 128 KiB
   const long long M = (long long)d->N * hw;
   if (M * d->x_cstride * 2 >= (1LL << 31) || M * d->y_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
-  const int ipw = hw <= 96 ? 96 / hw : 1;
-  const int mt = ipw * hw <= 96 ? 3 : 4;
-  *out = C3Plan{mt, d->Cin / 256, ipw, (d->N + ipw - 1) / ipw, d->Cout / 64};
+  const int ipw = d->Cin == 512 ? (hw <= 96 ? 96 / hw : 1) : 1;
+  const int mt = d->Cin == 512 ? (ipw * hw <= 96 ? 3 : 4) : 2;
+  *out = C3Plan{mt, d->Cin / 256, ipw, (d->N + ipw - 1) / ipw, d->Cout / 64, 1};
+  return FT_OK;
+}
+
+template <int MT, int NH>
+static int c3s2_launch(const C3Params& p, hipStream_t s) {
+  auto k = conv3x3s2_direct_kernel<MT, NH>;
+  constexpr int lds = 131072 + 512 + 2 * 64 * 4 + MT * 32 * 128;
+  FT_RAISE_LDS(k, lds);
+  hipLaunchKernelGGL(k, dim3(p.npt * p.ncb), dim3(256), lds, s, p);
+  FT_LAUNCH_CHECK("conv3x3s2_direct_kernel");
   return FT_OK;
 }
 
@@ -1011,7 +1296,7 @@ extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
 extern "C" int ft_conv_direct_stream_id(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;
-  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return 0x40000000 | (p3.ncb << 8) | p3.spt;
+  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return 0x40000000 | (p3.stride == 2 ? 0x10000000 : 0) | (p3.ncb << 8) | p3.spt;
   if (ft::cd_plan(d, &pl) != FT_OK) return -1;
   return ((pl.ksplit + 1) << 24) | ((pl.nc1 + pl.nc2) << 12) | pl.ncb;
 }
@@ -1031,8 +1316,12 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
   if (d && d->kh == 3 && c3_plan(d, &p3) == FT_OK) {
     if (!w_packed || !wstream || kpad < 9 * d->Cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
     const int total = p3.ncb * 4 * 9 * p3.spt * 512;
-    hipLaunchKernelGGL(c3_pack_kernel<2>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), static_cast<const half_t*>(w_packed),
-                       static_cast<uint4_t*>(wstream), p3.ncb, kpad, cout_pad);
+    const dim3 pg(ceil_div(total, 256));
+    const half_t* wsrc = static_cast<const half_t*>(w_packed);
+    uint4_t* wdst = static_cast<uint4_t*>(wstream);
+    if (p3.stride == 2) hipLaunchKernelGGL(c3s2_pack_kernel<2>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
+    else if (p3.spt == 4) hipLaunchKernelGGL(c3_pack_kernel<4>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
+    else hipLaunchKernelGGL(c3_pack_kernel<2>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
     FT_LAUNCH_CHECK("c3_pack_kernel");
     return FT_OK;
   }
@@ -1073,13 +1362,16 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
     q.scale = scale;
     q.shift = shift;
     q.HW = d->Hi * d->Wi; q.W = d->Wi; q.H = d->Hi; q.ipw = p3.ipw;
-    q.M = d->N * q.HW;
+    q.Ho = p3.stride == 2 ? d->Ho : 0; q.Wo = p3.stride == 2 ? d->Wo : 0;
+    q.M = p3.stride == 2 ? d->N * d->Ho * d->Wo : d->N * q.HW;
     q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.y_cstride = d->y_cstride; q.y_coff = d->y_coff;
     q.Cout = d->Cout; q.act = d->act; q.slope = d->slope;
     q.npt = p3.npt; q.ncb = p3.ncb;
-    q.x_bytes = (unsigned)((size_t)q.M * d->x_cstride * 2);
+    q.x_bytes = (unsigned)((size_t)d->N * q.HW * d->x_cstride * 2);
     q.y_bytes = (unsigned)((size_t)q.M * d->y_cstride * 2);
     q.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+    if (p3.stride == 2) return p3.mt == 1 ? c3s2_launch<1, 2>(q, as_stream(stream)) : c3s2_launch<2, 2>(q, as_stream(stream));
+    if (p3.spt == 4) return c3_launch<2, 4>(q, as_stream(stream));
     return p3.mt == 3 ? c3_launch<3, 2>(q, as_stream(stream)) : c3_launch<4, 2>(q, as_stream(stream));
   }
   CdPlan pl;

@@ -735,6 +735,160 @@ __global__ __launch_bounds__(256) void resample2d_pair_kernel(const float* __res
   }
 }
 
+// ---- Resample2d through an LDS window (round 4) ---------------------------------------------------------------------------
+// The gather kernels above are bound by cache-line REQUESTS, not bytes: with incoherent per-pixel flows every lane's taps sit
+// in their own lines (12 requests per pixel at C = 3), 38 M requests per launch at configs[3] shapes.  Here a workgroup owns a
+// 16 x 64 tile of output pixels (4 per thread): it reads the tile's flow once, reduces the bounding box of every tap the tile
+// touches (clamped indices, so the box is inside the image), loads that window of in1 — all C planes — into LDS with
+// row-contiguous, fully coalesced 4-byte-per-lane loads, and serves the four taps of every pixel from LDS.  A tile whose
+// window does not fit the LDS budget (a flow field with > ~20 px of spread inside 16 x 64 pixels) takes the direct gathers of
+// resample2d_pair_kernel for that tile only (workgroup-uniform branch).  Same weights, same order of the four products as
+// Resample2d_kernel.cu:42-59 restated above: results are bit-identical to the gather kernels.
+constexpr int kRsTH = 16, kRsTW = 64, kRsPPT = 4;          // tile rows / columns, pixels per thread
+constexpr int kRsMaxWindow = 6656;                         // window floats per plane (row pitch x rows): 3 planes x 26 KiB = 78 KiB, two workgroups per CU
+
+template <int C>
+__global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __restrict__ in1, const float* __restrict__ flow,
+                                                                float* __restrict__ out, int H, int W, int tiles_x, int tiles_y,
+                                                                unsigned in_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  __shared__ int s_box[4][4];                              // per wave: min x, max x, min y, max y
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = tiles_x * tiles_y;
+  const int b = blockIdx.x / tiles, trem = blockIdx.x - b * tiles;
+  const int ty0 = (trem / tiles_x) * kRsTH, tx0 = (trem % tiles_x) * kRsTW;
+  const size_t HW = (size_t)H * W;
+  const int x = tx0 + lane;
+  float w00[kRsPPT], w01[kRsPPT], w10[kRsPPT], w11[kRsPPT];
+  int xL[kRsPPT], xR[kRsPPT], yT[kRsPPT], yB[kRsPPT];
+  int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+#pragma unroll
+  for (int k = 0; k < kRsPPT; ++k) {
+    const int y = ty0 + k * 4 + wave;
+    const bool live = x < W && y < H;
+    float dx = 0.f, dy = 0.f;
+    if (live) {
+      const size_t pix = (size_t)y * W + x;
+      dx = flow[(b * 2 + 0) * HW + pix];
+      dy = flow[(b * 2 + 1) * HW + pix];
+    }
+    const float xf = (float)x + dx, yf = (float)y + dy;
+    const float fx = floorf(xf), fy = floorf(yf);
+    const float alpha = xf - fx, beta = yf - fy;
+    xL[k] = (int)fminf(fmaxf(fx, 0.f), (float)(W - 1));
+    xR[k] = (int)fminf(fmaxf(fx + 1.f, 0.f), (float)(W - 1));
+    yT[k] = (int)fminf(fmaxf(fy, 0.f), (float)(H - 1));
+    yB[k] = (int)fminf(fmaxf(fy + 1.f, 0.f), (float)(H - 1));
+    w00[k] = (1.f - alpha) * (1.f - beta); w01[k] = alpha * (1.f - beta);
+    w10[k] = (1.f - alpha) * beta;         w11[k] = alpha * beta;
+    if (live) {
+      bx0 = min(bx0, xL[k]); bx1 = max(bx1, xR[k]);
+      by0 = min(by0, yT[k]); by1 = max(by1, yB[k]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bx0 = min(bx0, __shfl_xor(bx0, off)); bx1 = max(bx1, __shfl_xor(bx1, off));
+    by0 = min(by0, __shfl_xor(by0, off)); by1 = max(by1, __shfl_xor(by1, off));
+  }
+  if (lane == 0) { s_box[wave][0] = bx0; s_box[wave][1] = bx1; s_box[wave][2] = by0; s_box[wave][3] = by1; }
+  __syncthreads();
+  bx0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+  bx1 = max(max(s_box[0][1], s_box[1][1]), max(s_box[2][1], s_box[3][1]));
+  by0 = min(min(s_box[0][2], s_box[1][2]), min(s_box[2][2], s_box[3][2]));
+  by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+  if (bx1 < 0) return;                                     // (a tile without a live pixel: cannot happen for ceil-divided grids)
+  bx0 = __builtin_amdgcn_readfirstlane(bx0); bx1 = __builtin_amdgcn_readfirstlane(bx1);
+  by0 = __builtin_amdgcn_readfirstlane(by0); by1 = __builtin_amdgcn_readfirstlane(by1);
+  // 16-byte DMA pieces need 16-byte-aligned sources: the window starts at a multiple of four columns (W % 4 == 0: every row base
+  // is aligned); otherwise 4-byte pieces, four times as many instructions
+  const bool vec4 = (W & 3) == 0;
+  if (vec4) bx0 &= ~3;
+  const int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
+  const int pitch = ww <= 64 ? 64 : (ww <= 128 ? 128 : (ww <= 256 ? 256 : ((ww + 255) & ~255)));   // floats per LDS row: a power of two up to 256
+  const bool fits = (((long long)pitch * wh + 255) & ~255LL) <= kRsMaxWindow;
+  if (fits) {
+    // the window of every plane through LDS-DMA, straight into LDS (no VGPR round trip, every piece in flight at once: the tile's
+    // latency is ONE memory round trip, not one per row).  A wave instruction moves 1 KiB = 256 consecutive LDS floats = 256 / pitch
+    // window rows (vec4) or 64 floats of one row (4-byte pieces); lanes past the window read out of range = 0
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in1), 0, in_bytes, 0x00020000);
+    constexpr unsigned kOOB = 0x80000000u;
+    const int plane = (pitch * wh + 255) & ~255;           // whole 1-KiB pieces per plane: a piece's tail never reaches the next plane
+    if (vec4) {
+      const int nfl = plane;                               // floats of one plane's window image
+      const int lrow = (lane * 4) / pitch, lcol = (lane * 4) % pitch;   // this lane's place inside a piece (pitch <= 256: 1, 2 or 4 rows per piece)
+      const int rpp = pitch >= 256 ? 1 : 256 / pitch;      // rows per piece
+      const int ppr = pitch >= 256 ? pitch / 256 : 1;      // pieces per row
+      const int npieces = pitch >= 256 ? wh * ppr : (wh + rpp - 1) / rpp;
+#pragma unroll 1
+      for (int c = 0; c < C; ++c) {
+        const unsigned cbase = (unsigned)((((size_t)b * C + c) * HW + (size_t)by0 * W + bx0) * 4);
+#pragma unroll 4
+        for (int pc = wave; pc < npieces; pc += 4) {
+          int r, q;
+          if (pitch >= 256) { r = pc / ppr; q = (pc - r * ppr) * 256 + lane * 4; }
+          else { r = pc * rpp + lrow; q = lcol; }
+          const unsigned voff = (r < wh && q < ww) ? cbase + (unsigned)((r * W + q) * 4) : kOOB;
+          if (pc * 256 < nfl)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(rs_smem + c * plane + pc * 256), 16, voff, 0, 0, 0);
+        }
+      }
+    } else {
+      const int nch = pitch >> 6;
+      const int npieces = wh * nch;
+#pragma unroll 1
+      for (int c = 0; c < C; ++c) {
+        const unsigned cbase = (unsigned)((((size_t)b * C + c) * HW + (size_t)by0 * W + bx0) * 4);
+#pragma unroll 4
+        for (int pc = wave; pc < npieces; pc += 4) {
+          const int r = pc / nch, j = pc - r * nch;
+          const int q = 64 * j + lane;
+          const unsigned voff = q < ww ? cbase + (unsigned)((r * W + q) * 4) : kOOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(rs_smem + c * plane + r * pitch + 64 * j), 4, voff, 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRsPPT; ++k) {
+      const int y = ty0 + k * 4 + wave;
+      if (x < W && y < H) {
+        const int oT = (yT[k] - by0) * pitch, oB = (yB[k] - by0) * pitch, oL = xL[k] - bx0, oR = xR[k] - bx0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* p = rs_smem + c * plane;
+          float v = w00[k] * p[oT + oL];
+          v += w01[k] * p[oT + oR];
+          v += w10[k] * p[oB + oL];
+          v += w11[k] * p[oB + oR];
+          out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kRsPPT; ++k) {
+      const int y = ty0 + k * 4 + wave;
+      if (x < W && y < H) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* p = in1 + ((size_t)b * C + c) * HW;
+          float v = w00[k] * p[(size_t)yT[k] * W + xL[k]];
+          v += w01[k] * p[(size_t)yT[k] * W + xR[k]];
+          v += w10[k] * p[(size_t)yB[k] * W + xL[k]];
+          v += w11[k] * p[(size_t)yB[k] * W + xR[k]];
+          out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
+        }
+      }
+    }
+  }
+#endif
+}
+
 // ---- ChannelNorm: sqrt(sum_c x^2) ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channelnorm_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
                                                           size_t HW, size_t total) {
@@ -1031,6 +1185,31 @@ extern "C" int ft_resample2d_fwd(const float* in1, const float* flow, float* out
                                  ft_stream_t stream) {
   if (!in1 || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return FT_ERR_INVALID_ARG;
   const size_t total = (size_t)B * H * W;
+  static const bool no_window = getenv("FT_RESAMPLE_WINDOW") && atoi(getenv("FT_RESAMPLE_WINDOW")) == 0;   // dev A/B: the gather kernels
+  const unsigned long long in_bytes = (unsigned long long)B * C * H * W * 4ull;
+  if (!no_window && C >= 1 && C <= 4 && W >= 1 && in_bytes < (1ull << 31)) {
+    const int tiles_x = ceil_div(W, kRsTW), tiles_y = ceil_div(H, kRsTH);
+    const long long nblk = (long long)B * tiles_x * tiles_y;
+    if (nblk <= 0x7fffffffLL) {
+      const dim3 grid((unsigned)nblk);
+      const size_t lds = (size_t)C * kRsMaxWindow * sizeof(float);
+#define FT_RS_LAUNCH(CC)                                                                                                   \
+  {                                                                                                                        \
+    auto kw = resample2d_window_kernel<CC>;                                                                                \
+    if (lds > 64 * 1024) FT_RAISE_LDS(kw, 112 * 1024);                                                                     \
+    hipLaunchKernelGGL(kw, grid, dim3(256), lds, as_stream(stream), in1, flow, out, H, W, tiles_x, tiles_y, (unsigned)in_bytes); \
+  }
+      switch (C) {
+        case 1: FT_RS_LAUNCH(1) break;
+        case 2: FT_RS_LAUNCH(2) break;
+        case 3: FT_RS_LAUNCH(3) break;
+        default: FT_RS_LAUNCH(4) break;
+      }
+#undef FT_RS_LAUNCH
+      FT_LAUNCH_CHECK("resample2d_window_kernel");
+      return FT_OK;
+    }
+  }
   static const bool no_pair = getenv("FT_RESAMPLE_PAIR") && atoi(getenv("FT_RESAMPLE_PAIR")) == 0;   // dev A/B
   if (!no_pair && W >= 2 && C >= 1 && C <= 4 && (long long)H * W < (1LL << 31)) {
     const dim3 grid(grid_for(total));

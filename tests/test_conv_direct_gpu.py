@@ -108,14 +108,15 @@ def test_direct_shortcut_conv_matches_oracle_and_igemm(hip_lib, case, monkeypatc
     assert (outs[True] - outs[False]).abs().max().item() <= 1e-2 * scale
 
 
-@pytest.mark.parametrize("case", [("l4_conv2_8x6", 64, 8, 6), ("odd_batch", 5, 8, 6), ("r101_12x9", 7, 12, 9), ("tiny_3x5", 3, 3, 5)],
+@pytest.mark.parametrize("case", [("l4_conv2_8x6", 64, 8, 6), ("odd_batch", 5, 8, 6), ("r101_12x9", 7, 12, 9), ("tiny_3x5", 3, 3, 5),
+                                  ("flownet_conv6_1_c1024", 5, 6, 8, 1024), ("c1024_full_tile_8x8", 2, 8, 8, 1024), ("c1024_tiny", 3, 2, 3, 1024)],
                          ids=lambda c: c[0])
 def test_direct_conv3x3_whole_maps_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
     """layer4's conv2 (3x3 / stride 1 / pad 1, 512 -> 512) on whole small maps: input tile resident in LDS, taps as row
     shifts (zero row outside the image), waves split K, weights straight to registers."""
-    name, N, H, W = case
+    name, N, H, W = case[:4]
     dev, dtype, seed = torch.device("cuda:0"), torch.float16, 35
-    C = 512
+    C = case[4] if len(case) > 4 else 512       # 1024: FlowNet's conv6_1 (FlowNetS.py:32): one image per workgroup, four 4-slice steps per tap
     w = synth.normal(seed, name + ".w", (C, C, 3, 3), std=(2.0 / (9 * C)) ** 0.5)
     bn = _bn(seed, name + ".bn", C)
     x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
@@ -149,6 +150,12 @@ GATHER_CASES = [
     ("stride1_big_map", 2, 20, 14, 256, 256, 1, "relu", 0),      # 3x3 / s1 on a map the whole-map kernel does not take
     ("odd_map_s2", 3, 13, 9, 256, 256, 2, "relu", 0),            # odd sizes: Ho = 7, Wo = 5, ragged pixel tile
     ("long_walk", 2, 8, 6, 1024, 256, 2, "relu", 0),             # 36 chunks of 256 channels: the run-time loop
+    # 512 -> * / stride 2 on input maps of <= 256 pixels: the whole-map stride-2 form (conv3x3s2_direct_kernel: two passes of 256
+    # channels over a resident input map) — l4_entry_conv2 above takes it as well
+    ("s2_whole_odd_map", 3, 13, 9, 512, 512, 2, "relu", 0),      # Ho x Wo = 7 x 5: ragged second pixel tile, odd input rows / columns
+    ("s2_whole_flownet_conv6", 4, 12, 16, 512, 1024, 2, "leaky", 32),   # FlowNetS conv6: 16 channel blocks, LeakyReLU, input slice
+    ("s2_whole_one_tile", 5, 8, 6, 512, 128, 2, "relu", 0),      # Ho x Wo = 4 x 3: one pixel tile (MT = 1)
+    ("s2_whole_16x16", 2, 16, 16, 512, 64, 2, "relu", 0),        # the largest input map (256 pixels), 64 output pixels exactly
 ]
 
 

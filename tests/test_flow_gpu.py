@@ -147,6 +147,25 @@ def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
         assert np.abs(out2.cpu().numpy() - ops_ref.resample2d_c(img2, flow2)).max() <= 1e-5, (b2, c2, h2, w2)
 
 
+def test_resample2d_window_kernel_paths(hip_lib, oracle_lib):
+    """The LDS-window form of Resample2d (16 x 64 tiles, csrc/flow_ops.hip): ragged maps with several tiles in both directions;
+    incoherent per-pixel flows (sigma 4 px: every tile's tap window fits LDS), one image whose flow spreads over the whole map
+    (window too large: that tile's direct gathers), far out-of-frame flows (border clamp without renormalisation,
+    Resample2d_kernel.cu:42-59), 1..4 channels."""
+    for (B, C, H, W) in ((3, 3, 70, 150), (2, 4, 33, 200), (2, 1, 16, 64), (1, 2, 50, 65)):
+        img = synth.normal(8, f"img{C}{W}", (B, C, H, W)).numpy()
+        flow = (synth.normal(8, f"flow{C}{W}", (B, 2, H, W)) * 4.0).numpy()
+        flow[B - 1] = (synth.normal(9, f"wide{C}{W}", (2, H, W)) * 60.0).numpy()       # spread >> tile: the fallback branch
+        flow[0, :, 0, 0] = (-1000.0, 2500.0)
+        flow[0, :, H - 1, W - 1] = (1e9, -1e9)
+        want = ops_ref.resample2d_c(img, flow)
+        out = torch.full((B, C, H, W), 7.0, dtype=torch.float32, device="cuda")
+        gi, gf = _cuda(img), _cuda(flow)
+        check(hip_lib.ft_resample2d_fwd(gi.data_ptr(), gf.data_ptr(), out.data_ptr(), B, C, H, W, _stream()))
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - want).max() <= 1e-5, (B, C, H, W)
+
+
 def test_upsample_and_normalise(hip_lib, oracle_lib):
     x = synth.normal(6, "flow2", (2, 2, 6, 9)).numpy()
     y = torch.empty((2, 2, 24, 36), dtype=torch.float32, device="cuda")
