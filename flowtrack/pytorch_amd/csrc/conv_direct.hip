@@ -927,6 +927,275 @@ __global__ __launch_bounds__(256) void c3s2_pack_kernel(const half_t* __restrict
   out[idx] = v;
 }
 
+
+// ---- the stride-2 form for TWO images per workgroup (round 4) ------------------------------------------------------------------
+// conv3x3s2_direct_kernel streams a channel block's 590 KB of weights for 48 output pixels; with 64 crops that is 512 workgroups
+// and the layer is bound by that stream (33 us; the stride-1 sibling, 96 pixels per workgroup, takes 20).  Here a workgroup takes
+// TWO images (<= 96 output pixels, MT = 3): their input maps (<= 512 pixels) are resident 128 channels at a time — four passes, the
+// next pass's tile in flight in registers — and the K split of a pass is (channel half) x (tap parity): wave w takes channels
+// [64 (w & 1), +64) of the taps with parity ((w >> 1) + pass) & 1, i.e. 5 + 4 + 5 + 4 or 4 + 5 + 4 + 5 taps over the four passes,
+// 18 four-slice steps per wave either way.  Every pass has five step slots; the slot a wave has no tap for multiplies zero weights
+// (an out-of-range load: no traffic).  Weight stream: [channel block][wave][its 18 steps in walk order][kk][i].
+template <int MT, int NLD>     // output pixel tiles (2 * Ho * Wo <= MT * 32); 1-KiB tile pieces per wave (2 * Hi * Wi * 256 B <= NLD * 4 KiB)
+__global__ __launch_bounds__(256, 1) void conv3x3s2p_direct_kernel(const C3Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int ROWB = 256, BN = 64, NTILE = 2 * MT, NP = 4, NSL = 5, NSTEP = NP * NSL;
+  constexpr int TROWS = MT * 32;
+  constexpr int ZROW = 131072, TAB = ZROW + ROWB, STG = TAB + 2 * BN * 4, STG_ROWB = BN * 2;
+  constexpr int PART = 4 * NTILE * 4096;
+  static_assert(NLD * 4096 <= ZROW && PART <= ZROW && STG + TROWS * STG_ROWB <= 163840, "LDS map");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int hch = wave & 1, qpar = wave >> 1;        // channel half of a pass, tap-parity group
+  int logical;
+  {
+    const int total = p.npt * p.ncb;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  const int npix_in = p.HW, npo = p.Ho * p.Wo;
+  const int rows_in = 2 * npix_in;                  // input pixels of this workgroup's two images
+  const int npix = 2 * npo;                         // its output pixels
+  const int m0 = pt * npix;
+  const int N_in = (p.M / npo) * npix_in;           // input pixels of the whole batch
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
+
+  // the input tile of one pass: row = input pixel (of either image), 128 channels = 16 16-byte positions, 4 rows per 1-KiB piece;
+  // XOR swizzle (position ^= row & 15) on the source side; through registers as in the one-image form
+  unsigned x_voff[NLD];
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int piece = t * 4 + wave;
+    const int row = piece * 4 + (lane >> 4), pos = lane & 15;
+    const int gp = pt * rows_in + row;
+    x_voff[t] = (row < rows_in && gp < N_in) ? (unsigned)((gp * p.x_cstride + p.x_coff) * 2 + (((pos ^ row) & 15) << 4)) : kOOB;
+  }
+  uint4_t treg[NLD];
+  auto load_tile = [&](int pass) {
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) treg[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, x_voff[t], pass * ROWB, 0);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) *reinterpret_cast<uint4_t*>(smem + (t * 4 + wave) * 1024 + lane * 16) = treg[t];
+  };
+  // step slot st = pass * 5 + i -> tap 2 i + ((qpar + pass) & 1) (none when that is 9) and the wave's stream index
+  auto slot_tap = [&](int st) { return 2 * (st % NSL) + ((qpar + st / NSL) & 1); };
+  const unsigned lane16 = (unsigned)lane * 16u;
+  uint4_t areg[3][4][2];
+  auto load_a = [&](auto slotc, int st) {
+    constexpr int SL = decltype(slotc)::value;
+    int base = 0x7fff0000;
+    if (st < NSTEP && slot_tap(st) < 9) {
+      const int pass = st / NSL;
+      const int sidx = (pass >> 1) * 9 + ((pass & 1) ? (qpar == 0 ? 5 : 4) : 0) + st % NSL;
+      base = ((cb * 4 + wave) * 18 + sidx) * 8192;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, base + (kk * 2 + i) * 1024, 0);
+  };
+  load_tile(0);
+  load_a(c0{}, 0);
+  load_a(c1{}, 1);
+  if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
+  if (tid < BN / 4) {
+    const float4_t one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const int ch = cb * BN + tid * 4;
+    reinterpret_cast<float4_t*>(smem + TAB)[tid] = p.scale ? *reinterpret_cast<const float4_t*>(p.scale + ch) : one;
+    reinterpret_cast<float4_t*>(smem + TAB + BN * 4)[tid] = p.shift ? *reinterpret_cast<const float4_t*>(p.shift + ch) : zero;
+  }
+  store_tile();
+  load_tile(1);
+  // per-lane geometry: tile row of tap (0, 0) of the lane's output pixel in each pixel tile, and its 9-bit tap validity
+  int ibase[MT], tmask[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int pp = j * 32 + l31;
+    int mk = 0, ib = 0;
+    if (pp < npix) {
+      const int img = pp >= npo ? 1 : 0, rem = pp - img * npo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+      ib = img * npix_in + iy0 * p.W + ix0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ny = iy0 + t / 3, nx = ix0 + t % 3;
+        if ((unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
+      }
+    }
+    ibase[j] = ib;
+    tmask[j] = mk;
+  }
+  float16_t acc[2][MT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto row_bases = [&](int t, int (&rb)[MT]) {      // t = 9: the slot without a tap (zero weights): any readable row
+    const int off = (t / 3) * p.W + (t % 3);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = ibase[j] + off;
+      const int v = row * ROWB + ((((hch * 8 + lhi) ^ row) & 15) << 4);
+      rb[j] = (t < 9 && ((tmask[j] >> t) & 1)) ? v : ZROW + (lhi << 4);
+    }
+  };
+  uint4_t fb[2][MT];
+  auto ldb = [&](auto setc, int s, const int (&rb)[MT]) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (s << 5)));
+  };
+  auto mma = [&](auto setc, auto slotc, auto kkc) {
+    constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]), __builtin_bit_cast(half8_t, fb[S][j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  int rb[MT], rbn[MT];
+  row_bases(slot_tap(0), rb);
+  ldb(c0{}, 0, rb);
+  cd_unroll<NSTEP>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int pass = st / NSL, i5 = st % NSL;
+    using slot = std::integral_constant<int, st % 3>;
+    load_a(std::integral_constant<int, (st + 2) % 3>{}, st + 2);
+    ldb(c1{}, 1, rb);
+    mma(c0{}, slot{}, std::integral_constant<int, 0>{});
+    ldb(c0{}, 2, rb);
+    mma(c1{}, slot{}, std::integral_constant<int, 1>{});
+    ldb(c1{}, 3, rb);
+    mma(c0{}, slot{}, std::integral_constant<int, 2>{});
+    if constexpr (i5 != NSL - 1) {
+      row_bases(slot_tap(st + 1), rbn);
+      ldb(c0{}, 0, rbn);
+    }
+    mma(c1{}, slot{}, std::integral_constant<int, 3>{});
+    if constexpr (st + 1 < NSTEP) {
+      if constexpr (i5 != NSL - 1) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) rb[j] = rbn[j];
+      } else {
+        // pass boundary: every wave is past its last read of this pass's tile -> the next 128 channels go from registers to LDS,
+        // the tile after that starts its flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CD_BARRIER();
+        store_tile();
+        if constexpr (pass + 2 < NP) load_tile(pass + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CD_BARRIER();
+        row_bases(slot_tap(st + 1), rb);
+        ldb(c0{}, 0, rb);
+      }
+    }
+  });
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();                                     // every wave is past its last read of the tile: the partials overwrite it
+
+  const float* tsc = reinterpret_cast<const float*>(smem + TAB);
+  const float* tsh = tsc + BN;
+  const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
+  char* stg = smem + STG;
+  float4_t* part = reinterpret_cast<float4_t*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4_t v = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+        part[((wave * NTILE + i * MT + j) * 4 + g4) * 64 + lane] = v;
+      }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+#pragma unroll
+  for (int k = 0; k < (NTILE + 3) / 4; ++k) {
+    const int tl = wave + 4 * k;
+    if (tl < NTILE) {
+      const int i = tl / MT, j = tl - i * MT;
+      const int ch = i * 32 + 16 * lhi, row = j * 32 + l31;
+      float4_t sc[4], sh[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4_t*>(tsc + ch + g4 * 4);
+        sh[g4] = *reinterpret_cast<const float4_t*>(tsh + ch + g4 * 4);
+      }
+      half8_t o[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float4_t v = part[((0 * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += part[((w * NTILE + tl) * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = v[e] * sc[g4][e] + sh[g4][e];
+          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)__builtin_fmaxf(u, u * act_k);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<half8_t*>(stg + row * STG_ROWB + ((((ch >> 3) + h) ^ (row & 7)) << 4)) = o[h];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CD_BARRIER();
+  constexpr int NST = TROWS * 8 / 256;
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int idx = tid + 256 * k, row = idx >> 3, ch = idx & 7;
+    const int m = m0 + row;
+    const uint4_t v = *reinterpret_cast<const uint4_t*>(stg + row * STG_ROWB + ((ch ^ (row & 7)) << 4));
+    const unsigned voff = (row < npix && m < p.M && cb * BN + ch * 8 < p.Cout) ? (unsigned)((m * p.y_cstride + p.y_coff + cb * BN + ch * 8) * 2) : kOOB;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, voff, 0, FT_YSTORE_BUF_AUX);
+  }
+#endif
+}
+
+// weight stream of the two-image form: [channel block][wave][18 steps in the wave's walk order][kk][i]; K-major source, k = tap * 512 + ci
+__global__ __launch_bounds__(256) void c3s2p_pack_kernel(const half_t* __restrict__ w, uint4_t* __restrict__ out, int ncb, int kpad, int cout_pad) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncb * 4 * 18 * 512) return;
+  const int lane = idx & 63;
+  int f = idx >> 6;
+  const int i = f & 1; f >>= 1;
+  const int kk = f & 3; f >>= 2;
+  int sidx = f % 18; f /= 18;
+  const int wv = f & 3, cb = f >> 2;
+  const int hch = wv & 1, qpar = wv >> 1;
+  int pass = 0;
+  for (; pass < 4; ++pass) {                       // the wave's passes hold 5 or 4 steps, alternating
+    const int np = ((qpar + pass) & 1) == 0 ? 5 : 4;
+    if (sidx < np) break;
+    sidx -= np;
+  }
+  const int tap = 2 * sidx + ((qpar + pass) & 1);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int co = cb * 64 + i * 32 + cd_sigma(l31);
+  const int k = tap * 512 + pass * 128 + hch * 64 + kk * 16 + 8 * lhi;
+  uint4_t v = {0u, 0u, 0u, 0u};
+  if (co < cout_pad && k < kpad) v = *reinterpret_cast<const uint4_t*>(w + (size_t)co * kpad + k);
+  out[idx] = v;
+}
+
 struct C3Plan {
   int mt, spt, ipw, npt, ncb, stride;
 };
@@ -946,7 +1215,15 @@ static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
     if (d->Cin != 512) return FT_ERR_UNSUPPORTED;                // (instantiated for two 256-channel passes)
     if ((long long)d->N * hw * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2 >= (1LL << 31))
       return FT_ERR_UNSUPPORTED;
-    *out = C3Plan{(d->Ho * d->Wo + 31) / 32, d->Cin / 256, 1, d->N, d->Cout / 64, 2};
+    // two images per workgroup (conv3x3s2p_direct_kernel: half the weight stream per output pixel) where that still gives about one
+    // workgroup per CU; else one image per workgroup
+    static const bool no_pair = getenv("FT_CD_NO_S2P") != nullptr;                                 // dev A/B
+    const int npo = d->Ho * d->Wo;
+    if (!no_pair && 2 * npo <= 96 && 2 * hw <= 512 && (long long)((d->N + 1) / 2) * (d->Cout / 64) >= 200) {
+      *out = C3Plan{(2 * npo + 31) / 32, d->Cin / 256, 2, (d->N + 1) / 2, d->Cout / 64, 2};
+      return FT_OK;
+    }
+    *out = C3Plan{(npo + 31) / 32, d->Cin / 256, 1, d->N, d->Cout / 64, 2};
     return FT_OK;
   }
   if (d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
@@ -957,6 +1234,16 @@ static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
   const int ipw = d->Cin == 512 ? (hw <= 96 ? 96 / hw : 1) : 1;
   const int mt = d->Cin == 512 ? (ipw * hw <= 96 ? 3 : 4) : 2;
   *out = C3Plan{mt, d->Cin / 256, ipw, (d->N + ipw - 1) / ipw, d->Cout / 64, 1};
+  return FT_OK;
+}
+
+template <int MT, int NLD>
+static int c3s2p_launch(const C3Params& p, hipStream_t s) {
+  auto k = conv3x3s2p_direct_kernel<MT, NLD>;
+  constexpr int lds = 131072 + 256 + 2 * 64 * 4 + MT * 32 * 128;
+  FT_RAISE_LDS(k, lds);
+  hipLaunchKernelGGL(k, dim3(p.npt * p.ncb), dim3(256), lds, s, p);
+  FT_LAUNCH_CHECK("conv3x3s2p_direct_kernel");
   return FT_OK;
 }
 
@@ -1296,7 +1583,7 @@ extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
 extern "C" int ft_conv_direct_stream_id(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;
-  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return 0x40000000 | (p3.stride == 2 ? 0x10000000 : 0) | (p3.ncb << 8) | p3.spt;
+  if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return 0x40000000 | (p3.stride == 2 ? (p3.ipw == 2 ? 0x30000000 : 0x10000000) : 0) | (p3.ncb << 8) | p3.spt;
   if (ft::cd_plan(d, &pl) != FT_OK) return -1;
   return ((pl.ksplit + 1) << 24) | ((pl.nc1 + pl.nc2) << 12) | pl.ncb;
 }
@@ -1319,7 +1606,8 @@ extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, 
     const dim3 pg(ceil_div(total, 256));
     const half_t* wsrc = static_cast<const half_t*>(w_packed);
     uint4_t* wdst = static_cast<uint4_t*>(wstream);
-    if (p3.stride == 2) hipLaunchKernelGGL(c3s2_pack_kernel<2>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
+    if (p3.stride == 2 && p3.ipw == 2) hipLaunchKernelGGL(c3s2p_pack_kernel, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
+    else if (p3.stride == 2) hipLaunchKernelGGL(c3s2_pack_kernel<2>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
     else if (p3.spt == 4) hipLaunchKernelGGL(c3_pack_kernel<4>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
     else hipLaunchKernelGGL(c3_pack_kernel<2>, pg, dim3(256), 0, as_stream(stream), wsrc, wdst, p3.ncb, kpad, cout_pad);
     FT_LAUNCH_CHECK("c3_pack_kernel");
@@ -1370,6 +1658,11 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
     q.x_bytes = (unsigned)((size_t)d->N * q.HW * d->x_cstride * 2);
     q.y_bytes = (unsigned)((size_t)q.M * d->y_cstride * 2);
     q.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+    if (p3.stride == 2 && p3.ipw == 2) {
+      const int nld = (2 * q.HW * 256 + 4095) / 4096;            // 1-KiB tile pieces per wave
+      if (p3.mt <= 2) return nld <= 16 ? c3s2p_launch<2, 16>(q, as_stream(stream)) : c3s2p_launch<2, 32>(q, as_stream(stream));
+      return nld <= 24 ? c3s2p_launch<3, 24>(q, as_stream(stream)) : c3s2p_launch<3, 32>(q, as_stream(stream));
+    }
     if (p3.stride == 2) return p3.mt == 1 ? c3s2_launch<1, 2>(q, as_stream(stream)) : c3s2_launch<2, 2>(q, as_stream(stream));
     if (p3.spt == 4) return c3_launch<2, 4>(q, as_stream(stream));
     return p3.mt == 3 ? c3_launch<3, 2>(q, as_stream(stream)) : c3_launch<4, 2>(q, as_stream(stream));

@@ -156,6 +156,11 @@ GATHER_CASES = [
     ("s2_whole_flownet_conv6", 4, 12, 16, 512, 1024, 2, "leaky", 32),   # FlowNetS conv6: 16 channel blocks, LeakyReLU, input slice
     ("s2_whole_one_tile", 5, 8, 6, 512, 128, 2, "relu", 0),      # Ho x Wo = 4 x 3: one pixel tile (MT = 1)
     ("s2_whole_16x16", 2, 16, 16, 512, 64, 2, "relu", 0),        # the largest input map (256 pixels), 64 output pixels exactly
+    # enough (image pair, channel block) workgroups for the TWO-images-per-workgroup form (conv3x3s2p_direct_kernel: four passes of
+    # 128 channels, K split by channel half x tap parity) — l4_entry_conv2 above takes it as well (32 pairs x 8 blocks)
+    ("s2_pair_odd_batch", 51, 12, 16, 512, 512, 2, "leaky", 32), # the last workgroup's second image does not exist; input slice
+    ("s2_pair_small_map", 50, 8, 8, 512, 512, 2, "relu", 0),     # 2 x 16 output pixels: one of the kernel's two pixel tiles is empty
+    ("s2_pair_odd_map", 56, 13, 9, 512, 512, 2, "relu", 0),      # Ho x Wo = 7 x 5 per image: 70 output pixels, ragged third tile
 ]
 
 
