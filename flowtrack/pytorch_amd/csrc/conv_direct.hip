@@ -424,6 +424,7 @@ struct C3Params {
   const float* shift;
   int M, HW, W, H, ipw;        // pixels, map size, images per workgroup (stride-2 form: the INPUT map; M = output pixels)
   int Ho, Wo;                  // stride-2 form: output map (0 in the stride-1 form)
+  int strip_rows, nstrips;     // stride-1 STRIP form (0: whole images): output rows per workgroup, strips per image
   int x_cstride, x_coff, y_cstride, y_coff;
   int Cout, act;
   float slope;
@@ -431,15 +432,19 @@ struct C3Params {
   unsigned x_bytes, y_bytes, ws_bytes;
 };
 
-template <int MT, int SPT>     // pixel tiles per workgroup; 4-slice steps per tap per wave (= C / 256)
+// TT > MT: the STRIP form for maps too large to be resident whole (FlowNet's conv5_1 on 12 x 16, FlowNetS.py:30): a workgroup owns
+// p.strip_rows output rows of one image; its tile holds those rows plus one halo row above and below ((strip_rows + 2) * W <=
+// TT * 32 tile rows; rows outside the image are out-of-range loads = zeros, so only the x borders need the tap mask).
+template <int MT, int SPT, int TT = MT>     // output pixel tiles per workgroup; 4-slice steps per tap per wave (= C / 256); tile row tiles
 __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = SPT * 256, ROWB = C * 2, BN = 64, NTILE = 2 * MT;
-  constexpr int TROWS = MT * 32;
+  constexpr int TROWS = MT * 32, TILE_ROWS = TT * 32;
+  constexpr bool STRIP = TT != MT;
   constexpr int ZROW = 131072, TAB = ZROW + ROWB, STG = TAB + 2 * BN * 4, STG_ROWB = BN * 2;
   constexpr int PART = 4 * NTILE * 4096;
   constexpr int NSTEP = 9 * SPT;
-  static_assert(TROWS * ROWB <= ZROW && PART <= ZROW && STG + TROWS * STG_ROWB <= 163840 && ZROW % ROWB == 0, "LDS map");
+  static_assert(TILE_ROWS * ROWB <= ZROW && PART <= ZROW && STG + TROWS * STG_ROWB <= 163840 && ZROW % ROWB == 0, "LDS map");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   using c0 = std::integral_constant<int, 0>;
@@ -455,8 +460,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int cb = logical % p.ncb, pt = logical / p.ncb;
-  const int npix = p.ipw * p.HW;                    // pixels of this workgroup's images
-  const int m0 = pt * npix;
+  // whole images: tile rows = output pixels = the pixels of ipw images.  Strip: the tile starts one image row above the strip.
+  int npix, m0, tile_m0, tile_rows;
+  if constexpr (STRIP) {
+    const int n = pt / p.nstrips, y0 = (pt - n * p.nstrips) * p.strip_rows;
+    const int rows = p.H - y0 < p.strip_rows ? p.H - y0 : p.strip_rows;
+    npix = rows * p.W;
+    m0 = n * p.HW + y0 * p.W;
+    tile_m0 = m0 - p.W;                             // (may be negative / run past the image: masked row by row below)
+    tile_rows = (rows + 2) * p.W;
+  } else {
+    npix = p.ipw * p.HW;                            // pixels of this workgroup's images
+    m0 = pt * npix;
+    tile_m0 = m0;
+    tile_rows = npix;
+  }
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
@@ -466,15 +484,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p
   //      16-byte position ^= row & 15) on the source side
   constexpr int CPR = ROWB / 16, RPL = 1024 / ROWB > 0 ? 1024 / ROWB : 1;
   constexpr int LPR = ROWB > 1024 ? ROWB / 1024 : 1;   // wave loads per row (C = 1024: 2)
-  constexpr int NLOAD = TROWS * ROWB / 1024 / 4;       // wave loads per wave
+  constexpr int NLOAD = TILE_ROWS * ROWB / 1024 / 4;   // wave loads per wave
 #pragma unroll
   for (int t = 0; t < NLOAD; ++t) {
     const int piece = t * 4 + wave;
     const int row = ROWB > 1024 ? piece / LPR : piece * RPL + lane / CPR;
     const int pos = ROWB > 1024 ? (piece % LPR) * 64 + lane : lane % CPR;
-    const int m = m0 + row;
-    const unsigned voff = (row < npix && m < p.M)
-                              ? (unsigned)((m * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)) : kOOB;
+    const int m = tile_m0 + row;
+    bool ok = row < tile_rows && m < p.M;
+    if constexpr (STRIP) {                            // halo rows above / below the image: out of range = zeros
+      const int img0 = (m0 / p.HW) * p.HW;
+      ok = row < tile_rows && m >= img0 && m < img0 + p.HW;
+    }
+    const unsigned voff = ok ? (unsigned)((m * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)) : kOOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + piece * 1024), 16, voff, 0, 0, 0);
   }
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -502,14 +524,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int pp = j * 32 + l31;
-    pix[j] = pp;
+    pix[j] = STRIP ? pp + p.W : pp;                  // tile row of the pixel itself (the strip's tile starts one image row higher)
     int mk = 0;
     if (pp < npix) {
-      const int rem = pp % p.HW, yy = rem / p.W, xx = rem - yy * p.W;
+      const int rem = pp % p.HW, yy = rem / p.W, xx = STRIP ? pp % p.W : rem - yy * p.W;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ny = yy + t / 3 - 1, nx = xx + t % 3 - 1;
-        if ((unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
+        // strip: rows above / below the image are zero rows OF THE TILE, only the x borders need the mask
+        if ((STRIP || (unsigned)ny < (unsigned)p.H) && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
       }
     }
     tmask[j] = mk;
@@ -696,10 +719,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2_direct_kernel(const C3Params
     const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int cb = logical % p.ncb, n = logical / p.ncb;
-  const int npix_in = p.HW;                         // input pixels of this workgroup's image
-  const int npix = p.Ho * p.Wo;                     // its output pixels
-  const int m0 = n * npix;
+  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  // whole image: the tile is the image's input map.  STRIP form (p.strip_rows > 0: maps of more than 256 input pixels, FlowNet's
+  // conv5 on 24 x 32): the workgroup owns strip_rows output rows; its tile = the 2 R + 1 input rows under them (rows outside the
+  // image are out-of-range loads = zeros: only the x borders need the tap mask)
+  const bool strip = p.strip_rows > 0;
+  int n = pt, npix = p.Ho * p.Wo, m0, tile0 = 0, tile_rows = p.HW;
+  if (strip) {
+    n = pt / p.nstrips;
+    const int y0 = (pt - n * p.nstrips) * p.strip_rows;
+    const int rows = p.Ho - y0 < p.strip_rows ? p.Ho - y0 : p.strip_rows;
+    npix = rows * p.Wo;
+    m0 = n * p.Ho * p.Wo + y0 * p.Wo;
+    tile0 = (2 * y0 - 1) * p.W;                     // first tile row as a pixel index of the image (negative for the top strip)
+    tile_rows = (2 * rows + 1) * p.W;
+  } else {
+    m0 = n * npix;
+  }
+  const int npix_in = p.HW;                         // input pixels of an image
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
@@ -713,7 +750,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2_direct_kernel(const C3Params
   for (int t = 0; t < NLOAD; ++t) {
     const int piece = t * 4 + wave;
     const int row = piece * 2 + (lane >> 5), pos = lane & 31;
-    x_voff[t] = row < npix_in ? (unsigned)(((n * npix_in + row) * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)) : kOOB;
+    const int ip = tile0 + row;                     // pixel of the image this tile row holds
+    x_voff[t] = (row < tile_rows && (unsigned)ip < (unsigned)npix_in)
+                    ? (unsigned)(((n * npix_in + ip) * p.x_cstride + p.x_coff) * 2 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)) : kOOB;
   }
   // The tile travels THROUGH REGISTERS (32 x 16 bytes per lane), not by LDS-DMA: the DMA path delivers ~25 GB/s per CU (98 KiB =
   // 3.9 us, exposed once per pass: 33 us for the layer on 512 workgroups), the register path several times that, and — the point —
@@ -758,12 +797,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2_direct_kernel(const C3Params
     int mk = 0, ib = 0;
     if (pp < npix) {
       const int oy = pp / p.Wo, ox = pp - oy * p.Wo;
-      const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+      const int iy0 = strip ? 2 * oy : 2 * oy - 1, ix0 = 2 * ox - 1;    // (a strip's tile starts at input row 2 y0 - 1)
       ib = iy0 * p.W + ix0;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ny = iy0 + t / 3, nx = ix0 + t % 3;
-        if ((unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
+        if ((strip || (unsigned)ny < (unsigned)p.H) && (unsigned)nx < (unsigned)p.W) mk |= 1 << t;
       }
     }
     ibase[j] = ib;
@@ -1198,6 +1237,7 @@ __global__ __launch_bounds__(256) void c3s2p_pack_kernel(const half_t* __restric
 
 struct C3Plan {
   int mt, spt, ipw, npt, ncb, stride;
+  int strip_rows = 0, nstrips = 0;
 };
 
 static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
@@ -1211,8 +1251,22 @@ static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
   if (d->stride == 2) {
     // one image per workgroup, its whole INPUT map (<= 256 pixels) resident 256 channels at a time (conv3x3s2_direct_kernel)
     static const bool no_s2 = getenv("FT_CD_NO_S2") != nullptr;                                   // dev A/B
-    if (no_s2 || d->Ho != (d->Hi + 1) / 2 || d->Wo != (d->Wi + 1) / 2 || hw > 256 || d->Ho * d->Wo > 64) return FT_ERR_UNSUPPORTED;
+    if (no_s2 || d->Ho != (d->Hi + 1) / 2 || d->Wo != (d->Wi + 1) / 2) return FT_ERR_UNSUPPORTED;
     if (d->Cin != 512) return FT_ERR_UNSUPPORTED;                // (instantiated for two 256-channel passes)
+    if (hw > 256 || d->Ho * d->Wo > 64) {
+      // strips of R output rows: (2 R + 1) * Wi <= 256 tile rows, R * Wo <= 64 output pixels (FlowNet's conv5 on 24 x 32: R = 3)
+      static const bool no_strip = getenv("FT_CD_NO_STRIP") != nullptr;                            // dev A/B
+      int R = (256 / d->Wi - 1) / 2;
+      if (R * d->Wo > 64) R = 64 / d->Wo;
+      if (no_strip || R < 1) return FT_ERR_UNSUPPORTED;
+      const int nstrips = (d->Ho + R - 1) / R;
+      const long long nwg = (long long)d->N * nstrips * (d->Cout / 64);
+      if (nwg < 200 || nwg > 1024) return FT_ERR_UNSUPPORTED;
+      if ((long long)d->N * hw * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2 >= (1LL << 31))
+        return FT_ERR_UNSUPPORTED;
+      *out = C3Plan{(R * d->Wo + 31) / 32, d->Cin / 256, 1, d->N * nstrips, d->Cout / 64, 2, R, nstrips};
+      return FT_OK;
+    }
     if ((long long)d->N * hw * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2 >= (1LL << 31))
       return FT_ERR_UNSUPPORTED;
     // two images per workgroup (conv3x3s2p_direct_kernel: half the weight stream per output pixel) where that still gives about one
@@ -1228,9 +1282,22 @@ static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
   }
   if (d->Ho != d->Hi || d->Wo != d->Wi) return FT_ERR_UNSUPPORTED;
   if (d->Cin != 512 && d->Cin != 1024) return FT_ERR_UNSUPPORTED;   // (instantiated for the 512-plane stage and FlowNet's conv6_1)
-  if (hw > (d->Cin == 512 ? 128 : 64)) return FT_ERR_UNSUPPORTED;  // the tile (every channel of the workgroup's images) must fit 128 KiB
   const long long M = (long long)d->N * hw;
   if (M * d->x_cstride * 2 >= (1LL << 31) || M * d->y_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
+  if (d->Cin == 512 && hw > 128) {
+    // maps too large to be resident whole: strips of R output rows + a halo row on either side, (R + 2) * W <= 128 tile rows and
+    // R * W <= 96 output pixels (FlowNet's conv5_1 on 12 x 16: R = 6), where that gives about one workgroup per CU or more
+    static const bool no_strip = getenv("FT_CD_NO_STRIP") != nullptr;                              // dev A/B
+    int R = 128 / d->Wi - 2;
+    if (R * d->Wi > 96) R = 96 / d->Wi;
+    if (no_strip || R < 2) return FT_ERR_UNSUPPORTED;
+    const int nstrips = (d->Hi + R - 1) / R;
+    const long long nwg = (long long)d->N * nstrips * (d->Cout / 64);
+    if (nwg < 200 || nwg > 1024) return FT_ERR_UNSUPPORTED;
+    *out = C3Plan{3, 2, 1, d->N * nstrips, d->Cout / 64, 1, R, nstrips};
+    return FT_OK;
+  }
+  if (hw > (d->Cin == 512 ? 128 : 64)) return FT_ERR_UNSUPPORTED;  // the tile (every channel of the workgroup's images) must fit 128 KiB
   const int ipw = d->Cin == 512 ? (hw <= 96 ? 96 / hw : 1) : 1;
   const int mt = d->Cin == 512 ? (ipw * hw <= 96 ? 3 : 4) : 2;
   *out = C3Plan{mt, d->Cin / 256, ipw, (d->N + ipw - 1) / ipw, d->Cout / 64, 1};
@@ -1257,9 +1324,9 @@ static int c3s2_launch(const C3Params& p, hipStream_t s) {
   return FT_OK;
 }
 
-template <int MT, int SPT>
+template <int MT, int SPT, int TT = MT>
 static int c3_launch(const C3Params& p, hipStream_t s) {
-  auto k = conv3x3_direct_kernel<MT, SPT>;
+  auto k = conv3x3_direct_kernel<MT, SPT, TT>;
   constexpr int lds = 131072 + SPT * 512 + 2 * 64 * 4 + MT * 32 * 128;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -1651,6 +1718,7 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
     q.shift = shift;
     q.HW = d->Hi * d->Wi; q.W = d->Wi; q.H = d->Hi; q.ipw = p3.ipw;
     q.Ho = p3.stride == 2 ? d->Ho : 0; q.Wo = p3.stride == 2 ? d->Wo : 0;
+    q.strip_rows = p3.strip_rows; q.nstrips = p3.nstrips;
     q.M = p3.stride == 2 ? d->N * d->Ho * d->Wo : d->N * q.HW;
     q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.y_cstride = d->y_cstride; q.y_coff = d->y_coff;
     q.Cout = d->Cout; q.act = d->act; q.slope = d->slope;
@@ -1664,6 +1732,7 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
       return nld <= 24 ? c3s2p_launch<3, 24>(q, as_stream(stream)) : c3s2p_launch<3, 32>(q, as_stream(stream));
     }
     if (p3.stride == 2) return p3.mt == 1 ? c3s2_launch<1, 2>(q, as_stream(stream)) : c3s2_launch<2, 2>(q, as_stream(stream));
+    if (p3.strip_rows) return c3_launch<3, 2, 4>(q, as_stream(stream));
     if (p3.spt == 4) return c3_launch<2, 4>(q, as_stream(stream));
     return p3.mt == 3 ? c3_launch<3, 2>(q, as_stream(stream)) : c3_launch<4, 2>(q, as_stream(stream));
   }

@@ -71,6 +71,8 @@ class DeconvResnet(HipModule):
     #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
     #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
     keypoints_in_plan = None
+    #: dev: layer1 + layer2 as two half-batch lanes (parallel graph branches); FT_SPLIT_LANES=1
+    split_lanes: int = int(os.environ.get("FT_SPLIT_LANES", "0") or 0)     # 1: lanes start together; 2: the second lane starts with its half of the stem
     #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
     fuse_heatmap: bool = os.environ.get("FT_FUSE_HEATMAP", "1") != "0"
     #: forward_keypoint_rows_exact(): a crop is re-run in the fp32 parity arithmetic when ft_heatmap_argmax_screen flags it:
@@ -153,94 +155,52 @@ class DeconvResnet(HipModule):
         stem = self.fused("conv1" + ("+maxpool" if pool_in_stem else ""), self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(),
                           act="relu", **mk)
         cur = new_act(B, H // 4, W // 4, 64, dtype, device)
-        if pool_in_stem:
+        split = self.split_lanes if (dtype == torch.float16 and B % 2 == 0 and B >= 32 and pool_in_stem) else 0
+        if split == 2:
+            stem.record(prog, a_in.batch_slice(0, B // 2), cur.batch_slice(0, B // 2), pool=True)     # (the other half: on the second lane)
+        elif pool_in_stem:
             stem.record(prog, a_in, cur, pool=True)
         else:
             a1 = new_act(B, H // 2, W // 2, 64, dtype, device)
             stem.record(prog, a_in, a1)
             record_maxpool(prog, a1, cur)
 
+        # FT_SPLIT_LANES=1 (dev, measured in profiles/README.md): layer1 + layer2 as TWO half-batch lanes (parallel graph branches).
+        # Their fused blocks are phase-locked across the chip — every workgroup reads its input, then multiplies, then writes, at
+        # the same time, so HBM idles while the matrix pipe runs and vice versa; two lanes half a block apart overlap them.
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), start=1):
+            if split and li == 1:
+                chain = []
+                hh, ww = cur.H, cur.W
+                for lj, lay in ((1, self.layer1), (2, self.layer2)):
+                    for bi, blk in enumerate(lay):
+                        hh, ww = hh // blk.stride, ww // blk.stride
+                        chain.append((f"layer{lj}.{bi}", blk, new_act(B, hh, ww, blk.conv1.cout * 4, dtype, device)))
+                prog.fork()
+                for half, (lo, hi) in enumerate(((0, B // 2), (B // 2, B))):
+                    c = cur.batch_slice(lo, hi)
+                    if half == 1:
+                        with prog.side():
+                            if split == 2:      # half a block of useful delay: the lanes' memory and matrix phases interleave
+                                stem.record(prog, a_in.batch_slice(lo, hi), cur.batch_slice(lo, hi), pool=True)
+                            for name, blk, out_full in chain:
+                                o = out_full.batch_slice(lo, hi)
+                                self._record_block(prog, name, blk, c, o, dtype, device)
+                                c = o
+                    else:
+                        for name, blk, out_full in chain:
+                            o = out_full.batch_slice(lo, hi)
+                            self._record_block(prog, name, blk, c, o, dtype, device)
+                            c = o
+                prog.join()
+                cur = chain[-1][2]
+                continue
+            if split and li == 2:
+                continue
             for bi, blk in enumerate(layer):
                 name = f"layer{li}.{bi}"
-                planes = blk.conv1.cout
-                s = blk.stride
-                Ho, Wo = cur.H // s, cur.W // s
-                c1 = self.fused(name + ".conv1", blk.conv1.weight, bn=blk.bn1.as_dict(), act="relu", **mk)
-                c2 = self.fused(name + ".conv2", blk.conv2.weight, stride=s, pad=1, bn=blk.bn2.as_dict(), act="relu", **mk)
-                c3 = self.fused(name + ".conv3", blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", **mk)
-                out = new_act(B, Ho, Wo, planes * 4, dtype, device)
-                if self.fuse_bottleneck and not len(blk.downsample) and s == 1 and bottleneck_fusable(c1, c2, c3, cur, out):
-                    # the whole block in one launch (t1 / t2 never leave LDS) or as three conv launches: which one is faster
-                    # depends on how many workgroups the stage's pixels make (each streams the block's whole weight set),
-                    # so both are recorded and the first-call benchmark keeps one (Program.tune_choices)
-                    t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
-                    t2 = new_act(B, Ho, Wo, planes, dtype, device)
-
-                    def fused_form():
-                        record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
-
-                    def conv_form():
-                        c1.record(prog, cur, t1)
-                        c2.record(prog, t1, t2)
-                        c3.record(prog, t2, out, residual=cur)
-                    forms = (("fused", fused_form), ("convs", conv_form))
-                    if not bottleneck_prefers_fused(cur, planes):
-                        forms = forms[::-1]
-                    prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
-                    for form_name, form in forms:
-                        prog.option(form_name)
-                        form()
-                    prog.end_choice()
-                    cur = out
-                    continue
-                t2 = new_act(B, Ho, Wo, planes, dtype, device)
-                fused = None
-                if len(blk.downsample) and self.fuse_shortcut:
-                    key = (name + ".conv3+downsample", dtype, str(device))
-                    fused = self._layers.get(key)
-                    if fused is None:
-                        fused = self._layers[key] = FusedShortcutConv(
-                            blk.conv3.weight, blk.bn3.as_dict(), blk.downsample[0].weight, blk.downsample[1].as_dict(), s,
-                            dtype=dtype, device=device, act="relu", label=name + ".conv3+downsample")
-                whole = self.fuse_bottleneck and fused is not None and bottleneck_entry_fusable(c1, c2, fused, cur, out)
-                if whole:
-                    # the 64-wide entry block whole (t1, t2 and the shortcut never leave the CU) or as head + K-concatenated
-                    # conv3: both recorded, the first-call benchmark keeps one
-                    prog.begin_choice(f"entry|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
-                    prog.option("fused")
-                    record_bottleneck_entry(prog, c1, c2, fused, cur, out, name + ".fused")
-                    prog.option("head+exit")
-                if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
-                    record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
-                else:
-                    head2 = self.fuse_bottleneck and s == 2 and bottleneck_head_stream_fusable(c1, c2, cur, t2)
-                    if head2:
-                        # the 256-plane entry block's conv1 + stride-2 conv2 as one streamed-weights launch, or as two launches:
-                        # both recorded, the first-call benchmark keeps one (the recorder's first choice: two launches)
-                        prog.begin_choice(f"head2|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{t2.cstride}")
-                        prog.option("convs")
-                    t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
-                    c1.record(prog, cur, t1)
-                    c2.record(prog, t1, t2)
-                    if head2:
-                        prog.option("fused")
-                        record_bottleneck_head_stream(prog, c1, c2, cur, t2, name + ".conv1+conv2")
-                        prog.end_choice()
-                if fused is not None:
-                    # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
-                    # the shortcut tensor never exists in HBM
-                    fused.record(prog, t2, cur, out)
-                elif len(blk.downsample):
-                    ds = self.fused(name + ".downsample", blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(),
-                                    act=None, **mk)
-                    res = new_act(B, Ho, Wo, planes * 4, dtype, device)
-                    ds.record(prog, cur, res)
-                    c3.record(prog, t2, out, residual=res)
-                else:
-                    c3.record(prog, t2, out, residual=cur)  # relu(bn3(conv3) + residual), blocks.py:114-119
-                if whole:
-                    prog.end_choice()
+                out = new_act(B, cur.H // blk.stride, cur.W // blk.stride, blk.conv1.cout * 4, dtype, device)
+                self._record_block(prog, name, blk, cur, out, dtype, device)
                 cur = out
 
         # head: 3 x (ConvTranspose 4/2/1 + bn + relu), then the 1x1 heatmap conv (pose_deconv.py:43-45) — fused behind
@@ -274,6 +234,89 @@ class DeconvResnet(HipModule):
             prog.add("ft_heatmap_keypoint_rows", heatmaps.data_ptr(), B, K, hh, hw, int(bool(self.keypoints_in_plan)),
                      plan.kp_idx.data_ptr(), plan.kp_rows.data_ptr(), keep=(plan.kp_idx, plan.kp_rows))
         return plan
+
+    def _record_block(self, prog, name: str, blk, cur, out, dtype, device) -> None:
+        """One Bottleneck (blocks.py:83-120) from view `cur` into view `out` (both may be batch slices of larger buffers): the
+        fused / unfused forms are recorded as alternatives where both exist, the first-call benchmark keeps one."""
+        B = cur.N
+        mk = dict(dtype=dtype, device=device)
+        planes = blk.conv1.cout
+        s = blk.stride
+        Ho, Wo = cur.H // s, cur.W // s
+        c1 = self.fused(name + ".conv1", blk.conv1.weight, bn=blk.bn1.as_dict(), act="relu", **mk)
+        c2 = self.fused(name + ".conv2", blk.conv2.weight, stride=s, pad=1, bn=blk.bn2.as_dict(), act="relu", **mk)
+        c3 = self.fused(name + ".conv3", blk.conv3.weight, bn=blk.bn3.as_dict(), act="relu", **mk)
+        if self.fuse_bottleneck and not len(blk.downsample) and s == 1 and bottleneck_fusable(c1, c2, c3, cur, out):
+            # the whole block in one launch (t1 / t2 never leave LDS) or as three conv launches: which one is faster
+            # depends on how many workgroups the stage's pixels make (each streams the block's whole weight set),
+            # so both are recorded and the first-call benchmark keeps one (Program.tune_choices)
+            t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
+            t2 = new_act(B, Ho, Wo, planes, dtype, device)
+
+            def fused_form():
+                record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
+
+            def conv_form():
+                c1.record(prog, cur, t1)
+                c2.record(prog, t1, t2)
+                c3.record(prog, t2, out, residual=cur)
+            forms = (("fused", fused_form), ("convs", conv_form))
+            if not bottleneck_prefers_fused(cur, planes):
+                forms = forms[::-1]
+            prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
+            for form_name, form in forms:
+                prog.option(form_name)
+                form()
+            prog.end_choice()
+            return
+        t2 = new_act(B, Ho, Wo, planes, dtype, device)
+        fused = None
+        if len(blk.downsample) and self.fuse_shortcut:
+            key = (name + ".conv3+downsample", dtype, str(device))
+            fused = self._layers.get(key)
+            if fused is None:
+                fused = self._layers[key] = FusedShortcutConv(
+                    blk.conv3.weight, blk.bn3.as_dict(), blk.downsample[0].weight, blk.downsample[1].as_dict(), s,
+                    dtype=dtype, device=device, act="relu", label=name + ".conv3+downsample")
+        whole = self.fuse_bottleneck and fused is not None and bottleneck_entry_fusable(c1, c2, fused, cur, out)
+        if whole:
+            # the 64-wide entry block whole (t1, t2 and the shortcut never leave the CU) or as head + K-concatenated
+            # conv3: both recorded, the first-call benchmark keeps one
+            prog.begin_choice(f"entry|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
+            prog.option("fused")
+            record_bottleneck_entry(prog, c1, c2, fused, cur, out, name + ".fused")
+            prog.option("head+exit")
+        if self.fuse_bottleneck and s == 1 and bottleneck_head_fusable(c1, c2, cur, t2):
+            record_bottleneck_head(prog, c1, c2, cur, t2, name + ".conv1+conv2")   # the 64-wide entry block: t1 in LDS only
+        else:
+            head2 = self.fuse_bottleneck and s == 2 and bottleneck_head_stream_fusable(c1, c2, cur, t2)
+            if head2:
+                # the 256-plane entry block's conv1 + stride-2 conv2 as one streamed-weights launch, or as two launches:
+                # both recorded, the first-call benchmark keeps one (the recorder's first choice: two launches)
+                prog.begin_choice(f"head2|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{t2.cstride}")
+                prog.option("convs")
+            t1 = new_act(B, cur.H, cur.W, planes, dtype, device)
+            c1.record(prog, cur, t1)
+            c2.record(prog, t1, t2)
+            if head2:
+                prog.option("fused")
+                record_bottleneck_head_stream(prog, c1, c2, cur, t2, name + ".conv1+conv2")
+                prog.end_choice()
+        if fused is not None:
+            # conv3 + bn3 and the projection shortcut as one GEMM over K = [t2 | block input] (blocks.py:104-119):
+            # the shortcut tensor never exists in HBM
+            fused.record(prog, t2, cur, out)
+        elif len(blk.downsample):
+            ds = self.fused(name + ".downsample", blk.downsample[0].weight, stride=s, bn=blk.downsample[1].as_dict(),
+                            act=None, **mk)
+            res = new_act(B, Ho, Wo, planes * 4, dtype, device)
+            ds.record(prog, cur, res)
+            c3.record(prog, t2, out, residual=res)
+        else:
+            c3.record(prog, t2, out, residual=cur)  # relu(bn3(conv3) + residual), blocks.py:114-119
+        if whole:
+            prog.end_choice()
+
 
     def plan_for(self, B: int, H: int, W: int, replica: int = 0) -> _PosePlan:
         """The plan (launch list + activation buffers + graph) of one input shape.  `replica` > 0 gives an independent copy

@@ -109,6 +109,8 @@ def test_direct_shortcut_conv_matches_oracle_and_igemm(hip_lib, case, monkeypatc
 
 
 @pytest.mark.parametrize("case", [("l4_conv2_8x6", 64, 8, 6), ("odd_batch", 5, 8, 6), ("r101_12x9", 7, 12, 9), ("tiny_3x5", 3, 3, 5),
+                                  # maps of more than 128 pixels at 512 channels: strips of R output rows + halo rows (FlowNet's conv5_1)
+                                  ("flownet_conv5_1_strips", 16, 12, 16), ("strips_ragged_last", 9, 13, 16), ("strips_w10", 9, 20, 10),
                                   ("flownet_conv6_1_c1024", 5, 6, 8, 1024), ("c1024_full_tile_8x8", 2, 8, 8, 1024), ("c1024_tiny", 3, 2, 3, 1024)],
                          ids=lambda c: c[0])
 def test_direct_conv3x3_whole_maps_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
@@ -161,6 +163,9 @@ GATHER_CASES = [
     ("s2_pair_odd_batch", 51, 12, 16, 512, 512, 2, "leaky", 32), # the last workgroup's second image does not exist; input slice
     ("s2_pair_small_map", 50, 8, 8, 512, 512, 2, "relu", 0),     # 2 x 16 output pixels: one of the kernel's two pixel tiles is empty
     ("s2_pair_odd_map", 56, 13, 9, 512, 512, 2, "relu", 0),      # Ho x Wo = 7 x 5 per image: 70 output pixels, ragged third tile
+    # input maps of more than 256 pixels: strips of R output rows over their 2 R + 1 input rows (FlowNetS conv5: 24 x 32 -> 12 x 16, R = 3)
+    ("s2_strips_flownet_conv5", 16, 24, 32, 512, 512, 2, "leaky", 0),
+    ("s2_strips_ragged", 9, 26, 20, 512, 512, 2, "relu", 32),    # Ho = 13 = 5 + 5 + 3 rows, odd input height, input slice
 ]
 
 
