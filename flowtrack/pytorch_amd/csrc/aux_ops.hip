@@ -375,6 +375,131 @@ __global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __rest
 
 // fast path of the above (W % 4 == 0, 16-byte aligned planes): one thread = 4 consecutive pixels = six 16-byte planar reads
 // and 64 (mode 0) / 2 x 32 (mode 1) contiguous output bytes; the first / last thread of a row also zero the pad columns.
+// ---- rgb mean + normalise + pack in ONE launch (round 4) ------------------------------------------------------------------
+// FlowNet2S starts with two passes over the frame pair: the per-sample, per-colour mean over both frames (models.py:255) and
+// (x - mean) / rgb_max into the stem's row-packed layout — 21.9 + 30.0 us at 16 x 512 x 384 for 75 MB read twice and 51 MB
+// written.  Here a workgroup keeps its share of a sample (R rows of all six planes: up to 72 float4 per lane, ~290 VGPRs, one
+// workgroup per CU) IN REGISTERS across the reduction: it sums its share, publishes the three partial sums as 8-byte
+// {epoch, value} granules (one sc1 store each: the data is the flag, no fence: cdna_hip_programming.md Guideline 16, form R2),
+// one wave sweeps the <= 21 x 3 granules of its sample until every tag carries this launch's epoch, every lane adds them in the
+// same fixed order, and the held pixels leave normalised.  The input is read ONCE.
+// Epoch without a memset node: every workgroup counts its own launches in a private word of `state` (all workgroups of a
+// sample have run equally often, so they agree); state is zeroed once at allocation.  Workgroups of a sample have consecutive
+// block ids and never wait for a later sample, so waiting cannot deadlock whatever else runs; the sweep is bounded (~0.1 s) and
+// on time-out the means are NaN and state's last word is set.
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+constexpr int kMpNit = 12;                 // 4-pixel groups per lane and plane: R * W / 4 <= 12 * 256
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void flow_mean_pack_pair_kernel(const float* __restrict__ in, float rgb_max, T* __restrict__ y,
+                                                                     float* __restrict__ mean_out, unsigned long long* state,
+                                                                     int H, int W, int R, int nW, int lpad, int wpitch,
+                                                                     unsigned long long* err) {
+  __shared__ float s_w[4][3];
+  __shared__ float s_val[64];
+  __shared__ unsigned s_epoch;
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / nW, w = blockIdx.x - b * nW;
+  const int r0 = w * R, rows = H - r0 < R ? H - r0 : R;
+  const int W4 = W >> 2, nitems = rows * W4;
+  const size_t HW = (size_t)H * W;
+  gu64_t* st = (gu64_t*)state + (size_t)b * 4 * nW;     // [0, 3 nW): granules; [3 nW, 4 nW): launch counts
+  if (tid == 0) {
+    const unsigned e = (unsigned)__hip_atomic_load(st + 3 * nW + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __hip_atomic_store(st + 3 * nW + w, (unsigned long long)(e == 0u ? 1u : e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_epoch = e == 0u ? 1u : e;
+    s_fail = 0;
+  }
+  // ---- this workgroup's share, all six planes, into registers
+  float4_t v[kMpNit][6];
+#pragma unroll
+  for (int it = 0; it < kMpNit; ++it) {
+    const int idx = it * 256 + tid;
+    const bool live = idx < nitems;
+    const int row = live ? idx / W4 : 0, g = live ? idx - row * W4 : 0;
+    const float* px = in + (size_t)b * 6 * HW + (size_t)(r0 + row) * W + 4 * g;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl)
+      v[it][pl] = live ? *reinterpret_cast<const float4_t*>(px + (size_t)pl * HW) : float4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  // ---- partial sums per colour (planes 2c, 2c + 1 = the colour's two frames), fixed order
+  float sc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < kMpNit; ++it)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float4_t q = v[it][2 * c + f];
+        sc[c] += (q[0] + q[1]) + (q[2] + q[3]);
+      }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sc[c] += __shfl_xor(sc[c], off);
+    if (lane == 0) s_w[wave][c] = sc[c];
+  }
+  __syncthreads();
+  const unsigned epoch = s_epoch;
+  if (tid < 3) {
+    const float part = (s_w[0][tid] + s_w[1][tid]) + (s_w[2][tid] + s_w[3][tid]);
+    __hip_atomic_store(st + w * 3 + tid, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(part),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                      // ONE aligned 8-byte sc1 store per granule
+  }
+  // ---- one wave sweeps the sample's granules until every tag is this launch's
+  if (wave == 0) {
+    const int ng = 3 * nW;
+    unsigned val = 0u;
+    bool ok = false;
+    for (unsigned spins = 0; ; ++spins) {
+      ok = true;
+      if (lane < ng) {
+        const unsigned long long x = __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        val = (unsigned)x;
+        ok = (unsigned)(x >> 32) == epoch;
+      }
+      if (__all(ok)) break;
+      if (spins >= (1u << 16)) { if (lane == 0) s_fail = 1; break; }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    s_val[lane] = __uint_as_float(val);
+  }
+  __syncthreads();
+  float m[3];
+  {
+    const float inv_L = 1.0f / (float)(2 * HW);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < nW; ++k) s += s_val[3 * k + c];
+      m[c] = s_fail ? __uint_as_float(0x7fc00000u) : s * inv_L;
+    }
+  }
+  if (s_fail && tid == 0) *err = 1ull;
+  if (w == 0 && tid < 3) mean_out[b * 3 + tid] = m[tid];
+  // ---- the held pixels leave normalised: (x - mean) / rgb_max in fp32, then the cast (flow_pack_pair4_kernel's arithmetic)
+  const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < kMpNit; ++it) {
+    const int idx = it * 256 + tid;
+    if (idx < nitems) {
+      const int row = idx / W4, g = idx - row * W4;
+      T* yr = y + ((size_t)b * H + r0 + row) * wpitch * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float o[8] = {(v[it][0][e] - m[0]) / rgb_max, (v[it][2][e] - m[1]) / rgb_max, (v[it][4][e] - m[2]) / rgb_max,
+                            (v[it][1][e] - m[0]) / rgb_max, (v[it][3][e] - m[1]) / rgb_max, (v[it][5][e] - m[2]) / rgb_max, 0.f, 0.f};
+        store8<T>(yr + (size_t)(lpad + 4 * g + e) * 8, o);
+      }
+      if (g == 0)
+        for (int xp = 0; xp < lpad; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+      if (g == W4 - 1)
+        for (int xp = lpad + W; xp < wpitch; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+    }
+  }
+}
+
 // Same arithmetic per element as the scalar kernel ((x - mean) / rgb_max in fp32, then the cast).
 template <typename T>
 __global__ __launch_bounds__(256) void flow_pack_pair4_kernel(const float* __restrict__ in, const float* __restrict__ mean,
@@ -675,6 +800,42 @@ extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float r
     hipLaunchKernelGGL(flow_pack_pair_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,
                        rgb_max, static_cast<float*>(y), B, H, W, lpad, wpitch, total, mode);
   FT_LAUNCH_CHECK("flow_pack_pair_kernel");
+  return FT_OK;
+}
+
+// rows per workgroup / workgroups per sample of flow_mean_pack_pair_kernel, or false where it does not apply
+static bool mean_pack_plan(int H, int W, int* R, int* nW) {
+  if (H <= 0 || W < 4 || (W & 3)) return false;
+  int r = (kMpNit * 256 * 4) / W;
+  if (r < 1) return false;
+  r = r < H ? r : H;
+  const int n = (H + r - 1) / r;
+  if (3 * n > 64) return false;                     // one lane per granule in the sweep
+  *R = (H + n - 1) / n;                             // same workgroup count, balanced rows
+  *nW = n;
+  return true;
+}
+
+extern "C" long long ft_flow_mean_pack_pair_state_words(int B, int H, int W) {
+  int R, nW;
+  if (B <= 0 || !mean_pack_plan(H, W, &R, &nW)) return 0;
+  return (long long)B * 4 * nW + 1;
+}
+
+extern "C" int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* y, int B, int H, int W, int lpad, int wpitch,
+                                      int dtype, unsigned long long* state, float* mean, ft_stream_t stream) {
+  if (!inputs || !y || !state || !mean || B <= 0 || rgb_max == 0.f || lpad < 0 || wpitch < lpad + W) return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
+  int R, nW;
+  if (!mean_pack_plan(H, W, &R, &nW) || (reinterpret_cast<uintptr_t>(inputs) & 15) != 0) return FT_ERR_UNSUPPORTED;
+  unsigned long long* err = state + (size_t)B * 4 * nW;
+  if (dtype == FT_F16)
+    hipLaunchKernelGGL(flow_mean_pack_pair_kernel<half_t>, dim3(B * nW), dim3(256), 0, as_stream(stream), inputs, rgb_max,
+                       static_cast<half_t*>(y), mean, state, H, W, R, nW, lpad, wpitch, err);
+  else
+    hipLaunchKernelGGL(flow_mean_pack_pair_kernel<float>, dim3(B * nW), dim3(256), 0, as_stream(stream), inputs, rgb_max,
+                       static_cast<float*>(y), mean, state, H, W, R, nW, lpad, wpitch, err);
+  FT_LAUNCH_CHECK("flow_mean_pack_pair_kernel");
   return FT_OK;
 }
 

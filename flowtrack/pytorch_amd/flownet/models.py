@@ -18,6 +18,7 @@ kernel; the x4 bilinear upsample folds in div_flow.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -409,6 +410,10 @@ def record_flownetfusion(prog: Program, p: FlowNetFusion, x: ActView, prefix: st
     return flow0
 
 
+#: FlowNet2S / SD: rgb mean + normalise + pack as one launch (ft_flow_mean_pack_pair); FT_FUSE_MEAN_PACK=0 keeps the two launches
+FUSE_MEAN_PACK = os.environ.get("FT_FUSE_MEAN_PACK", "1") != "0"
+
+
 class _FlowPlan:
     def __init__(self, prog, x_static, out):
         self.prog, self.x_static, self.out = prog, x_static, out
@@ -426,8 +431,20 @@ class _FlowBase(HipModule):
         the conv that reads it: 3 for the 7x7/s2 stems, 1 for FlowNetSD's 3x3/s1 conv0).  A mode may also be a
         (mode, pad) pair."""
         B, _, _, H, W = x_static.shape
-        partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
         mean = torch.empty((B * 3,), dtype=torch.float32, device=device)
+        modes = list(modes)
+        words = int(_lib.load().ft_flow_mean_pack_pair_state_words(B, H, W)) if FUSE_MEAN_PACK else 0
+        if words and len(modes) == 1 and (modes[0] == 0 or (isinstance(modes[0], tuple) and modes[0][0] == 0)):
+            # one 6-channel view (FlowNet2S / SD): mean + normalise + pack as ONE launch that reads the frame pair once
+            # (ft_flow_mean_pack_pair: the workgroups of a sample exchange their partial sums inside the launch)
+            vpad = modes[0][1] if isinstance(modes[0], tuple) else pad
+            view = new_rowpacked_act(B, H, W, 6, vpad, dtype, device)
+            state = torch.zeros((words,), dtype=torch.int64, device=device)         # zeroed once; private to this plan
+            prog.add("ft_flow_mean_pack_pair", x_static.data_ptr(), ctypes.c_float(self.rgb_max), view.t.data_ptr(), B, H, W,
+                     view.lpad, view.wpitch, _lib.dtype_code(dtype), state.data_ptr(), mean.data_ptr(),
+                     keep=(x_static, view.t, state, mean))
+            return [view]
+        partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
         prog.add("ft_flow_rgb_mean", x_static.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(),
                  keep=(x_static, partial, mean))
         outs = []

@@ -166,6 +166,43 @@ def test_resample2d_window_kernel_paths(hip_lib, oracle_lib):
         assert np.abs(out.cpu().numpy() - want).max() <= 1e-5, (B, C, H, W)
 
 
+def test_fused_mean_pack_pair_matches_the_two_launches(hip_lib):
+    """ft_flow_mean_pack_pair (rgb mean + (x - mean) / rgb_max + row-packing in ONE launch, the workgroups of a sample exchanging
+    their partial sums as tagged 8-byte words inside the launch; models.py:255-257) against ft_flow_rgb_mean + ft_flow_pack_pair:
+    the same mean up to the summation order, hence the same packed view up to that (fp32) and to the last fp16 bit almost
+    everywhere; pad columns zero; REPEATED launches on one state buffer with changing inputs (the epoch logic: a stale tag of the
+    previous launch must never satisfy the sweep); one / two / sixteen workgroups per sample; ragged last workgroup."""
+    from flowtrack.pytorch_amd.hip_ops import new_rowpacked_act
+    for (B, H, W, pad) in ((16, 384, 512, 3), (3, 130, 100, 3), (2, 64, 64, 1), (5, 50, 260, 3)):
+        words = int(hip_lib.ft_flow_mean_pack_pair_state_words(B, H, W))
+        assert words > 0
+        state = torch.zeros(words, dtype=torch.int64, device="cuda")
+        for dtype, tol in ((torch.float16, 1e-3), (torch.float32, 1e-6)):
+            for rep in range(3):
+                pair = (synth.frame_pairs(40 + rep, B, H, W) * (1.0 + 0.5 * rep)).cuda()
+                partial = torch.empty(B * 3 * _lib.FT_RGB_MEAN_SPLITS, device="cuda")
+                mean2 = torch.empty(B * 3, device="cuda")
+                want = new_rowpacked_act(B, H, W, 6, pad, dtype, "cuda")
+                want.t.fill_(5.0)
+                check(hip_lib.ft_flow_rgb_mean(pair.data_ptr(), B, H, W, partial.data_ptr(), mean2.data_ptr(), _stream()))
+                check(hip_lib.ft_flow_pack_pair(pair.data_ptr(), mean2.data_ptr(), ctypes.c_float(255.0), want.t.data_ptr(), B, H, W, 0,
+                                                want.lpad, want.wpitch, _lib.dtype_code(dtype), _stream()))
+                got = new_rowpacked_act(B, H, W, 6, pad, dtype, "cuda")
+                got.t.fill_(7.0)
+                mean1 = torch.empty(B * 3, device="cuda")
+                check(hip_lib.ft_flow_mean_pack_pair(pair.data_ptr(), ctypes.c_float(255.0), got.t.data_ptr(), B, H, W, got.lpad,
+                                                     got.wpitch, _lib.dtype_code(dtype), state.data_ptr(), mean1.data_ptr(), _stream()))
+                torch.cuda.synchronize()
+                assert int(state[-1]) == 0, "a workgroup timed out waiting for its sample's partial sums"
+                ref = pair.view(B, 3, -1).double().mean(-1).flatten().float()
+                assert (mean1 - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() and (mean1 - mean2).abs().max().item() <= 1e-3
+                d = (got.t.float() - want.t.float()).abs()
+                assert d.max().item() <= tol, (B, H, W, dtype, rep, d.max().item())
+                assert torch.all(got.t[:, :, :got.lpad] == 0) and torch.all(got.t[:, :, got.lpad + W:] == 0) and torch.all(got.t[..., 6:] == 0)
+    assert int(hip_lib.ft_flow_mean_pack_pair_state_words(2, 64, 62)) == 0          # W % 4 != 0: the two launches
+    assert int(hip_lib.ft_flow_mean_pack_pair_state_words(1, 2048, 2048)) == 0      # more than 21 workgroups per sample
+
+
 def test_upsample_and_normalise(hip_lib, oracle_lib):
     x = synth.normal(6, "flow2", (2, 2, 6, 9)).numpy()
     y = torch.empty((2, 2, 24, 36), dtype=torch.float32, device="cuda")
