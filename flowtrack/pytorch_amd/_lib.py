@@ -110,7 +110,8 @@ _PROTOTYPES = {
     "ft_flow_rgb_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ft_flow_pack_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 7 + [c_void_p]),
     "ft_flow_mean_pack_pair_state_words": (ctypes.c_longlong, [c_int, c_int, c_int]),
-    "ft_flow_mean_pack_pair": (c_int, [c_void_p, c_float, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p]),
+    "ft_flow_mean_pack_pair": (c_int, [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_int] * 4
+                               + [c_void_p, c_void_p, c_void_p]),
     "ft_upsample_bilinear4x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ft_correlation_out_shape": (c_int, [c_int] * 8 + [POINTER(c_int)] * 3),
     "ft_correlation_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

@@ -388,15 +388,16 @@ __global__ __launch_bounds__(256) void flow_pack_pair_kernel(const float* __rest
 // block ids and never wait for a later sample, so waiting cannot deadlock whatever else runs; the sweep is bounded (~0.1 s) and
 // on time-out the means are NaN and state's last word is set.
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-constexpr int kMpNit = 12;                 // 4-pixel groups per lane and plane: R * W / 4 <= 12 * 256
+constexpr int kMpNit = 6;                  // 4-pixel groups per lane and plane: R * W / 4 <= 6 * 256 (36 float4 per lane: two workgroups per CU)
 
 template <typename T>
-__global__ __launch_bounds__(256, 1) void flow_mean_pack_pair_kernel(const float* __restrict__ in, float rgb_max, T* __restrict__ y,
-                                                                     float* __restrict__ mean_out, unsigned long long* state,
-                                                                     int H, int W, int R, int nW, int lpad, int wpitch,
+__global__ __launch_bounds__(256, 2) void flow_mean_pack_pair_kernel(const float* __restrict__ in, float rgb_max, T* __restrict__ y,
+                                                                     T* __restrict__ y3, float* __restrict__ mean_out,
+                                                                     unsigned long long* state, int B, int H, int W, int R, int nW,
+                                                                     int lpad, int wpitch, int lpad3, int wpitch3,
                                                                      unsigned long long* err) {
   __shared__ float s_w[4][3];
-  __shared__ float s_val[64];
+  __shared__ float s_val[128];
   __shared__ unsigned s_epoch;
   __shared__ int s_fail;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -449,21 +450,25 @@ __global__ __launch_bounds__(256, 1) void flow_mean_pack_pair_kernel(const float
   }
   // ---- one wave sweeps the sample's granules until every tag is this launch's
   if (wave == 0) {
-    const int ng = 3 * nW;
-    unsigned val = 0u;
-    bool ok = false;
+    const int ng = 3 * nW;                           // <= 128: two granules per lane
+    unsigned val[2] = {0u, 0u};
     for (unsigned spins = 0; ; ++spins) {
-      ok = true;
-      if (lane < ng) {
-        const unsigned long long x = __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        val = (unsigned)x;
-        ok = (unsigned)(x >> 32) == epoch;
+      bool ok = true;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gi = lane + 64 * h;
+        if (gi < ng) {
+          const unsigned long long x = __hip_atomic_load(st + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          val[h] = (unsigned)x;
+          ok = ok && (unsigned)(x >> 32) == epoch;
+        }
       }
       if (__all(ok)) break;
       if (spins >= (1u << 16)) { if (lane == 0) s_fail = 1; break; }
       __builtin_amdgcn_s_sleep(32);
     }
-    s_val[lane] = __uint_as_float(val);
+    s_val[lane] = __uint_as_float(val[0]);
+    s_val[lane + 64] = __uint_as_float(val[1]);
   }
   __syncthreads();
   float m[3];
@@ -479,23 +484,45 @@ __global__ __launch_bounds__(256, 1) void flow_mean_pack_pair_kernel(const float
   if (s_fail && tid == 0) *err = 1ull;
   if (w == 0 && tid < 3) mean_out[b * 3 + tid] = m[tid];
   // ---- the held pixels leave normalised: (x - mean) / rgb_max in fp32, then the cast (flow_pack_pair4_kernel's arithmetic)
-  const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // y: the 6-channel view [B, H, wpitch, 8] (frame 0's colours, then frame 1's); y3: the siamese view [2 B, H, wpitch3, 4] (frame f
+  // of sample b = image f * B + b); either may be absent
+  const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, z4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < kMpNit; ++it) {
     const int idx = it * 256 + tid;
     if (idx < nitems) {
       const int row = idx / W4, g = idx - row * W4;
-      T* yr = y + ((size_t)b * H + r0 + row) * wpitch * 8;
+      float o[4][8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float o[8] = {(v[it][0][e] - m[0]) / rgb_max, (v[it][2][e] - m[1]) / rgb_max, (v[it][4][e] - m[2]) / rgb_max,
-                            (v[it][1][e] - m[0]) / rgb_max, (v[it][3][e] - m[1]) / rgb_max, (v[it][5][e] - m[2]) / rgb_max, 0.f, 0.f};
-        store8<T>(yr + (size_t)(lpad + 4 * g + e) * 8, o);
+        o[e][0] = (v[it][0][e] - m[0]) / rgb_max; o[e][1] = (v[it][2][e] - m[1]) / rgb_max; o[e][2] = (v[it][4][e] - m[2]) / rgb_max;
+        o[e][3] = (v[it][1][e] - m[0]) / rgb_max; o[e][4] = (v[it][3][e] - m[1]) / rgb_max; o[e][5] = (v[it][5][e] - m[2]) / rgb_max;
+        o[e][6] = 0.f; o[e][7] = 0.f;
       }
-      if (g == 0)
-        for (int xp = 0; xp < lpad; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
-      if (g == W4 - 1)
-        for (int xp = lpad + W; xp < wpitch; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+      if (y) {
+        T* yr = y + ((size_t)b * H + r0 + row) * wpitch * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store8<T>(yr + (size_t)(lpad + 4 * g + e) * 8, o[e]);
+        if (g == 0)
+          for (int xp = 0; xp < lpad; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+        if (g == W4 - 1)
+          for (int xp = lpad + W; xp < wpitch; ++xp) store8<T>(yr + (size_t)xp * 8, z8);
+      }
+      if (y3) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          T* yr = y3 + (((size_t)f * B + b) * H + r0 + row) * wpitch3 * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q[4] = {o[e][3 * f], o[e][3 * f + 1], o[e][3 * f + 2], 0.f};
+            store4c<T>(yr + (size_t)(lpad3 + 4 * g + e) * 4, q);
+          }
+          if (g == 0)
+            for (int xp = 0; xp < lpad3; ++xp) store4c<T>(yr + (size_t)xp * 4, z4);
+          if (g == W4 - 1)
+            for (int xp = lpad3 + W; xp < wpitch3; ++xp) store4c<T>(yr + (size_t)xp * 4, z4);
+        }
+      }
     }
   }
 }
@@ -810,7 +837,7 @@ static bool mean_pack_plan(int H, int W, int* R, int* nW) {
   if (r < 1) return false;
   r = r < H ? r : H;
   const int n = (H + r - 1) / r;
-  if (3 * n > 64) return false;                     // one lane per granule in the sweep
+  if (3 * n > 128) return false;                    // two granules per lane in the sweep
   *R = (H + n - 1) / n;                             // same workgroup count, balanced rows
   *nW = n;
   return true;
@@ -822,19 +849,20 @@ extern "C" long long ft_flow_mean_pack_pair_state_words(int B, int H, int W) {
   return (long long)B * 4 * nW + 1;
 }
 
-extern "C" int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* y, int B, int H, int W, int lpad, int wpitch,
-                                      int dtype, unsigned long long* state, float* mean, ft_stream_t stream) {
-  if (!inputs || !y || !state || !mean || B <= 0 || rgb_max == 0.f || lpad < 0 || wpitch < lpad + W) return FT_ERR_INVALID_ARG;
+extern "C" int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* y, int lpad, int wpitch, void* y3, int lpad3, int wpitch3,
+                                      int B, int H, int W, int dtype, unsigned long long* state, float* mean, ft_stream_t stream) {
+  if (!inputs || (!y && !y3) || !state || !mean || B <= 0 || rgb_max == 0.f) return FT_ERR_INVALID_ARG;
+  if ((y && (lpad < 0 || wpitch < lpad + W)) || (y3 && (lpad3 < 0 || wpitch3 < lpad3 + W))) return FT_ERR_INVALID_ARG;
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
   int R, nW;
   if (!mean_pack_plan(H, W, &R, &nW) || (reinterpret_cast<uintptr_t>(inputs) & 15) != 0) return FT_ERR_UNSUPPORTED;
   unsigned long long* err = state + (size_t)B * 4 * nW;
   if (dtype == FT_F16)
     hipLaunchKernelGGL(flow_mean_pack_pair_kernel<half_t>, dim3(B * nW), dim3(256), 0, as_stream(stream), inputs, rgb_max,
-                       static_cast<half_t*>(y), mean, state, H, W, R, nW, lpad, wpitch, err);
+                       static_cast<half_t*>(y), static_cast<half_t*>(y3), mean, state, B, H, W, R, nW, lpad, wpitch, lpad3, wpitch3, err);
   else
     hipLaunchKernelGGL(flow_mean_pack_pair_kernel<float>, dim3(B * nW), dim3(256), 0, as_stream(stream), inputs, rgb_max,
-                       static_cast<float*>(y), mean, state, H, W, R, nW, lpad, wpitch, err);
+                       static_cast<float*>(y), static_cast<float*>(y3), mean, state, B, H, W, R, nW, lpad, wpitch, lpad3, wpitch3, err);
   FT_LAUNCH_CHECK("flow_mean_pack_pair_kernel");
   return FT_OK;
 }

@@ -1272,9 +1272,22 @@ static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
   };
   const int force = getenv("FT_BNS_VARIANT") ? atoi(getenv("FT_BNS_VARIANT")) : -1;   // dev / tests: 1, 2 or 3 (read per call)
   if (d->P == 128) {
-    const int th = rows(192, 256);
-    if (th < 1) return FT_ERR_UNSUPPORTED;
-    *out = BnsPlan{0, th, ceil_div(d->H, th), d->W, 1};
+    // strips of <= 192 output pixels on <= 256 halo pixels (<128, 4, 3>), or of <= 128 on <= 192 (<128, 3, 2>, round 4) where the
+    // large strips leave CUs idle: ResNet-101 at 384 x 288 with 16 crops per GPU has 160 large strips for 256 CUs (48 x 36 maps,
+    // 5 rows each) and exactly 256 small ones (3 rows).  Cost = rounds of 256 workgroups x MFMAs per wave: 32 K16 steps of conv1
+    // on MT1 halo tiles + (72 + 32) steps on MT2 output tiles, per pair of channel tiles.
+    const int th_b = rows(192, 256), th_s = rows(128, 192);
+    if (th_b < 1 && th_s < 1) return FT_ERR_UNSUPPORTED;
+    const int force128 = getenv("FT_BNS_VARIANT128") ? atoi(getenv("FT_BNS_VARIANT128")) : 0;   // dev / tests: 1 large, 2 small (read per call)
+    auto cost = [&](int th, int mt1, int mt2) {
+      const long long wg = (long long)d->N * ceil_div(d->H, th);
+      return ((wg + 255) / 256) * (long long)(32 * mt1 + 104 * mt2);
+    };
+    bool small = th_b < 1 || (th_s >= 1 && cost(th_s, 3, 2) < cost(th_b, 4, 3));
+    if (force128 == 1 && th_b >= 1) small = false;
+    if (force128 == 2 && th_s >= 1) small = true;
+    const int th = small ? th_s : th_b;
+    *out = BnsPlan{small ? 5 : 0, th, ceil_div(d->H, th), d->W, 1};
     return FT_OK;
   }
   const int th_big = rows(96, 120), th_small = rows(64, 96);
@@ -1429,6 +1442,7 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   hipStream_t s = as_stream(stream);
   switch (pl.variant) {
     case 0: return bns_launch<128, 4, 3>(p, s);
+    case 5: return bns_launch<128, 3, 2>(p, s);
     case 1: return bns_launch<256, 4, 3>(p, s);
     case 3: return bns_launch_direct<2, 1, true>(p, s);
     case 4: return bns_launch_direct<4, 1, false, 8>(p, s);

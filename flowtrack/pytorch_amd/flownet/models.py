@@ -410,8 +410,11 @@ def record_flownetfusion(prog: Program, p: FlowNetFusion, x: ActView, prefix: st
     return flow0
 
 
-#: FlowNet2S / SD: rgb mean + normalise + pack as one launch (ft_flow_mean_pack_pair); FT_FUSE_MEAN_PACK=0 keeps the two launches
-FUSE_MEAN_PACK = os.environ.get("FT_FUSE_MEAN_PACK", "1") != "0"
+#: rgb mean + normalise + pack as one launch (ft_flow_mean_pack_pair) instead of two.  OFF by default: measured at 16 x 512 x 384 the
+#: launch takes 46 us against 23 + 30 us, but the graph replay of FlowNet2S does not move (0.923-0.925 vs 0.923-0.928 ms, same box:
+#: the sample's workgroups wait for each other between their read and their write phase), and a launch whose workgroups wait for
+#: each other is not worth carrying for nothing.  FT_FUSE_MEAN_PACK=1 records it (tests/test_flow_gpu.py covers it either way).
+FUSE_MEAN_PACK = os.environ.get("FT_FUSE_MEAN_PACK", "0") == "1"
 
 
 class _FlowPlan:
@@ -432,28 +435,38 @@ class _FlowBase(HipModule):
         (mode, pad) pair."""
         B, _, _, H, W = x_static.shape
         mean = torch.empty((B * 3,), dtype=torch.float32, device=device)
-        modes = list(modes)
+        modes = [m if isinstance(m, tuple) else (m, pad) for m in modes]
+        outs = [None] * len(modes)
         words = int(_lib.load().ft_flow_mean_pack_pair_state_words(B, H, W)) if FUSE_MEAN_PACK else 0
-        if words and len(modes) == 1 and (modes[0] == 0 or (isinstance(modes[0], tuple) and modes[0][0] == 0)):
-            # one 6-channel view (FlowNet2S / SD): mean + normalise + pack as ONE launch that reads the frame pair once
-            # (ft_flow_mean_pack_pair: the workgroups of a sample exchange their partial sums inside the launch)
-            vpad = modes[0][1] if isinstance(modes[0], tuple) else pad
-            view = new_rowpacked_act(B, H, W, 6, vpad, dtype, device)
+        if words:
+            # mean + normalise + pack as ONE launch that reads the frame pair once (ft_flow_mean_pack_pair: the workgroups of a
+            # sample exchange their partial sums inside the launch); it writes the first 6-channel view and the first siamese
+            # view asked for, any further view (another padding) is packed from the mean it leaves behind
+            i6 = next((i for i, (mode, _) in enumerate(modes) if mode == 0), None)
+            i3 = next((i for i, (mode, _) in enumerate(modes) if mode == 1), None)
+            v6 = new_rowpacked_act(B, H, W, 6, modes[i6][1], dtype, device) if i6 is not None else None
+            v3 = new_rowpacked_act(2 * B, H, W, 3, modes[i3][1], dtype, device) if i3 is not None else None
             state = torch.zeros((words,), dtype=torch.int64, device=device)         # zeroed once; private to this plan
-            prog.add("ft_flow_mean_pack_pair", x_static.data_ptr(), ctypes.c_float(self.rgb_max), view.t.data_ptr(), B, H, W,
-                     view.lpad, view.wpitch, _lib.dtype_code(dtype), state.data_ptr(), mean.data_ptr(),
-                     keep=(x_static, view.t, state, mean))
-            return [view]
-        partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
-        prog.add("ft_flow_rgb_mean", x_static.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(),
-                 keep=(x_static, partial, mean))
-        outs = []
-        for mode in modes:
-            mode, pad = mode if isinstance(mode, tuple) else (mode, pad)
-            view = new_rowpacked_act(B if mode == 0 else 2 * B, H, W, 6 if mode == 0 else 3, pad, dtype, device)
+            prog.add("ft_flow_mean_pack_pair", x_static.data_ptr(), ctypes.c_float(self.rgb_max),
+                     v6.t.data_ptr() if v6 is not None else None, v6.lpad if v6 is not None else 0, v6.wpitch if v6 is not None else 0,
+                     v3.t.data_ptr() if v3 is not None else None, v3.lpad if v3 is not None else 0, v3.wpitch if v3 is not None else 0,
+                     B, H, W, _lib.dtype_code(dtype), state.data_ptr(), mean.data_ptr(),
+                     keep=(x_static, state, mean, v6.t if v6 is not None else None, v3.t if v3 is not None else None))
+            if i6 is not None:
+                outs[i6] = v6
+            if i3 is not None:
+                outs[i3] = v3
+        else:
+            partial = torch.empty((B * 3 * _lib.FT_RGB_MEAN_SPLITS,), dtype=torch.float32, device=device)
+            prog.add("ft_flow_rgb_mean", x_static.data_ptr(), B, H, W, partial.data_ptr(), mean.data_ptr(),
+                     keep=(x_static, partial, mean))
+        for i, (mode, vpad) in enumerate(modes):
+            if outs[i] is not None:
+                continue
+            view = new_rowpacked_act(B if mode == 0 else 2 * B, H, W, 6 if mode == 0 else 3, vpad, dtype, device)
             prog.add("ft_flow_pack_pair", x_static.data_ptr(), mean.data_ptr(), ctypes.c_float(self.rgb_max),
                      view.t.data_ptr(), B, H, W, mode, view.lpad, view.wpitch, _lib.dtype_code(dtype), keep=(view.t,))
-            outs.append(view)
+            outs[i] = view
         return outs
 
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:  # pragma: no cover - abstract

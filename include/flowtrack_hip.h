@@ -337,16 +337,17 @@ int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max,
                       void* y, int B, int H, int W, int mode, int lpad,
                       int wpitch, int dtype, ft_stream_t stream);
 
-/* The two calls above as ONE launch for the 6-channel (mode 0) view: every workgroup keeps its rows of the sample in registers
+/* The two calls above as ONE launch, writing the 6-channel (mode 0) view y [B,H,wpitch,8] and / or the siamese (mode 1) view y3
+ * [2B,H,wpitch3,4] (either may be NULL): every workgroup keeps its rows of the sample in registers
  * across the mean reduction (partial sums exchanged as tagged 8-byte words in `state`), so the frame pair is read once
  * (lib/flownet/model/models.py:255-257).  `state`: ft_flow_mean_pack_pair_state_words(B, H, W) 8-byte words (0 = the shape is not
- * covered: W % 4 != 0 or more than 21 x 12288 pixels per frame -> use the two calls), zeroed ONCE by the caller at allocation and
+ * covered: W % 4 != 0 or more than 42 x 6144 pixels per frame -> use the two calls), zeroed ONCE by the caller at allocation and
  * private to this (B, H, W) from then on; its last word becomes non-zero if a workgroup ever timed out waiting for its sample's
  * sums (means are NaN then).  mean fp32 [B*3] is written as well.  Same arithmetic per element as ft_flow_pack_pair; the mean's
  * summation order differs from ft_flow_rgb_mean's (last-bit differences). */
 long long ft_flow_mean_pack_pair_state_words(int B, int H, int W);
-int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* y, int B, int H, int W, int lpad, int wpitch, int dtype,
-                           unsigned long long* state, float* mean, ft_stream_t stream);
+int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* y, int lpad, int wpitch, void* y3, int lpad3, int wpitch3,
+                           int B, int H, int W, int dtype, unsigned long long* state, float* mean, ft_stream_t stream);
 
 /* ---- F7: nn.Upsample(scale_factor=4, mode='bilinear') * mul ----------------
  * (FlowNetS.py:58, models.py:292; align_corners=False).  NCHW fp32 in/out. */

@@ -161,6 +161,63 @@ def test_stream_256_variants_match_oracle_and_each_other(hip_lib, case, variant,
         assert (diff > 0).float().mean().item() < 0.05, "the two forms should agree bit for bit almost everywhere"
 
 
+S128 = [c for c in STREAM_CASES if c[6] == 128] + [
+    ("s128_r101_b16_48x36", 16, 48, 36, 512, 0, 128),    # configs[2] per-GPU shape: 160 strips of 5 rows -> 256 strips of 3 rows
+    ("s128_recycle_small", 40, 48, 36, 512, 0, 128),     # 640 small strips: LDS reuse across workgroups
+]
+
+
+@pytest.mark.parametrize("case", S128, ids=[c[0] for c in S128])
+def test_stream_128_strip_sizes_match_oracle_and_each_other(hip_lib, case, monkeypatch):
+    """Both strip sizes of the 128-plane fused kernel (layer2's identity blocks, blocks.py:105-120) on every 128-plane shape,
+    whatever the cost model would pick: FT_BNS_VARIANT128 = 1 (<= 192 output pixels on <= 256 halo pixels, <128, 4, 3>) / 2 (<= 128
+    on <= 192, <128, 3, 2>: the form that fills 256 CUs at ResNet-101 384x288 with 16 crops per GPU).  Same weights, same fp16
+    roundings of t1 / t2: both agree with the oracle and, almost everywhere, with each other; without the switch the library picks
+    the small strips exactly where they need fewer rounds x work."""
+    name, N, H, W, xcs, xoff, P = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 27
+    C = 4 * P
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+    t2 = F.relu(_bnf(F.conv2d(t1, w2, padding=1), bn2))
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + x)
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    c3 = FusedConv(w3, bn=bn3, label="conv3", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    outs = {}
+    for v in (1, 2, 0):
+        if v:
+            monkeypatch.setenv("FT_BNS_VARIANT128", str(v))
+        else:
+            monkeypatch.delenv("FT_BNS_VARIANT128", raising=False)
+        y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
+        prog = make_program()
+        record_bottleneck(prog, c1, c2, c3, xv, y, name)
+        assert prog.calls[0][0] == "ft_bottleneck_stream_fwd"
+        run_program(prog)
+        got = view_to_nchw(y)
+        y.t.fill_(5.0)
+        run_program(prog)
+        assert torch.equal(view_to_nchw(y), got), f"{name} strips {v}: two runs differ"
+        assert torch.all(y.t[..., :32] == 5.0), "channels outside the output slice were written"
+        outs[v] = got
+    scale = max(1.0, want.abs().max().item())
+    for v in (1, 2):
+        err = (outs[v] - want).abs().max().item()
+        assert err <= 2e-2 * scale, f"{name} strips {v}: vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    diff = (outs[1] - outs[2]).abs()
+    assert diff.max().item() <= 1e-2 * scale and (diff > 0).float().mean().item() < 0.05
+    assert torch.equal(outs[0], outs[1]) or torch.equal(outs[0], outs[2])
+    if name == "s128_r101_b16_48x36":
+        assert torch.equal(outs[0], outs[2]) , "160 large strips on 256 CUs: the cost model takes the 256 small ones"
+
+
 # ft_bottleneck_stream_fwd(head_only, stride 2): conv1 + stride-2 conv2 of the 256-plane entry block (layer3.0): (name, N, H, W, x stride, x offset)
 HEAD2_CASES = [("h2_r50_32x24", 3, 32, 24, 512, 0), ("h2_r101_48x36", 2, 48, 36, 512, 0), ("h2_tiny_4x2", 1, 4, 2, 512, 0),
                ("h2_ragged_rows_10x8", 2, 10, 8, 544, 32), ("h2_ragged_last_30x24", 2, 30, 24, 512, 0), ("h2_recycle", 70, 32, 24, 512, 0)]

@@ -171,7 +171,7 @@ def test_fused_mean_pack_pair_matches_the_two_launches(hip_lib):
     their partial sums as tagged 8-byte words inside the launch; models.py:255-257) against ft_flow_rgb_mean + ft_flow_pack_pair:
     the same mean up to the summation order, hence the same packed view up to that (fp32) and to the last fp16 bit almost
     everywhere; pad columns zero; REPEATED launches on one state buffer with changing inputs (the epoch logic: a stale tag of the
-    previous launch must never satisfy the sweep); one / two / sixteen workgroups per sample; ragged last workgroup."""
+    previous launch must never satisfy the sweep); one / two / three / thirty-two workgroups per sample; ragged last workgroup."""
     from flowtrack.pytorch_amd.hip_ops import new_rowpacked_act
     for (B, H, W, pad) in ((16, 384, 512, 3), (3, 130, 100, 3), (2, 64, 64, 1), (5, 50, 260, 3)):
         words = int(hip_lib.ft_flow_mean_pack_pair_state_words(B, H, W))
@@ -187,20 +187,36 @@ def test_fused_mean_pack_pair_matches_the_two_launches(hip_lib):
                 check(hip_lib.ft_flow_rgb_mean(pair.data_ptr(), B, H, W, partial.data_ptr(), mean2.data_ptr(), _stream()))
                 check(hip_lib.ft_flow_pack_pair(pair.data_ptr(), mean2.data_ptr(), ctypes.c_float(255.0), want.t.data_ptr(), B, H, W, 0,
                                                 want.lpad, want.wpitch, _lib.dtype_code(dtype), _stream()))
+                want3 = new_rowpacked_act(2 * B, H, W, 3, pad, dtype, "cuda")
+                want3.t.fill_(5.0)
+                check(hip_lib.ft_flow_pack_pair(pair.data_ptr(), mean2.data_ptr(), ctypes.c_float(255.0), want3.t.data_ptr(), B, H, W, 1,
+                                                want3.lpad, want3.wpitch, _lib.dtype_code(dtype), _stream()))
                 got = new_rowpacked_act(B, H, W, 6, pad, dtype, "cuda")
                 got.t.fill_(7.0)
+                got3 = new_rowpacked_act(2 * B, H, W, 3, pad, dtype, "cuda")
+                got3.t.fill_(7.0)
                 mean1 = torch.empty(B * 3, device="cuda")
-                check(hip_lib.ft_flow_mean_pack_pair(pair.data_ptr(), ctypes.c_float(255.0), got.t.data_ptr(), B, H, W, got.lpad,
-                                                     got.wpitch, _lib.dtype_code(dtype), state.data_ptr(), mean1.data_ptr(), _stream()))
+                # rep 0: both views; rep 1: the 6-channel view alone; rep 2: the siamese view alone
+                p6 = got.t.data_ptr() if rep != 2 else None
+                p3 = got3.t.data_ptr() if rep != 1 else None
+                check(hip_lib.ft_flow_mean_pack_pair(pair.data_ptr(), ctypes.c_float(255.0), p6, got.lpad, got.wpitch, p3, got3.lpad,
+                                                     got3.wpitch, B, H, W, _lib.dtype_code(dtype), state.data_ptr(), mean1.data_ptr(),
+                                                     _stream()))
                 torch.cuda.synchronize()
                 assert int(state[-1]) == 0, "a workgroup timed out waiting for its sample's partial sums"
                 ref = pair.view(B, 3, -1).double().mean(-1).flatten().float()
                 assert (mean1 - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() and (mean1 - mean2).abs().max().item() <= 1e-3
+                if p3 is not None:
+                    d3 = (got3.t.float() - want3.t.float()).abs()
+                    assert d3.max().item() <= tol, (B, H, W, dtype, rep, d3.max().item())
+                    assert torch.all(got3.t[:, :, :got3.lpad] == 0) and torch.all(got3.t[:, :, got3.lpad + W:] == 0) and torch.all(got3.t[..., 3:] == 0)
+                if p6 is None:
+                    continue
                 d = (got.t.float() - want.t.float()).abs()
                 assert d.max().item() <= tol, (B, H, W, dtype, rep, d.max().item())
                 assert torch.all(got.t[:, :, :got.lpad] == 0) and torch.all(got.t[:, :, got.lpad + W:] == 0) and torch.all(got.t[..., 6:] == 0)
     assert int(hip_lib.ft_flow_mean_pack_pair_state_words(2, 64, 62)) == 0          # W % 4 != 0: the two launches
-    assert int(hip_lib.ft_flow_mean_pack_pair_state_words(1, 2048, 2048)) == 0      # more than 21 workgroups per sample
+    assert int(hip_lib.ft_flow_mean_pack_pair_state_words(1, 2048, 2048)) == 0      # more than 42 workgroups per sample
 
 
 def test_upsample_and_normalise(hip_lib, oracle_lib):
