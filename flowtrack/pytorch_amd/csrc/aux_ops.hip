@@ -830,6 +830,7 @@ extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float r
   return FT_OK;
 }
 
+constexpr int kMpMaxGrid = 512;            // 256 CUs x two workgroups (__launch_bounds__(256, 2)): every workgroup of the grid is resident
 // rows per workgroup / workgroups per sample of flow_mean_pack_pair_kernel, or false where it does not apply
 static bool mean_pack_plan(int H, int W, int* R, int* nW) {
   if (H <= 0 || W < 4 || (W & 3)) return false;
@@ -845,7 +846,7 @@ static bool mean_pack_plan(int H, int W, int* R, int* nW) {
 
 extern "C" long long ft_flow_mean_pack_pair_state_words(int B, int H, int W) {
   int R, nW;
-  if (B <= 0 || !mean_pack_plan(H, W, &R, &nW)) return 0;
+  if (B <= 0 || !mean_pack_plan(H, W, &R, &nW) || (long long)B * nW > kMpMaxGrid) return 0;
   return (long long)B * 4 * nW + 1;
 }
 
@@ -856,6 +857,7 @@ extern "C" int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* 
   if (dtype != FT_F16 && dtype != FT_F32) return FT_ERR_INVALID_ARG;
   int R, nW;
   if (!mean_pack_plan(H, W, &R, &nW) || (reinterpret_cast<uintptr_t>(inputs) & 15) != 0) return FT_ERR_UNSUPPORTED;
+  if ((long long)B * nW > kMpMaxGrid) return FT_ERR_UNSUPPORTED;   // the sample's workgroups wait for each other: all resident
   unsigned long long* err = state + (size_t)B * 4 * nW;
   if (dtype == FT_F16)
     hipLaunchKernelGGL(flow_mean_pack_pair_kernel<half_t>, dim3(B * nW), dim3(256), 0, as_stream(stream), inputs, rgb_max,

@@ -341,7 +341,8 @@ int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max,
  * [2B,H,wpitch3,4] (either may be NULL): every workgroup keeps its rows of the sample in registers
  * across the mean reduction (partial sums exchanged as tagged 8-byte words in `state`), so the frame pair is read once
  * (lib/flownet/model/models.py:255-257).  `state`: ft_flow_mean_pack_pair_state_words(B, H, W) 8-byte words (0 = the shape is not
- * covered: W % 4 != 0 or more than 42 x 6144 pixels per frame -> use the two calls), zeroed ONCE by the caller at allocation and
+ * covered: W % 4 != 0, more than 42 x 6144 pixels per frame, or more than 512 workgroups = B x ceil(H x W / 6144) so that not
+ * all of them would be resident while they wait for each other -> use the two calls), zeroed ONCE by the caller at allocation and
  * private to this (B, H, W) from then on; its last word becomes non-zero if a workgroup ever timed out waiting for its sample's
  * sums (means are NaN then).  mean fp32 [B*3] is written as well.  Same arithmetic per element as ft_flow_pack_pair; the mean's
  * summation order differs from ft_flow_rgb_mean's (last-bit differences). */
