@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "ft_common.h"
+#include "conv_wstat.h"
 
 namespace ft {
 namespace {
@@ -1640,6 +1641,8 @@ static int cd_dispatch(const CdParams& p, hipStream_t s) {
 extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;
+  ft::WsPlan pw;
+  if (d && d->kh == 5) return ft::ws_plan(d, &pw);                        // 5x5 / stride 2 on 64 channels: register-stationary (conv_wstat.hip)
   if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return FT_OK;     // whole small maps; other 3x3s: the gather form
   return ft::cd_plan(d, &pl);
 }
@@ -1650,6 +1653,8 @@ extern "C" int ft_conv_direct_supported(const ft_conv_desc* d) {
 extern "C" int ft_conv_direct_stream_id(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;
+  ft::WsPlan pw;
+  if (d && d->kh == 5) return ft::ws_plan(d, &pw) == FT_OK ? (0x50000000 | pw.ncg) : -1;
   if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return 0x40000000 | (p3.stride == 2 ? (p3.ipw == 2 ? 0x30000000 : 0x10000000) : 0) | (p3.ncb << 8) | p3.spt;
   if (ft::cd_plan(d, &pl) != FT_OK) return -1;
   return ((pl.ksplit + 1) << 24) | ((pl.nc1 + pl.nc2) << 12) | pl.ncb;
@@ -1658,6 +1663,8 @@ extern "C" int ft_conv_direct_stream_id(const ft_conv_desc* d) {
 extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
   ft::CdPlan pl;
   ft::C3Plan p3;
+  ft::WsPlan pw;
+  if (d && d->kh == 5) return ft::ws_plan(d, &pw) == FT_OK ? ft::ws_weight_bytes(pw) : 0;
   if (d && d->kh == 3 && ft::c3_plan(d, &p3) == FT_OK) return (long long)p3.ncb * 4 * 9 * p3.spt * 8192;
   if (ft::cd_plan(d, &pl) != FT_OK) return 0;
   if (pl.ksplit == 0) return (long long)d->Cout * d->Cin * 2;
@@ -1667,6 +1674,11 @@ extern "C" long long ft_conv_direct_weight_bytes(const ft_conv_desc* d) {
 extern "C" int ft_conv_direct_pack(const ft_conv_desc* d, const void* w_packed, int kpad, int cout_pad, void* wstream, ft_stream_t stream) {
   using namespace ft;
   C3Plan p3;
+  if (d && d->kh == 5) {
+    WsPlan pw;
+    const int st = ws_plan(d, &pw);
+    return st != FT_OK ? st : ws_pack(d, pw, w_packed, kpad, cout_pad, wstream, as_stream(stream));
+  }
   if (d && d->kh == 3 && c3_plan(d, &p3) == FT_OK) {
     if (!w_packed || !wstream || kpad < 9 * d->Cin || cout_pad < d->Cout) return FT_ERR_INVALID_ARG;
     const int total = p3.ncb * 4 * 9 * p3.spt * 512;
@@ -1708,6 +1720,11 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
                                   const void* residual, void* y, ft_stream_t stream) {
   using namespace ft;
   C3Plan p3;
+  if (d && d->kh == 5) {
+    WsPlan pw;
+    const int st = ws_plan(d, &pw);
+    return st != FT_OK ? st : ws_launch(d, pw, x, wstream, scale, shift, y, as_stream(stream));
+  }
   if (d && d->kh == 3 && c3_plan(d, &p3) == FT_OK) {
     if (!x || !wstream || !y) return FT_ERR_INVALID_ARG;
     C3Params q{};

@@ -805,7 +805,7 @@ class FusedConv:
             res_ptr = self._tail.data_ptr()
         w, _, scale, shift = self._packed_for(d)
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
-        ws = _direct_stream(self, d, w, x.t.device) if (self.k in (1, 3) and isinstance(y, ActView) and not self.tail_cout and not pool) else None
+        ws = _direct_stream(self, d, w, x.t.device) if (self.k in (1, 3, 5) and isinstance(y, ActView) and not self.tail_cout and not pool) else None
         if ws is not None:
             # two forms of the same launch; the in-situ benchmark (Program.tune_choices) keeps the faster one
             dd = ConvDesc.from_buffer_copy(d)
@@ -849,9 +849,11 @@ def _direct_stream(owner, d: ConvDesc, w: torch.Tensor, device) -> Optional[torc
     """The ft_conv_direct weight stream of `d` (built once per packed weight set, cached on the layer), or None when the
     layer does not qualify."""
     lib = _lib.load()
-    if not CONV_DIRECT or d.dtype != _lib.FT_F16 or d.Cin + d.x2_cin < 256:
+    # (5x5 / stride 2 on 64 channels — FlowNet's conv2 — has a form of its own: weights stationary in registers, any pixel count)
+    wstat = d.kh == 5 and d.Cin == 64 and d.stride == 2 and not d.x2_cin
+    if not CONV_DIRECT or d.dtype != _lib.FT_F16 or (d.Cin + d.x2_cin < 256 and not wstat) or (d.kh == 5 and not wstat):
         return None
-    if d.N * d.Ho * d.Wo > CONV_DIRECT_MAX_PIXELS and not (CONV_DIRECT_MAX_PIXELS >= 65536 and d.kh == 1 and d.Cin in (256, 512)
+    if not wstat and d.N * d.Ho * d.Wo > CONV_DIRECT_MAX_PIXELS and not (CONV_DIRECT_MAX_PIXELS >= 65536 and d.kh == 1 and d.Cin in (256, 512)
                                                           and not d.x2_cin and not d.has_residual):
         return None     # (beyond the bound only the weight-stationary short-K forms exist: ResNet layer2.0 / layer3.0 conv1)
     if lib.ft_conv_direct_supported(ctypes.byref(d)) != 0:

@@ -240,3 +240,54 @@ print("ok")
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", [("flownet_conv2_like", 2, 96, 128, 128, "bias"),     # whole 8 x 8 patches, two output groups
+                                  ("ragged_patches", 3, 41, 55, 128, "bn"),            # Ho x Wo = 21 x 28: ragged last patch row / column
+                                  ("one_group", 2, 30, 34, 64, "bias"),                # Cout = 64: one group, odd sizes
+                                  ("three_groups", 1, 64, 48, 192, "none"),            # 3 does not divide an XCD's 32 workgroups
+                                  ("tiny_map", 5, 5, 3, 256, "bn"),                    # a map smaller than one patch, four groups
+                                  ("many_patches", 7, 136, 200, 128, "bias")],         # 7 x 9 x 13 = 819 patches: > 6 per workgroup pair
+                         ids=lambda c: c[0])
+def test_direct_conv5x5s2_register_stationary_matches_oracle_and_igemm(hip_lib, case, monkeypatch):
+    """FlowNet's conv2 (5x5 / stride 2 / pad 2 on 64 channels, FlowNetS.py:21): weights stationary in registers, 19 x 19 input
+    patches double-buffered in LDS, K quarters reduced through LDS (conv_wstat.hip)."""
+    name, N, H, W, Cout, norm = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 37
+    Cin = 64
+    w = synth.normal(seed, name + ".w", (Cout, Cin, 5, 5), std=(2.0 / (25 * Cin)) ** 0.5)
+    bias = synth.normal(seed, name + ".bias", (Cout,), 0.2) if norm == "bias" else None
+    bn = _bn(seed, name + ".bn", Cout) if norm == "bn" else None
+    x = synth.normal(seed, name + ".x", (N, Cin, H, W)).half().float()
+    want = F.conv2d(x, w, bias, stride=2, padding=2)
+    if bn is not None:
+        want = _bnf(want, bn)
+    want = F.leaky_relu(want, 0.1)
+    conv = FusedConv(w, stride=2, pad=2, bias=bias, bn=bn, act="leaky", slope=0.1, dtype=dtype, device=dev, label=name)
+    xv = nchw_to_view(x, dtype, dev, cstride=Cin + 16, coff=8)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    outs = {}
+    for mode in (True, False):
+        monkeypatch.setattr(hip_ops, "CONV_DIRECT", mode)
+        monkeypatch.setattr(hip_ops, "_TILE_CACHE", {})
+        y = ActView(torch.full((N, Ho, Wo, Cout + 24), 3.0, dtype=dtype, device=dev), Cout, 16)
+        prog = make_program()
+        conv.record(prog, xv, y)
+        prog.resolve_choices()      # recorded as [direct | implicit GEMM]: keep the first form
+        assert prog.calls[0][0] == ("ft_conv_direct_fwd" if mode else "ft_conv2d_fwd_ws"), prog.calls[0][0]
+        run_program(prog)
+        outs[mode] = view_to_nchw(y)
+        assert torch.all(y.t[..., :16] == 3.0) and torch.all(y.t[..., 16 + Cout:] == 3.0), "channels outside the output slice were written"
+        if mode:
+            d = prog.conv_records[0][3]
+            assert hip_lib.ft_conv_direct_weight_bytes(d) == (Cout // 64) * 200 * 1024
+            for _ in range(3):                     # determinism (the exchange buffer and both patch buffers are recycled)
+                y.t.fill_(5.0)
+                run_program(prog)
+                assert torch.equal(view_to_nchw(y), outs[True])
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[True] - want).abs().max().item()
+    assert err <= 1e-2 * scale, f"{name}: register-stationary conv vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    diff = (outs[True] - outs[False]).abs()
+    assert diff.max().item() <= 5e-3 * scale, f"{name}: direct vs igemm max abs diff {diff.max().item():.3e}"
+    assert (diff > 0).float().mean().item() < 0.05, "same fp16 inputs, fp32 accumulation: only the summation order differs"
