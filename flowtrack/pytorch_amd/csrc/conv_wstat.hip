@@ -14,10 +14,19 @@
 // thread: 16-byte stores, 128 contiguous bytes per 8 lanes).  L2 -> LDS traffic: the input once per output group (x 1.41 halo).
 //
 // LDS map: [patch 0: 48 KiB][patch 1: 48 KiB][exchange: 64 KiB] = 160 KiB.
-//  * patch: pixel p = row * 19 + col at p * 128 B, its eight 16-byte chunks XOR-ed with (col >> 1) & 7 — the 32 pixels of a
-//    B fragment are 8 columns two apart in 4 rows, so the eight lanes of a row hit eight distinct chunks of one 128-byte half;
+//  * patch: see the layout note at ws_read (256-byte pixel pairs, 16 slots XOR-ed with a (column, row) key: conflict-free
+//    ds_read_b128 fragments);
 //  * exchange: [quarter][group of 4 channels G = 0..15][pixel ^ (G >> 1)][4 floats]: writes are lane-linear per (register
-//    group, tile), and the eight lanes that finish one pixel read eight distinct 16-byte columns.
+//    group, tile), the eight lanes that finish one pixel read eight distinct 16-byte columns.
+//
+// What was measured on the way (FlowNet2S conv2, 16 x 192 x 256 x 64 -> 96 x 128 x 128; implicit GEMM 122-125 us):
+//   first correct version (reads left to the compiler's schedule, finish after a second barrier)      98-100 us
+//   finish / next patch's loads / tile-0 exchange writes hung between the MFMAs, tiles one after the other   92-93 us
+//   + conflict-free patch layout, every in-loop LDS access as inline asm (hipcc had put `s_waitcnt vmcnt(0)` — the whole
+//     next patch — in front of compiler-visible LDS accesses and of the first in-loop use of preloaded registers)   86-87 us
+//   dead ends: FOUR waves (one per SIMD, both channel tiles per wave: 37 % less LDS traffic) 100-110 us — 64-68 cycles per
+//   MFMA whatever the number of accumulator chains; both pixel tiles interleaved per k-step in the 8-wave form: slower than the
+//   implicit GEMM (8.6 k cycles per patch against 6.0 k).  tools/dev/ws_phases.py prints the per-phase cycle sums.
 #include "conv_wstat.h"
 
 #include <stdlib.h>
@@ -26,14 +35,14 @@
 
 namespace ft {
 
-constexpr int kWsPW = 19;                        // input patch edge: (8 - 1) * 2 + 5
-constexpr int kWsNPX = kWsPW * kWsPW;            // 361 pixels
-constexpr int kWsPieces = 48;                    // 1-KiB wave loads per patch buffer (46 hold pixels; 6 per wave)
+constexpr int kWsPH = 19;                        // input patch rows / used columns: (8 - 1) * 2 + 5
+constexpr int kWsPairs = 10;                     // a patch row = 10 pixel PAIRS of 256 B (column 19 is padding)
+constexpr int kWsPieces = 48;                    // 1-KiB wave loads per patch buffer (19 * 10 * 256 B = 47.5 KiB; 6 per wave)
 constexpr int kWsPatchB = kWsPieces * 1024;
 constexpr int kWsPartB = 4 * 16 * 64 * 16;
 constexpr int kWsLds = 2 * kWsPatchB + kWsPartB;
 constexpr int kWsNJ = 25;                        // k-steps per wave
-constexpr int kWsTileOff = 4 * 2 * kWsPW * 128;  // second pixel tile of the patch: four output rows further down
+constexpr int kWsTileOff = 4 * 2 * kWsPairs * 256;   // second pixel tile of the patch: four output rows further down
 
 __host__ __device__ constexpr int ws_sigma(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }   // as cd_sigma: a lane owns 16 consecutive channels
 
@@ -56,25 +65,53 @@ struct WsParams {
 // B fragments are read kWsAhead half-steps before their MFMA, by hand: left to itself the compiler emitted read / wait /
 // multiply on one fragment register set (the LDS latency in front of every MFMA).  The reads are inline asm, the counted
 // lgkmcnt waits carry the fragment register as an in-out operand so no MFMA can move above its wait (LDS operations return in
-// order: compiler-generated LDS traffic between them only makes a count conservative).  `hook(hs)` runs after half-step hs:
-// the kernel hangs everything else of the patch loop there — the next patch's LDS-DMA loads, the previous patch's finish, this
-// patch's exchange writes of tile 0 — so that none of it waits in front of the matrix pipe.  `mid()` sits between the tiles.
-constexpr int kWsAhead = 6, kWsHS = 2 * kWsNJ;
+// order: other LDS traffic between them only makes a count conservative).  `hook(hs)` runs after half-step hs: the kernel hangs
+// everything else of the patch loop there — the next patch's LDS-DMA loads, the previous patch's finish, this patch's exchange
+// writes of tile 0 — so that none of it waits in front of the matrix pipe.  `mid()` sits between the tiles.
+//
+// Patch layout (conflict-free for ds_read_b128's 16-lane groups {0-3, 12-15, 20-27}, ...: a B fragment's 32 pixels are 8
+// columns two apart in 4 rows two apart, ALL of one column parity — with 128-byte pixels in row-major order every lane sat in
+// the same 128-byte half of the 64 banks, a 2-way conflict on every read): input pixel (r, cc) lives in the 256-byte PAIR
+// r * 10 + cc / 2, at 16-byte slot ((cc & 1) * 8 + chunk) ^ key, key = (cc / 2 & 3) | ((r / 2 & 3) << 2): the 16 lanes of a
+// group differ in (cc / 2 & 3, r / 2 & 3), so they cover the 16 slots of a bank row.
+constexpr int kWsAhead = 5, kWsHS = 2 * kWsNJ;
 template <int Q, int HS>
-__device__ __forceinline__ void ws_read(unsigned abase, const int (&hk16)[3], uint4_t& b) {
+__device__ __forceinline__ void ws_read(unsigned abase, const int (&hk)[3][3], uint4_t& b) {
   constexpr int J = HS % kWsNJ, s = Q * kWsNJ + J, tap = s >> 2, c16 = s & 3, ty = tap / 5, tx = tap % 5;
-  constexpr int toff = (ty * kWsPW + tx) * 128 + (HS / kWsNJ) * kWsTileOff;
-  const unsigned a = abase + (unsigned)((c16 << 5) ^ hk16[tx >> 1]);
+  constexpr int toff = (ty * kWsPairs + (tx >> 1)) * 256 + (HS / kWsNJ) * kWsTileOff;
+  constexpr int lc = (((tx & 1) << 3) | (c16 << 1)) << 4;
+  const unsigned a = abase + (unsigned)(lc ^ hk[tx >> 1][ty >> 1]);
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(a), "n"(toff));
 }
+// the finish's exchange reads (quarters 2H, 2H + 1 of the thread's octet) and their sum, NEWER LDS operations later
+template <int H>
+__device__ __forceinline__ void ws_ex_rd(unsigned addr, float4_t (&fr)[4]) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[0]) : "v"(addr), "n"(H * 32768));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[1]) : "v"(addr), "n"(H * 32768 + 1024));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[2]) : "v"(addr), "n"(H * 32768 + 16384));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[3]) : "v"(addr), "n"(H * 32768 + 16384 + 1024));
+}
+template <int H, int NEWER>
+__device__ __forceinline__ void ws_ex_sum(float4_t (&fr)[4], float (&v)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) : "n"(NEWER));
+#pragma unroll
+  for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (H == 0) v[e2 * 4 + e] = fr[e2][e] + fr[2 + e2][e];
+      else v[e2 * 4 + e] = (v[e2 * 4 + e] + fr[e2][e]) + fr[2 + e2][e];
+    }
+}
+__device__ __forceinline__ void ws_ex_wr(unsigned addr, float4_t u) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(u) : "memory"); }
+
 template <int Q, typename Hook, typename Mid>
-__device__ __forceinline__ void ws_mfma(const uint4_t (&wt)[kWsNJ], unsigned abase, const int (&hk16)[3], float16_t (&acc)[2], Hook&& hook, Mid&& mid) {
+__device__ __forceinline__ void ws_mfma(const uint4_t (&wt)[kWsNJ], unsigned abase, const int (&hk)[3][3], float16_t (&acc)[2], Hook&& hook, Mid&& mid) {
   uint4_t b[kWsAhead + 1];
-  static_for<kWsAhead>([&](auto hc) { ws_read<Q, decltype(hc)::value>(abase, hk16, b[decltype(hc)::value]); });
+  static_for<kWsAhead>([&](auto hc) { ws_read<Q, decltype(hc)::value>(abase, hk, b[decltype(hc)::value]); });
   static_for<kWsHS>([&](auto hc) {
     constexpr int hs = decltype(hc)::value, j = hs % kWsNJ, t = hs / kWsNJ;
     if constexpr (hs == kWsNJ) mid();
-    if constexpr (hs + kWsAhead < kWsHS) ws_read<Q, hs + kWsAhead>(abase, hk16, b[(hs + kWsAhead) % (kWsAhead + 1)]);
+    if constexpr (hs + kWsAhead < kWsHS) ws_read<Q, hs + kWsAhead>(abase, hk, b[(hs + kWsAhead) % (kWsAhead + 1)]);
     constexpr int sl = hs % (kWsAhead + 1);
     constexpr int behind = kWsHS - 1 - hs < kWsAhead ? kWsHS - 1 - hs : kWsAhead;     // reads issued after half-step hs's
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[sl]) : "n"(behind));
@@ -112,32 +149,32 @@ __global__ __launch_bounds__(512, 1) void conv5x5s2_wstat_kernel(const WsParams 
 #pragma unroll
     for (int j = 0; j < kWsNJ; ++j) wt[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)lane * 16u, wbase + j * 1024, 0);
   }
-  // finishing thread: pixel tid >> 3 of the patch, channels cg * 64 + (tid & 7) * 8 ..: their shifts in registers, the group's
-  // folded scales in the tail of patch buffer 0 (pieces 46 and 47 hold no pixel and are never loaded)
+  // finishing thread: pixel tid >> 3 of the patch, channels cg * 64 + (tid & 7) * 8 .., their folded scales / shifts in registers
   const int e_pix = tid >> 3, e_oct = tid & 7;
-  float* tab = reinterpret_cast<float*>(smem + 46 * 1024);
-  const bool has_scale = p.scale != nullptr;
-  if (tid < 64) tab[tid] = has_scale ? p.scale[cg * 64 + tid] : 1.f;
-  float sh[8];
+  float sc[8], sh[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) sh[e] = p.shift ? p.shift[cg * 64 + e_oct * 8 + e] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = p.scale ? p.scale[cg * 64 + e_oct * 8 + e] : 1.f;
+    sh[e] = p.shift ? p.shift[cg * 64 + e_oct * 8 + e] : 0.f;
+  }
   const float act_k = p.act == FT_ACT_RELU ? 0.f : (p.act == FT_ACT_LEAKY ? p.slope : 1.f);
 
   // loader lanes: wave load t * 8 + wave fills 16-byte slots S = piece * 64 + lane of the patch buffer
-  int l_rel[6], l_row[6], l_col[6];
+  constexpr int NLD = 6;
+  int l_rel[NLD], l_rc[NLD];
 #pragma unroll
-  for (int t = 0; t < 6; ++t) {
+  for (int t = 0; t < NLD; ++t) {
     const int S = (t * 8 + wave) * 64 + lane;
-    const int px = S >> 3, phys = S & 7;
-    const int row = px / kWsPW, col = px - row * kWsPW;
-    const int chunk = phys ^ ((col >> 1) & 7);
+    const int pr = S >> 4, phys = S & 15;
+    const int row = pr / kWsPairs, cp = pr - row * kWsPairs;
+    const int logical = phys ^ ((cp & 3) | (((row >> 1) & 3) << 2));
+    const int col = cp * 2 + (logical >> 3), chunk = logical & 7;
     l_rel[t] = ((row * p.W + col) * p.x_cstride + p.x_coff) * 2 + chunk * 16;
-    l_row[t] = px < kWsNPX ? row : (1 << 24);
-    l_col[t] = col;
+    l_rc[t] = ((row < kWsPH && col < kWsPH) ? row : 0x7fff) | (col << 16);
   }
   const int tiles = p.tiles_x * p.tiles_y;
-  // LDS-DMA of patch `id` into buffer `bufi`: nx_* are set once per patch (nx_set), piece t is issued by issue_one(t) — up to
-  // six loads per wave (pieces 46 and 47 hold no pixel); patches past the end / pixels outside the image read out of range
+  // LDS-DMA of patch `id` into buffer `bufi`: nx_* are set once per patch (nx_set), piece t is issued by issue_one(t) — six
+  // loads per wave; patches past the end / pixels outside the image / the padding column read out of range (zeros)
   int nx_iy0 = 0, nx_ix0 = 0, nx_origin = 0, nx_buf = 0;
   bool nx_live = false;
   auto nx_set = [&](int id, int bufi) {
@@ -150,60 +187,49 @@ __global__ __launch_bounds__(512, 1) void conv5x5s2_wstat_kernel(const WsParams 
   };
   auto issue_one = [&](auto tc) {
     constexpr int t = decltype(tc)::value;
-    if (t * 8 + wave >= 46) return;           // (wave-uniform: the waits count "all but the newest store", not loads)
-    const bool ok = nx_live && (unsigned)(nx_iy0 + l_row[t]) < (unsigned)p.H && (unsigned)(nx_ix0 + l_col[t]) < (unsigned)p.W;
+    const bool ok = nx_live && (unsigned)(nx_iy0 + (l_rc[t] & 0xffff)) < (unsigned)p.H && (unsigned)(nx_ix0 + (l_rc[t] >> 16)) < (unsigned)p.W;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + nx_buf + (t * 8 + wave) * 1024), 16,
                                              ok ? (unsigned)(nx_origin + l_rel[t]) : kOOB, 0, 0, 0);
   };
-  // B fragment of pixel tile 0: lane (n, lhi) = output (n >> 3, n & 7), 16-byte chunk (c16 * 2 + lhi) ^ ((n & 7) + (tx >> 1))
-  const int b_base = ((2 * (l31 >> 3)) * kWsPW + 2 * (l31 & 7)) * 128;
-  int hk16[3];
+  // B fragment of pixel tile 0: lane (n, lhi) = output (oy, ox) = (n >> 3, n & 7) reads input (2 oy + ty, 2 ox + tx): pair
+  // (2 oy + ty) * 10 + ox + tx / 2, slot ((tx & 1) * 8 + c16 * 2 + lhi) ^ key; hk[tx / 2][ty / 2] = (lhi ^ key) * 16
+  const int oy_l = l31 >> 3, ox_l = l31 & 7;
+  const int b_base = (2 * oy_l * kWsPairs + ox_l) * 256;
+  int hk[3][3];
 #pragma unroll
-  for (int t2 = 0; t2 < 3; ++t2) hk16[t2] = (lhi ^ (((l31 & 7) + t2) & 7)) << 4;
-  char* part = smem + 2 * kWsPatchB;
+  for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) hk[a2][b2] = (lhi ^ (((ox_l + a2) & 3) | (((oy_l + b2) & 3) << 2))) << 4;
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
+  const unsigned ex0 = lds0 + 2u * kWsPatchB;
 
-  // finish of a patch, in three pieces (see ws_mfma): v = K quarters 0 + 1; + 2 + 3; scale / shift / activation / store
+  // Finish of a patch, in pieces hung between the MFMAs (see ws_mfma).  Every LDS access inside the patch loop is inline asm:
+  // hipcc orders a compiler-visible LDS access behind ALL earlier LDS-DMA loads (it put an `s_waitcnt vmcnt(0)` — the whole
+  // next patch — in front of the finish, in the middle of the MFMA walk).  ex_rd issues the four reads of two K quarters,
+  // ex_sum (two half-steps = two B reads later: lgkmcnt(2)) adds them up.
   float v[8];
+  float4_t fr[4];
   unsigned vo_prev = kOOB;            // where the patch whose sums sit in the exchange buffer goes (none yet)
-  const char* ex = part + ((2 * e_oct * 64 + (e_pix ^ e_oct)) << 4);
-  auto fin0 = [&]() {
-#pragma unroll
-    for (int e2 = 0; e2 < 2; ++e2) {
-      const float4_t f = *reinterpret_cast<const float4_t*>(ex + e2 * 1024), g = *reinterpret_cast<const float4_t*>(ex + 16384 + e2 * 1024);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e2 * 4 + e] = f[e] + g[e];
-    }
-  };
-  auto fin1 = [&]() {
-#pragma unroll
-    for (int e2 = 0; e2 < 2; ++e2) {
-      const float4_t f = *reinterpret_cast<const float4_t*>(ex + 32768 + e2 * 1024), g = *reinterpret_cast<const float4_t*>(ex + 49152 + e2 * 1024);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e2 * 4 + e] = (v[e2 * 4 + e] + f[e]) + g[e];
-    }
-  };
-  auto fin2 = [&]() {
+  const unsigned ex_addr = ex0 + (unsigned)((2 * e_oct * 64 + (e_pix ^ e_oct)) << 4);
+  auto fin_c = [&]() {
     half8_t o;
-    if (has_scale) {                  // (the scale table stays in LDS: 32 KiB of reads per patch that a bias-only layer does not pay)
-#pragma unroll
-      for (int e2 = 0; e2 < 2; ++e2) {
-        const float4_t f = *reinterpret_cast<const float4_t*>(tab + e_oct * 8 + e2 * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e2 * 4 + e] *= f[e];
-      }
-    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float u = v[e] + sh[e];
+      const float u = v[e] * sc[e] + sh[e];
       o[e] = (half_t)__builtin_fmaxf(u, u * act_k);
     }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo_prev, 0, FT_YSTORE_BUF_AUX);
   };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights and tables are in registers before the patch loads are counted
+  // ... and the compiler has to KNOW it: it cannot see the wait above, and would guard the first use of each of these registers
+  // inside the loop with its own vmcnt — a vmcnt(0), i.e. the whole next patch, in front of the finish's scale / shift
+#pragma unroll
+  for (int j = 0; j < kWsNJ; ++j) asm volatile("" : "+v"(wt[j]));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(sc[e]), "+v"(sh[e]));
   nx_set(p0, 0);
-  static_for<6>([&](auto tc) { issue_one(tc); });
+  static_for<NLD>([&](auto tc) { issue_one(tc); });
   int k = 0;
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;       // dev (FT_CD_DBG & 32): per-phase s_memtime sums of this wave
 #define WS_TS(i) do { if (p.dbg & 32) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[i] += t_ - tprev; tprev = t_; } } while (0)
@@ -231,14 +257,15 @@ __global__ __launch_bounds__(512, 1) void conv5x5s2_wstat_kernel(const WsParams 
       constexpr int t = decltype(tc)::value, r4 = decltype(rc)::value;
       const int G = c * 8 + lhi * 4 + r4, px = t * 32 + l31;
       const float4_t u = {acc[t][r4 * 4], acc[t][r4 * 4 + 1], acc[t][r4 * 4 + 2], acc[t][r4 * 4 + 3]};
-      *reinterpret_cast<float4_t*>(part + (((q * 16 + G) * 64 + (px ^ (G >> 1))) << 4)) = u;
+      ws_ex_wr(ex0 + (unsigned)((((q * 16 + G) * 64 + (px ^ (G >> 1))) << 4)), u);
     };
     auto hook = [&](auto hc) {
       constexpr int hs = decltype(hc)::value;
-      if constexpr (hs < 12 && hs % 2 == 0) issue_one(std::integral_constant<int, hs / 2>{});     // six loads, then the finish's store
-      if constexpr (hs == 5) fin0();
-      if constexpr (hs == 11) fin1();
-      if constexpr (hs == 17) fin2();
+      if constexpr (hs < 2 * NLD && hs % 2 == 0) issue_one(std::integral_constant<int, hs / 2>{});     // six loads, then the finish's store
+      if constexpr (hs == 1) ws_ex_rd<0>(ex_addr, fr);
+      if constexpr (hs == 3) { ws_ex_sum<0, 2>(fr, v); ws_ex_rd<1>(ex_addr, fr); }
+      if constexpr (hs == 5) ws_ex_sum<1, 2>(fr, v);
+      if constexpr (hs == 13) fin_c();
       if constexpr (hs >= 28 && hs < 44 && hs % 4 == 0) ex_write(std::integral_constant<int, 0>{}, std::integral_constant<int, (hs - 28) / 4>{});
       if constexpr (hs == 45) {
         const int img = id / tiles, rem = id - img * tiles;
@@ -251,12 +278,13 @@ __global__ __launch_bounds__(512, 1) void conv5x5s2_wstat_kernel(const WsParams 
     // between the tiles: everyone has taken the previous patch's sums out of the exchange buffer
     auto mid = [&]() { asm volatile("s_barrier" ::: "memory"); };
     switch (q) {
-      case 0: ws_mfma<0>(wt, abase, hk16, acc, hook, mid); break;
-      case 1: ws_mfma<1>(wt, abase, hk16, acc, hook, mid); break;
-      case 2: ws_mfma<2>(wt, abase, hk16, acc, hook, mid); break;
-      default: ws_mfma<3>(wt, abase, hk16, acc, hook, mid); break;
+      case 0: ws_mfma<0>(wt, abase, hk, acc, hook, mid); break;
+      case 1: ws_mfma<1>(wt, abase, hk, acc, hook, mid); break;
+      case 2: ws_mfma<2>(wt, abase, hk, acc, hook, mid); break;
+      default: ws_mfma<3>(wt, abase, hk, acc, hook, mid); break;
     }
     WS_TS(3);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the last MFMAs' results, read by inline asm: beyond any hazard window)
     static_for<4>([&](auto rc) { ex_write(std::integral_constant<int, 1>{}, rc); });
     vo_prev = vo_next;
     WS_TS(5);
@@ -272,7 +300,9 @@ __global__ __launch_bounds__(512, 1) void conv5x5s2_wstat_kernel(const WsParams 
     return;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  fin0(); fin1(); fin2();                                // the last patch
+  ws_ex_rd<0>(ex_addr, fr); ws_ex_sum<0, 0>(fr, v);
+  ws_ex_rd<1>(ex_addr, fr); ws_ex_sum<1, 0>(fr, v);
+  fin_c();                                               // the last patch
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead loads of the last trip must not outlive the workgroup's LDS
 #endif
 }
