@@ -69,6 +69,15 @@ __device__ __forceinline__ void unroll_for(F&& f) {
 #define FT_BNK_KEY_SHIFT 1
 #endif
 #define BNK_KEY(r) (((r) >> FT_BNK_KEY_SHIFT) & 7)
+// T1 (the 18- or 10-pixel-wide halo patch conv2's taps read at a row / column shift): ds_read_b128 serves lanes {0-3, 12-15,
+// 20-27} together = with 16-pixel tile rows: columns 0-3 and 12-15 of one patch row and 4-11 of the next.  Keyed by the linear
+// index (r >> 1 = 9 * row + column / 2) columns 12-13 of a row and 10-11 of the next share key AND 128-byte half: a 2-way
+// conflict in every such read (+1 LDS cycle on 4: the 30-33 % conflict cycles the PMC kept showing).  Keyed by the COLUMN pair
+// alone the sixteen lanes cover the sixteen slots.  (8-pixel tile rows: four rows x four columns per group; the old key stays.)
+#ifndef FT_BNK_T1_COLKEY
+#define FT_BNK_T1_COLKEY 1
+#endif
+template <int TW> __device__ __forceinline__ int bnk_t1_key(int r, int pc) { return (FT_BNK_T1_COLKEY && TW == 16) ? ((pc >> 1) & 7) : BNK_KEY(r); }
 
 constexpr int kC = 256, kP = 64;                 // block width / planes this kernel is written for
 // LDS map (bytes).  Phase 1: two 32-KiB stages (64-channel x chunk 24 KiB + W1 K-slice 8 KiB) at 0 .. 64 Ki.
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       const int iy = qy0 - 1 + pr, ix = qx0 - 1 + pc;
       const bool inside = r < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       char* rowp = t1 + r * 128 + lhi * 8;
-      const int rsw = BNK_KEY(r) << 4;
+      const int rsw = bnk_t1_key<TW>(r, pc) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         half4_t h;
@@ -308,11 +317,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   // wave -> output-channel tile wc2 = wave >> 1 x two 32-pixel tiles (wp2 = wave & 1)
   const int a2_row = wc2 * 32 + l31;
   const int a2_off = a2_row * 128 + ((lhi ^ BNK_KEY(a2_row)) << 4);
-  int r0[2];
+  int r0[2], c0[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = wp2 * 64 + j * 32 + l31;
     r0[j] = (m / TW) * PW + (m % TW);
+    c0[j] = m % TW;
   }
   float16_t acc2[2];
 #pragma unroll
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = r0[j] + ky * PW + kx;
-      const int lsw = lhi ^ BNK_KEY(r);
+      const int lsw = lhi ^ bnk_t1_key<TW>(r, c0[j] + kx);
       const char* rowp = t1 + r * 128;
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
