@@ -54,6 +54,7 @@ namespace {
 // would make hipcc drain the LDS-DMA queue with a vmcnt(0) per load (measured: 64 serialized L2 round trips per tile)
 constexpr int kSlabB = 32 * 1024;
 constexpr int kScaleOff = 24 * 1024, kShiftOff = 28 * 1024;
+constexpr int kTailBiasOff = 2048;     // bytes behind kShiftOff: the fused tail's 32 biases (MODE 1)
 constexpr int kMaxCout8 = 1024;
 typedef uint32_t uint2v_t __attribute__((ext_vector_type(2)));
 }  // namespace
@@ -129,6 +130,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvParams p)
     for (int c = tid; c < p.Cout_pad; c += 512) {
       ls[c] = p.scale ? p.scale[c] : 1.f;
       lh[c] = p.shift ? p.shift[c] : 0.f;
+    }
+    // MODE 1: the fused tail's bias as well (Cout <= 256 there: the upper half of the shift table is free).  Read with
+    // `bt[co]` in the tail's last lines it was TWELVE ordinary loads per lane per tile, each behind a vmcnt(0) = a serialized
+    // L2 round trip that also waits for the next tile's LDS-DMA and for the store before it.
+    if constexpr (MODE == 1) {
+      if (tid < 32) lh[kTailBiasOff / 4 + tid] = reinterpret_cast<const float*>(p.tail_w + (size_t)32 * kT8 * 2)[tid];
     }
     __syncthreads();
   }
@@ -478,7 +485,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvParams p)
     // hoisted out of the tile loop: kept live across the K-loop those cost 54 spilled registers, reloaded here one by one)
     const char* tw = p.tail_w;
     asm volatile("" : "+s"(tw));
-    const float* bt = reinterpret_cast<const float*>(tw + (size_t)32 * kT8 * 2);
     // the tail weights in THIS kernel's operand order (4th section of the tail pack, include/flowtrack_hip.h): fp16
     // [channel half wc][step st = (i, pr)][hi, lo][lane][8], lane (l31 = tail output, lhi) holding the weights of channels
     // wc * 128 + st * 16 + 4 lhi + {0..3} and + 8 + {0..3}: one coalesced 16-byte load per lane per (step, hi / lo) — gathered
@@ -535,11 +541,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvParams p)
 #pragma unroll
         for (int q4 = 0; q4 < 3; ++q4) {
           const float4_t o = slab[((wp * 2 + wc) * 3 + q4) * 64 + lane];
+          const float4_t bq = *reinterpret_cast<const float4_t*>(smem + kRingB + kShiftOff + kTailBiasOff + (8 * q4 + 4 * lhi) * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int co2 = e + 8 * q4 + 4 * lhi;
             if (co2 < p.tail_cout) {
-              const float v = a2[4 * q4 + e] + o[e] + bt[co2];
+              const float v = a2[4 * q4 + e] + o[e] + bq[e];
               if (p.out_layout == FT_LAYOUT_NHWC)
                 reinterpret_cast<half_t*>(p.y)[((long long)n * hw + pix) * p.y_cstride + p.y_coff + co2] = (half_t)v;
               else
