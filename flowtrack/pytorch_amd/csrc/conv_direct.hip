@@ -1628,7 +1628,8 @@ static int cd_dispatch(const CdParams& p, hipStream_t s) {
       default: return cd_launch<KSPLIT, HAS_RES, 0>(p, s);
     }
   }
-  switch (n) {       // K = 1024 / 2048 in 256-channel chunks
+  switch (n) {       // K = 512 (ResNet layer3.0.conv1) / 1024 / 2048 in 256-channel chunks
+    case 2: return cd_launch<KSPLIT, HAS_RES, 2>(p, s);
     case 4: return cd_launch<KSPLIT, HAS_RES, 4>(p, s);
     case 8: return cd_launch<KSPLIT, HAS_RES, 8>(p, s);
     default: return cd_launch<KSPLIT, HAS_RES, 0>(p, s);

@@ -200,7 +200,12 @@ double ft_conv_flops(const ft_conv_desc* d);
  * x2_* or an identity residual), for layers with few pixels and long K (ResNet layer3/4 at batch 64, blocks.py:89,95,
  * 98-103): a workgroup owns 96 pixels, the pixel operand streams through an LDS ring, each wave loads its weight
  * fragments from a fragment-ordered stream directly into registers (csrc/conv_direct.hip).
- *   ft_conv_direct_supported     FT_OK when the shape qualifies (Cin, x2_cin multiples of 64, Cout multiple of 256 — or
+ * The same five entry points also carry the other weight-streaming / weight-stationary forms (each with its own stream layout,
+ * told apart by ft_conv_direct_stream_id): 3x3 / stride 1 and 2 on whole small maps or row strips (512 / 1024 channels: ResNet
+ * layer4's conv2, blocks.py:92-95; FlowNet conv5 .. conv6_1, FlowNetS.py:27-32), the 3x3 gather form, the persistent K = 256
+ * form, and — round 4 — the REGISTER-STATIONARY 5x5 / stride 2 / pad 2 form on 64 input channels with Cout % 64 == 0 (FlowNet's
+ * conv2, FlowNetS.py:21: csrc/conv_wstat.hip; plain NHWC fp16 input and output, no residual / second input).
+ *   ft_conv_direct_supported     FT_OK when the shape qualifies (1x1: Cin, x2_cin multiples of 64, Cout multiple of 256 — or
  *                                Cin, x2_cin multiples of 256 and Cout of 64 for the K-split form)
  *   ft_conv_direct_weight_bytes  size of the weight stream
  *   ft_conv_direct_pack          builds it from the ft_conv_pack_geometry layout w_packed [cout_pad][kpad] (once per weight set)
