@@ -447,7 +447,13 @@ __device__ __forceinline__ void corr_unroll(F&& f) {
 // the staged band: 87 us.
 // NRS = 2: eight waves, the second four take the upper half of the R output rows with their own f1 fragments and read the
 // same ring: two waves per SIMD, one's band stores issue while the other's products run on the matrix pipe.
-template <int KS, int R, int DRAD, bool STAGED, int NRS>
+typedef uint32_t corr_u2_t __attribute__((ext_vector_type(2)));
+// TR (round 4): the products TRANSPOSED — f2 window columns as the MFMA's rows, f1 pixels as its columns — so that a lane owns ONE
+// output pixel and its accumulator registers walk the displacement axis: the four registers of a group are four CONSECUTIVE
+// x-displacements = 8 contiguous output bytes.  A group that lies wholly inside the band leaves as one 8-byte store (2-byte
+// aligned: the 441-channel rows have no better alignment), a group cut by the band's end as up to three 2-byte stores: 7.5 lane
+// stores per pixel and y-displacement on average instead of 21 — the kernel is bound by the issue of scattered lane stores.
+template <int KS, int R, int DRAD, bool STAGED, int NRS, bool TR = false>
 __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
                                                                           half_t* __restrict__ y, int H, int W, unsigned f2_bytes,
                                                                           unsigned y_bytes, int f_cstride, int y_cstride, int y_coff,
@@ -540,8 +546,14 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
   // act(v) = max(v, s*v) for s in [0, 1] (relu: 0, leaky: slope, none: 1); the 1/C of the correlation rides along
   const float k_pos = inv_c, k_neg = inv_c * (act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f));
   const int yrow_bytes = W * y_cstride * 2;
-  unsigned s_voff[STAGED ? 1 : 16];              // !STAGED: the band leaves as 2-byte stores in the accumulator layout
-  if constexpr (!STAGED) {
+  unsigned s_voff[(STAGED || TR) ? 1 : 16];      // !STAGED: the band leaves as 2-byte stores in the accumulator layout
+  // TR: lane (c, h) = f1 pixel x = 2c + par; register 4 gq + e = window column 8 gq + 4 h + e of this half: displacement index
+  // dxi = 32 jt + 8 gq + 4 h + e - c.  t_base = byte offset of (pixel, dxi of gq = e = 0); group gq / element e ride in the
+  // instruction's immediate offset.
+  const int t_dxi0 = 32 * jt + 4 * h - c;
+  const bool t_px = 2 * c + par < W;
+  const unsigned t_base = (unsigned)((((n * H) * W + 2 * c + par) * y_cstride + y_coff + t_dxi0) * 2);
+  if constexpr (!STAGED && !TR) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int G = (g & 3) + 8 * (g >> 2);
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
     constexpr int slot = jj % 3;
     // row jj has landed (this wave's share).  !STAGED: behind it row jj+1 and the 16*R band stores of the previous step may fly
     if constexpr (STAGED || jj == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL + 16 * RW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL + (TR ? 20 : 16) * RW) : "memory");
     asm volatile("s_barrier" ::: "memory");               // everyone's has; everyone is done reading the slot refilled now
     issue(jj + 2, (jj + 2) % 3);
     const int j = i0 - DRAD + jj;
@@ -579,7 +591,42 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
         const int r = rs * RW + rw;                      // wave-uniform
         const int dyi = jj - r;
         const bool live = dyi >= 0 && dyi < D && i0 + r < Hq;
-        if (live) {
+        if constexpr (TR) {
+          // always 4 x (one 8-byte + four 2-byte) stores per (step, row), most of them out of range, so that the waits can count
+          if (live) {
+            float16_t acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            if (row_ok) {
+#pragma unroll
+              for (int s = 0; s < KS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, b[s]), __builtin_bit_cast(half8_t, a[rw][s]), acc, 0, 0, 0);
+            }
+            const int soff = (2 * (i0 + r) + q) * yrow_bytes + dyi * D * 2;
+            corr_unroll<4>([&](auto gc) {
+              constexpr int gq = decltype(gc)::value;
+              const int d0 = t_dxi0 + 8 * gq;                          // displacement index of element 0
+              const bool full = t_px && d0 >= 0 && d0 + 3 < D;
+              half_t hv[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[e] = (half_t)__builtin_fmaxf(acc[4 * gq + e] * k_pos, acc[4 * gq + e] * k_neg);
+              const half4_t h4 = {hv[0], hv[1], hv[2], hv[3]};
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(corr_u2_t, h4), rsrc_y, full ? t_base + 16 * gq : kOOB, soff, 0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const bool one = t_px && !full && (unsigned)(d0 + e) < (unsigned)D;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv[e]), rsrc_y, one ? t_base + 16 * gq + 2 * e : kOOB, soff, 0);
+              }
+            });
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              __builtin_amdgcn_raw_buffer_store_b64(corr_u2_t{0u, 0u}, rsrc_y, kOOB, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rsrc_y, kOOB, 0, 0);
+            }
+          }
+        } else if (live) {
           float16_t acc;
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -1112,8 +1159,10 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
       static const bool stg = getenv("FT_CORR_STAGED") && atoi(getenv("FT_CORR_STAGED")) == 1;   // dev A/B: band through LDS
       static const bool w8 = !(getenv("FT_CORR_WAVES") && atoi(getenv("FT_CORR_WAVES")) == 4);     // dev A/B: four waves, R = 3
       const int R = (stg || !w8) ? 3 : 4;
+      static const bool tr = getenv("FT_CORR_TR") && atoi(getenv("FT_CORR_TR")) == 1;               // dev A/B: 1 = the transposed band (slower)
       auto k = stg ? correlation_mfma_rows64_kernel<16, 3, 10, true, 1>
-                   : (w8 ? correlation_mfma_rows64_kernel<16, 4, 10, false, 2> : correlation_mfma_rows64_kernel<16, 3, 10, false, 1>);
+                   : (w8 ? (tr ? correlation_mfma_rows64_kernel<16, 4, 10, false, 2, true> : correlation_mfma_rows64_kernel<16, 4, 10, false, 2>)
+                         : correlation_mfma_rows64_kernel<16, 3, 10, false, 1>);
       constexpr size_t ldst = 3 * 64 * 512 + 512 + 3 * 64 * (8 * 21 * 2) + 128;
       static bool raised[64] = {};
       int dev = 0;
