@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FT_LIB_PATH") or os.path.join(HERE, "libflowtrack_hip.so")  # FT_LIB_PATH: developer A/B builds
 
 FT_OK = 0
+FT_ERR_UNSUPPORTED = 2   # ft_status: valid but not implemented for this combination
 FT_F16, FT_F32 = 0, 1
 FT_ACT_NONE, FT_ACT_RELU, FT_ACT_LEAKY = 0, 1, 2
 FT_LAYOUT_NHWC, FT_LAYOUT_NCHW_F32 = 0, 1
@@ -36,7 +37,7 @@ class ConvDesc(ctypes.Structure):
         ("res_cstride", c_int), ("res_coff", c_int), ("act", c_int), ("slope", c_float),
         ("x_lpad", c_int), ("x_wpitch", c_int), ("tile_hint", c_int),
         ("x2_cin", c_int), ("x2_hi", c_int), ("x2_wi", c_int), ("x2_cstride", c_int), ("x2_coff", c_int), ("x2_stride", c_int),
-        ("tail_cout", c_int), ("pool", c_int),
+        ("tail_cout", c_int), ("pool", c_int), ("shift_nstride", c_int),
     ]
 
 
@@ -110,6 +111,11 @@ _PROTOTYPES = {
     "ft_flow_rgb_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ft_flow_pack_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 7 + [c_void_p]),
     "ft_flow_mean_pack_pair_state_words": (ctypes.c_longlong, [c_int, c_int, c_int]),
+    "ft_flow_pack_pair_sums_chunks": (ctypes.c_longlong, [c_int]),
+    "ft_conv_shift_nstride_supported": (c_int, [POINTER(ConvDesc)]),
+    "ft_flow_pack_pair_sums": (c_int, [c_void_p, c_float, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "ft_flow_mean_fold": (c_int, [c_void_p, c_float, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
     "ft_flow_mean_pack_pair": (c_int, [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_int] * 4
                                + [c_void_p, c_void_p, c_void_p]),
     "ft_upsample_bilinear4x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -580,6 +580,104 @@ __global__ __launch_bounds__(256) void flow_pack_pair4_kernel(const float* __res
   }
 }
 
+// ---- the rgb mean folded into conv1 (include/flowtrack_hip.h, ft_flow_pack_pair_sums / ft_flow_mean_fold) -------------------
+// Pass 1: one workgroup = FT_PACK_SUMS_ROWS image rows of one sample.  x / rgb_max leaves as fp16 into the row-AND-column padded
+// view (the padding pixels are pass 2's), the colour sums of the rows (both frames) leave as one partial per (sample, colour,
+// chunk): fixed order inside the workgroup (lane-local over its groups, xor-butterfly, the four waves), fixed order in pass 2.
+__global__ __launch_bounds__(256) void flow_pack_pair_sums_kernel(const float* __restrict__ in, float rgb_max, half_t* __restrict__ y,
+                                                                  int H, int W, int pad, int wpitch, int nchunk,
+                                                                  float* __restrict__ partial) {
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+  const int r0 = chunk * FT_PACK_SUMS_ROWS;
+  const int rows = H - r0 < FT_PACK_SUMS_ROWS ? H - r0 : FT_PACK_SUMS_ROWS;
+  const size_t HW = (size_t)H * W;
+  const int W4 = W >> 2;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int idx = threadIdx.x; idx < rows * W4; idx += 256) {
+    const int r = idx / W4, g = idx - r * W4;
+    const int yy = r0 + r;
+    float4_t v[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        v[f][c] = *reinterpret_cast<const float4_t*>(in + (((size_t)b * 3 + c) * 2 + f) * HW + (size_t)yy * W + 4 * g);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      s[c] += ((v[0][c][0] + v[0][c][1]) + (v[0][c][2] + v[0][c][3])) + ((v[1][c][0] + v[1][c][1]) + (v[1][c][2] + v[1][c][3]));
+    half_t* yr = y + (((size_t)b * (H + 2 * pad) + pad + yy) * wpitch + pad + 4 * g) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float o[8] = {v[0][0][e] / rgb_max, v[0][1][e] / rgb_max, v[0][2][e] / rgb_max,
+                          v[1][0][e] / rgb_max, v[1][1][e] / rgb_max, v[1][2][e] / rgb_max, 0.f, 0.f};
+      store8<half_t>(yr + e * 8, o);
+    }
+  }
+  __shared__ float sw[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[c] += __shfl_xor(s[c], off);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6][c] = s[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    partial[((size_t)b * 3 + c) * nchunk + chunk] = (sw[0][c] + sw[1][c]) + (sw[2][c] + sw[3][c]);
+  }
+}
+
+// Pass 2: grid (B, K).  Every workgroup re-derives its sample's means (3 x nchunk floats, the same order everywhere), then
+// takes its share of the sample's padding pixels; workgroup (b, 0) also writes mean[b] and the sample's shift vector.
+__global__ __launch_bounds__(256) void flow_mean_fold_kernel(const float* __restrict__ partial, int nchunk, float inv_L, float rgb_max,
+                                                             half_t* __restrict__ y, int H, int W, int pad, int wpitch,
+                                                             const float* __restrict__ wsum, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int Cout, float* __restrict__ shift_n,
+                                                             float* __restrict__ mean) {
+  const int b = blockIdx.x;
+  float m[3] = {0.f, 0.f, 0.f}, mf[3];
+  const float* pb = partial + (size_t)b * 3 * nchunk;
+  for (int i = threadIdx.x & 63; i < nchunk; i += 64) {     // the three colours' loads of a round fly together
+    m[0] += pb[i];
+    m[1] += pb[nchunk + i];
+    m[2] += pb[2 * nchunk + i];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m[c] += __shfl_xor(m[c], off);
+    m[c] *= inv_L;
+    mf[c] = (float)(half_t)(m[c] / rgb_max);
+  }
+  if (blockIdx.y == 0) {
+    if (threadIdx.x < 3) mean[b * 3 + threadIdx.x] = m[threadIdx.x];
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+      const float* w = wsum + co * 8;
+      const float corr = ((mf[0] * w[0] + mf[1] * w[1]) + mf[2] * w[2]) + ((mf[0] * w[3] + mf[1] * w[4]) + mf[2] * w[5]);
+      shift_n[(size_t)b * Cout + co] = (shift ? shift[co] : 0.f) - (scale ? scale[co] : 1.f) * corr;
+    }
+  }
+  // padding pixels of the sample: `pad` full rows on top, `pad` at the bottom, then per image row the left `pad` and the right
+  // wpitch - pad - W columns
+  const float o[8] = {mf[0], mf[1], mf[2], mf[0], mf[1], mf[2], 0.f, 0.f};
+  const int nfull = 2 * pad * wpitch, nside = wpitch - W;
+  const int total = nfull + H * nside;
+  half_t* yb = y + (size_t)b * (H + 2 * pad) * wpitch * 8;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < total; i += gridDim.y * 256) {
+    int row, col;
+    if (i < nfull) {
+      const int r = i / wpitch;
+      col = i - r * wpitch;
+      row = r < pad ? r : H + r;            // r in [pad, 2 pad): rows H + pad ...
+    } else {
+      const int j = i - nfull, r = j / nside, k = j - r * nside;
+      row = pad + r;
+      col = k < pad ? k : W + k;            // k in [pad, nside): columns pad + W ...
+    }
+    store8<half_t>(yb + ((size_t)row * wpitch + col) * 8, o);
+  }
+}
+
 // ---- nn.Upsample(scale_factor=4, mode='bilinear'), align_corners=False, times `mul` -------------
 __global__ __launch_bounds__(256) void upsample_bilinear4x_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   int h, int w, size_t total, float mul) {
@@ -827,6 +925,39 @@ extern "C" int ft_flow_pack_pair(const float* inputs, const float* mean, float r
     hipLaunchKernelGGL(flow_pack_pair_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), inputs, mean,
                        rgb_max, static_cast<float*>(y), B, H, W, lpad, wpitch, total, mode);
   FT_LAUNCH_CHECK("flow_pack_pair_kernel");
+  return FT_OK;
+}
+
+extern "C" long long ft_flow_pack_pair_sums_chunks(int H) { return H > 0 ? (H + FT_PACK_SUMS_ROWS - 1) / FT_PACK_SUMS_ROWS : 0; }
+
+extern "C" int ft_flow_pack_pair_sums(const float* inputs, float rgb_max, void* y, int B, int H, int W, int pad, int wpitch, int dtype,
+                                      float* partial, ft_stream_t stream) {
+  if (!inputs || !y || !partial || B <= 0 || H <= 0 || W <= 0 || pad < 0 || wpitch < W + 2 * pad || rgb_max == 0.f)
+    return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(inputs) & 15) != 0) return FT_ERR_UNSUPPORTED;
+  const int nchunk = (int)ft_flow_pack_pair_sums_chunks(H);
+  if ((long long)B * nchunk > 0x7fffffffLL) return FT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(flow_pack_pair_sums_kernel, dim3(B * nchunk), dim3(256), 0, as_stream(stream), inputs, rgb_max,
+                     static_cast<half_t*>(y), H, W, pad, wpitch, nchunk, partial);
+  FT_LAUNCH_CHECK("flow_pack_pair_sums_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_flow_mean_fold(const float* partial, float rgb_max, void* y, int B, int H, int W, int pad, int wpitch, int dtype,
+                                 const float* wsum, const float* scale, const float* shift, int Cout, float* shift_n, float* mean,
+                                 ft_stream_t stream) {
+  if (!partial || !y || !wsum || !shift_n || !mean || B <= 0 || H <= 0 || W <= 0 || pad < 0 || wpitch < W + 2 * pad || Cout <= 0 ||
+      rgb_max == 0.f)
+    return FT_ERR_INVALID_ARG;
+  if (dtype != FT_F16) return FT_ERR_UNSUPPORTED;
+  const int nchunk = (int)ft_flow_pack_pair_sums_chunks(H);
+  const int total = 2 * pad * wpitch + H * (wpitch - W);
+  int k = (total + 1023) / 1024;            // ~4 padding pixels per thread
+  k = k < 1 ? 1 : (k > 16 ? 16 : k);
+  hipLaunchKernelGGL(flow_mean_fold_kernel, dim3(B, k), dim3(256), 0, as_stream(stream), partial, nchunk,
+                     1.0f / ((float)2 * H * W), rgb_max, static_cast<half_t*>(y), H, W, pad, wpitch, wsum, scale, shift, Cout, shift_n,
+                     mean);
+  FT_LAUNCH_CHECK("flow_mean_fold_kernel");
   return FT_OK;
 }
 

@@ -62,6 +62,7 @@ struct ConvParams {
   unsigned y_bytes;   // conv_igemm8_kernel: size of the output buffer (buffer descriptor range of its direct stores)
   unsigned w_bytes;   // conv_igemm8_kernel: size of the packed weight set (all phases and channel tiles)
   int dbg;            // developer ablation (FT_CONV_DBG): 1 = no MFMA, 2 = no operand loads, 4 = no epilogue; 0 in production
+  int shift_n;        // > 0: `shift` is per sample, [N][shift_n] floats (conv_stem_persist_kernel only)
 };
 
 template <typename T> struct Elem;

@@ -1482,6 +1482,12 @@ __global__ __launch_bounds__(512, 1) void conv_stem_persist_kernel(const ConvPar
     // patch(t) was issued before the previous tile's NST stores: it has landed once at most NST operations are outstanding
     if (it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     FT_LDS_BARRIER();            // everyone's pieces of patch(t); every read of the other patch buffer and of the output tile is done
+    if (p.shift_n) {             // per-sample shift (FlowNet2S's rgb mean folded into conv1, ft_flow_mean_fold): issued AHEAD of the
+                                 // look-ahead patch loads, so the wait in front of the epilogue leaves those in flight
+      const int ns = t < t_hi ? t / tiles_per_img : 0;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) sh[g4] = *reinterpret_cast<const float4_t*>(p.shift + (size_t)ns * p.shift_n + wc * 32 + g4 * 8 + lhi * 4);
+    }
     load_patch(t + 2, buf ^ 1);
 
     float16_t acc[MT_P];
@@ -2334,6 +2340,22 @@ static int launch_stem_nt(const ConvParams& p, int nt, dim3 grid, size_t lds, hi
   return launch_stem_k<KH, STRIDE, RUNB, 1>(p, grid, lds, s);
 }
 
+// geometry of the persistent stem form for `d` (pw / npww / lds), or false where it does not apply
+static bool stem_persist_plan(const ft_conv_desc* d, const Geometry& g, int* pw_out, int* npww_out, size_t* lds_out, int* ntiles_out) {
+  static const bool no_persist = getenv("FT_STEM_PERSIST") && atoi(getenv("FT_STEM_PERSIST")) == 0;
+  const int runb = g.cin_pad * 2, cpb = d->x_cstride * 2;
+  const int ph = 7 * d->stride + d->kh;
+  const int rb1 = 15 * d->stride * cpb + runb;
+  const int pw = (d->stride == 2 && cpb == 16) ? round_up(ceil_div(rb1, 16), 2) : ceil_div(rb1, 16);   // the kernel's parity swizzle pairs chunks
+  const int npww = ceil_div(ceil_div(ph * pw, 64), 4);
+  const size_t lds = (size_t)d->kh * 64 * runb + 2 * (2 * (size_t)npww * 4096 + 16384);   // weights + two quartets' patch pair and output tile
+  const long long ybytes = (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2;
+  const int ntiles = d->N * ceil_div(d->Ho, 8) * ceil_div(d->Wo, 16);
+  if (no_persist || d->kh != 7 || npww > 12 || lds > 160 * 1024 || ybytes >= (1LL << 31) || ntiles < 512) return false;
+  *pw_out = pw; *npww_out = npww; *lds_out = lds; *ntiles_out = ntiles;
+  return true;
+}
+
 static int launch_stem(ConvParams p, const ft_conv_desc* d, const Geometry& g, hipStream_t s) {
   const int runb = g.cin_pad * 2, cpb = d->x_cstride * 2;
   const int ph = 7 * d->stride + d->kh;
@@ -2345,14 +2367,10 @@ static int launch_stem(ConvParams p, const ft_conv_desc* d, const Geometry& g, h
     nt = 1;
   {
     // persistent weight-stationary form (one workgroup per CU walks many 8 x 16 tiles): FT_STEM_PERSIST=0 keeps the per-tile kernel
-    static const bool no_persist = getenv("FT_STEM_PERSIST") && atoi(getenv("FT_STEM_PERSIST")) == 0;
-    const int rb1 = 15 * d->stride * cpb + runb;
-    const int pw = (d->stride == 2 && cpb == 16) ? round_up(ceil_div(rb1, 16), 2) : ceil_div(rb1, 16);   // the kernel's parity swizzle pairs chunks
-    const int npww = ceil_div(ceil_div(ph * pw, 64), 4);
-    const size_t lds = (size_t)d->kh * 64 * runb + 2 * (2 * (size_t)npww * 4096 + 16384);   // weights + two quartets' patch pair and output tile
+    int pw, npww, ntiles;
+    size_t lds;
     const long long ybytes = (long long)d->N * d->Ho * d->Wo * d->y_cstride * 2;
-    const int ntiles = d->N * ceil_div(d->Ho, 8) * ceil_div(d->Wo, 16);
-    if (!no_persist && d->kh == 7 && npww <= 12 && lds <= 160 * 1024 && ybytes < (1LL << 31) && ntiles >= 512) {
+    if (stem_persist_plan(d, g, &pw, &npww, &lds, &ntiles)) {
       p.h_pw = pw;
       p.h_npww = npww;
       p.h_pb = npww * 4 * 1024;
@@ -2373,6 +2391,7 @@ static int launch_stem(ConvParams p, const ft_conv_desc* d, const Geometry& g, h
       return FT_OK;
     }
   }
+  if (p.shift_n) return FT_ERR_UNSUPPORTED;              // the per-tile kernel reads one shared shift vector
   const int tws = 16 * nt;
   const int rb = (tws - 1) * d->stride * cpb + runb;     // bytes of one patch row
   p.h_pw = ceil_div(rb, 16);
@@ -2478,6 +2497,24 @@ static bool halo_ok(const ft_conv_desc* d, const Geometry& g) {
   if (!g.dma || d->dtype != FT_F16 || d->has_residual) return false;
   if (!(d->transposed || (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1))) return false;
   return d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 && d->y_cstride % 8 == 0;
+}
+
+// ft_conv_desc.shift_nstride: the persistent row-packed 7x7 / stride 2 fp16 stem only
+static bool shift_n_ok(const ft_conv_desc* d, const Geometry& g) {
+  if (d->shift_nstride < d->Cout || d->shift_nstride % 4 || d->pool || d->tail_cout > 0 || d->x2_cin > 0 || d->kh != 7 || d->stride != 2)
+    return false;
+  if (!stem_ok(d, g)) return false;
+  if ((unsigned long long)d->N * d->Hi * d->x_wpitch * d->x_cstride * 2 >= (1ull << 31)) return false;
+  int pw, npww, ntiles;
+  size_t lds;
+  return stem_persist_plan(d, g, &pw, &npww, &lds, &ntiles);
+}
+
+extern "C" int ft_conv_shift_nstride_supported(const ft_conv_desc* d) {
+  Geometry g;
+  const int st = geometry(d, &g);
+  if (st != FT_OK) return st;
+  return shift_n_ok(d, g) ? FT_OK : FT_ERR_UNSUPPORTED;
 }
 
 constexpr int kHintSkShift = 21;     // tile_hint bits 21-23: the cross-workgroup K split (needs a workspace): codes 0..3 = 1, 2, 4, 8
@@ -2756,6 +2793,7 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   p.nph = g.nphases;
   static const int dbg = env_int("FT_CONV_DBG");
   p.dbg = dbg;
+  p.shift_n = d->shift_nstride;
   p.epi_lds = d->dtype == FT_F16 && d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 &&
               d->y_cstride % 8 == 0 && (!d->has_residual || (d->res_coff % 8 == 0 && d->res_cstride % 8 == 0));
   hipStream_t s = as_stream(stream);
@@ -2763,6 +2801,11 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   const unsigned long long x_bytes =
       (unsigned long long)d->N * d->Hi * (d->x_wpitch > 0 ? d->x_wpitch : d->Wi) * d->x_cstride * esz;
 
+  if (d->shift_nstride != 0) {      // per-sample shift: straight to the persistent stem, the one kernel that reads it
+    if (!shift || !shift_n_ok(d, g)) return FT_ERR_UNSUPPORTED;
+    p.x_bytes = (unsigned)x_bytes;
+    return launch_stem(p, d, g, s);
+  }
   if (d->pool) {            // stem + max-pool: y is the pooled [N, Ho/2, Wo/2, Cout] map
     if (!g.rowpack || x_bytes >= (1ull << 31) || d->tail_cout > 0 || d->x2_cin > 0 || d->has_residual) return FT_ERR_UNSUPPORTED;
     p.x_bytes = (unsigned)x_bytes;

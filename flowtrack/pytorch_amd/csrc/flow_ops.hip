@@ -453,8 +453,15 @@ typedef uint32_t corr_u2_t __attribute__((ext_vector_type(2)));
 // x-displacements = 8 contiguous output bytes.  A group that lies wholly inside the band leaves as one 8-byte store (2-byte
 // aligned: the 441-channel rows have no better alignment), a group cut by the band's end as up to three 2-byte stores: 7.5 lane
 // stores per pixel and y-displacement on average instead of 21 — the kernel is bound by the issue of scattered lane stores.
-template <int KS, int R, int DRAD, bool STAGED, int NRS, bool TR = false>
-__global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
+// DIRECT (round 4, second form): the tile's columns are the IMAGE columns of this parity (32 of them at W <= 64) instead of two
+// 32-column halves of the 104-column window — half the MFMAs and half the band store instructions per (f2 row, output row).
+// The band of f1 pixel i then is f2 pixel i2 = i + dxi - DRAD in [0, 32); the displacements that fall off the image
+// (i2 < 0 or >= 32: structural zeros the window form produced from its zero columns) are written by the lanes of the
+// columns i2 mod 32, which are out of band for that row: every lane slot with (c - i + DRAD) mod 32 < D stores, a real product
+// where the difference did not wrap, zero where it did.  NWV waves = NWV / 2 output rows x 2 column parities, one row per wave
+// (six waves / R = 3 give 256 workgroups at 16 x 48 rows, eight / R = 4 give 192).
+template <int KS, int R, int DRAD, bool STAGED, int NRS, bool TR = false, bool DIRECT = false, int NWV = 4 * NRS>
+__global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
                                                                           half_t* __restrict__ y, int H, int W, unsigned f2_bytes,
                                                                           unsigned y_bytes, int f_cstride, int y_cstride, int y_coff,
                                                                           int act, float slope, int ngy) {
@@ -462,20 +469,26 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
   constexpr int C = KS * 16, ROWB = C * 2;
   constexpr int D = 2 * DRAD + 1, WROWS = 64 + 4 * DRAD;
   constexpr int NJ = R + 2 * DRAD;          // f2 rows of the class this workgroup walks
-  constexpr int RW = R / NRS;               // output rows per wave
-  constexpr int SLOT = 64 * ROWB, NL = SLOT / 1024 / (4 * NRS);
-  static_assert(R % NRS == 0 && (NRS == 1 || !STAGED), "row sets");
-  constexpr int ZROW = 3 * SLOT, STG = ZROW + ROWB;
+  constexpr int NSETS = DIRECT ? NWV / 2 : NRS;   // row sets among the waves
+  constexpr int RW = R / NSETS;             // output rows per wave
+  constexpr int SLOT = 64 * ROWB, NL = (SLOT / 1024 + NWV - 1) / NWV;   // wave-loads per wave and ring row (the last ones may fall behind the slot: scratch)
+  static_assert(R % NSETS == 0 && (NRS == 1 || !STAGED) && !(DIRECT && (STAGED || TR)) && (!DIRECT || D <= 32) && NWV % 2 == 0, "row sets");
+  // DIRECT: four ring slots, rows issued THREE steps ahead.  vmcnt counts loads and stores in one queue, in order, so "row jj has
+  // landed" can only be asked as "everything older than the ops issued after it is done"; at distance three the stores of three
+  // steps may still be in flight (vmcnt(2 NL + 48) <= 63).  Measured: no gain over distance two (52.0 vs 51.6 us) — the store
+  // round trip is not what a step waits for; kept because it costs nothing.
+  constexpr int DEPTH = DIRECT ? 3 : 2, NSLOT = DEPTH + 1;
+  constexpr int ZROW = NSLOT * SLOT, STG = ZROW + ROWB;
   constexpr int GD = 8;
   constexpr int PROW = GD * D * 2;          // bytes of a pixel's run per group
   constexpr int TILE = 64 * PROW;           // the transpose tile of one output row
   constexpr int DUMMY = STG + R * TILE;     // 128 bytes: where the lanes outside the band write
-  static_assert(PROW % 16 == 0 && (!STAGED || DUMMY + 128 <= 160 * 1024) && ROWB == 512 && NL * 4 * NRS * 1024 == SLOT, "shape");
+  static_assert(PROW % 16 == 0 && (!STAGED || DUMMY + 128 <= 160 * 1024) && ROWB == 512 && (DIRECT || NL * NWV * 1024 == SLOT), "shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int par = wave & 1, jt = (wave >> 1) & 1, rs = wave >> 2;
+  const int par = wave & 1, jt = DIRECT ? 0 : (wave >> 1) & 1, rs = DIRECT ? wave >> 1 : wave >> 2;
   const int c = lane & 31, h = lane >> 5;
   int n, q, i0;
   {
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
   // operand B: column = window pixel 64*jt + 2*c + par = image column x2 (ring row x2), the zero row outside the image
   int wr = 64 * jt + 2 * c + par;
   wr = wr < WROWS ? wr : WROWS - 1;
-  const int x2 = wr - 2 * DRAD;
+  const int x2 = DIRECT ? 2 * c + par : wr - 2 * DRAD;
   const bool in_img = (unsigned)x2 < (unsigned)W;
   const int b_base = in_img ? x2 * ROWB : ZROW - 0;      // slot-relative for image columns; ZROW is absolute (see b_abs)
   const int b_key = in_img ? (x2 >> 1) & 15 : 0;
@@ -518,10 +531,10 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
   unsigned l_voff[NL];
 #pragma unroll
   for (int t = 0; t < NL; ++t) {
-    const int i = t * 4 * NRS + wave;
+    const int i = t * NWV + wave;
     const int row = i * 2 + (lane >> 5), pos = lane & 31;
     const int lc = pos ^ ((row >> 1) & 15);
-    l_voff[t] = row < W ? (unsigned)(((n * H) * W + row) * f_cstride * 2 + lc * 16) : kOOB;
+    l_voff[t] = (row < W && i < SLOT / 1024) ? (unsigned)(((n * H) * W + row) * f_cstride * 2 + lc * 16) : kOOB;
   }
   const int row_bytes = W * f_cstride * 2;
   auto issue = [&](int jj, int slot) {       // always NL loads per wave: rows outside the image / past the walk are out of range
@@ -530,20 +543,25 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
     const int soff = row_ok ? (2 * j + q) * row_bytes : 0;
 #pragma unroll
     for (int t = 0; t < NL; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + slot * SLOT + (t * 4 * NRS + wave) * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(t * NWV + wave < SLOT / 1024 ? smem + slot * SLOT + (t * NWV + wave) * 1024
+                                                                                           : smem + STG + 128), 16,
                                                row_ok ? l_voff[t] : kOOB, soff, 0, 0);
   };
   // band lanes: accumulator register g of lane (c, h) = f1 pixel rr = G(g) + 4h (of this column parity) x window column c
   // -> displacement index dxi = c + 32*jt - rr, kept when 0 <= dxi < D and the pixel lies inside the image
-  const int dxi0 = c + 32 * jt - 4 * h;
+  const int dxi0 = DIRECT ? c - 4 * h + DRAD : c + 32 * jt - 4 * h;
   const int lane_base = STG + (8 * h + par) * PROW + dxi0 * 2;     // byte of (pixel 2*(4h) + par, dxi0) of tile 0
-  int vmask = 0;
+  int vmask = 0, realmask = 0;       // DIRECT: stores / stores that carry a product (the others are the off-image zeros)
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int G = (g & 3) + 8 * (g >> 2);
-    if ((unsigned)(dxi0 - G) < (unsigned)D && 2 * (G + 4 * h) + par < W) vmask |= 1 << g;
+    const int dr = dxi0 - G, dd = DIRECT ? dr & 31 : dr;
+    if ((unsigned)dd < (unsigned)D && 2 * (G + 4 * h) + par < W) vmask |= 1 << g;
+    if (dd == dr) realmask |= 1 << g;
   }
   // act(v) = max(v, s*v) for s in [0, 1] (relu: 0, leaky: slope, none: 1); the 1/C of the correlation rides along
+  const int cdbg = DIRECT ? act >> 8 : 0;      // developer ablation (FT_CORR_DBG): 1 = every band store out of range, 2 = no MFMAs; 0 in production
+  if constexpr (DIRECT) act &= 0xff;
   const float k_pos = inv_c, k_neg = inv_c * (act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f));
   const int yrow_bytes = W * y_cstride * 2;
   unsigned s_voff[(STAGED || TR) ? 1 : 16];      // !STAGED: the band leaves as 2-byte stores in the accumulator layout
@@ -558,22 +576,24 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
     for (int g = 0; g < 16; ++g) {
       const int G = (g & 3) + 8 * (g >> 2);
       const int x = 2 * (G + 4 * h) + par;
-      s_voff[g] = ((vmask >> g) & 1) ? (unsigned)(((n * H) * W + x) * y_cstride + y_coff + dxi0 - G) * 2u : kOOB;
+      const int dd = DIRECT ? (dxi0 - G) & 31 : dxi0 - G;
+      s_voff[g] = (((vmask >> g) & 1) && !(cdbg & 1)) ? (unsigned)(((n * H) * W + x) * y_cstride + y_coff + dd) * 2u : kOOB;
     }
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
-  issue(0, 0);
-  issue(1, 1);
+  corr_unroll<DEPTH>([&](auto pc) { issue(decltype(pc)::value, decltype(pc)::value); });
   corr_unroll<NJ>([&](auto jc) {
     constexpr int jj = decltype(jc)::value;
-    constexpr int slot = jj % 3;
+    constexpr int slot = jj % NSLOT;
     // row jj has landed (this wave's share).  !STAGED: behind it row jj+1 and the 16*R band stores of the previous step may fly
-    if constexpr (STAGED || jj == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");
+    // (DIRECT: rows jj+1, jj+2 and the stores of up to three steps)
+    if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((DEPTH - 1) * NL + 16 * RW * (jj < DEPTH ? jj : DEPTH)) : "memory");
+    else if constexpr (STAGED || jj == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL + (TR ? 20 : 16) * RW) : "memory");
     asm volatile("s_barrier" ::: "memory");               // everyone's has; everyone is done reading the slot refilled now
-    issue(jj + 2, (jj + 2) % 3);
+    issue(jj + DEPTH, (jj + DEPTH) % NSLOT);
     const int j = i0 - DRAD + jj;
     const bool row_ok = (unsigned)j < (unsigned)Hq;
     uint4_t b[KS];
@@ -630,7 +650,7 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
           float16_t acc;
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-          if (row_ok) {
+          if (row_ok && !(cdbg & 2)) {
 #pragma unroll
             for (int s = 0; s < KS; ++s)
               acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[rw][s]), __builtin_bit_cast(half8_t, b[s]), acc, 0, 0, 0);
@@ -638,7 +658,8 @@ __global__ __launch_bounds__(256 * NRS, 1) void correlation_mfma_rows64_kernel(c
           const int soff = (2 * (i0 + r) + q) * yrow_bytes + dyi * D * 2;
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
-            const half_t hv = (half_t)__builtin_fmaxf(acc[g] * k_pos, acc[g] * k_neg);
+            half_t hv = (half_t)__builtin_fmaxf(acc[g] * k_pos, acc[g] * k_neg);
+            if constexpr (DIRECT) hv = ((realmask >> g) & 1) ? hv : (half_t)0.f;
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rsrc_y, s_voff[g], soff, 0);
           }
         } else {
@@ -1158,12 +1179,20 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
       // FlowNetC's shape on maps up to 64 wide: 64-column ring slots (FT_CORR_STAGED=1: band transposed through LDS)
       static const bool stg = getenv("FT_CORR_STAGED") && atoi(getenv("FT_CORR_STAGED")) == 1;   // dev A/B: band through LDS
       static const bool w8 = !(getenv("FT_CORR_WAVES") && atoi(getenv("FT_CORR_WAVES")) == 4);     // dev A/B: four waves, R = 3
-      const int R = (stg || !w8) ? 3 : 4;
       static const bool tr = getenv("FT_CORR_TR") && atoi(getenv("FT_CORR_TR")) == 1;               // dev A/B: 1 = the transposed band (slower)
+      static const bool direct = !(getenv("FT_CORR_DIRECT") && atoi(getenv("FT_CORR_DIRECT")) == 0);   // dev A/B: 0 = the window-column tiles
+      static const int dwaves = getenv("FT_CORR_DIRECT_WAVES") ? atoi(getenv("FT_CORR_DIRECT_WAVES")) : 6;   // dev A/B: 8 = R 4 (192 workgroups at 16 x 48 rows)
+      static const int cdbg = getenv("FT_CORR_DBG") ? atoi(getenv("FT_CORR_DBG")) : 0;               // dev ablation (DIRECT form): 1 = no band stores, 2 = no MFMAs
+      const bool dir = direct && !stg && w8 && !tr;
+      const bool d6 = dir && dwaves == 6;
+      const int R = (stg || !w8 || d6) ? 3 : 4;
       auto k = stg ? correlation_mfma_rows64_kernel<16, 3, 10, true, 1>
-                   : (w8 ? (tr ? correlation_mfma_rows64_kernel<16, 4, 10, false, 2, true> : correlation_mfma_rows64_kernel<16, 4, 10, false, 2>)
+                   : (w8 ? (tr ? correlation_mfma_rows64_kernel<16, 4, 10, false, 2, true>
+                               : (d6 ? correlation_mfma_rows64_kernel<16, 3, 10, false, 2, false, true, 6>
+                                     : (direct ? correlation_mfma_rows64_kernel<16, 4, 10, false, 2, false, true>
+                                               : correlation_mfma_rows64_kernel<16, 4, 10, false, 2>)))
                          : correlation_mfma_rows64_kernel<16, 3, 10, false, 1>);
-      constexpr size_t ldst = 3 * 64 * 512 + 512 + 3 * 64 * (8 * 21 * 2) + 128;
+      const size_t ldst = dir ? 4 * 64 * 512 + 512 + 128 + 1024 : 3 * 64 * 512 + 512 + 3 * 64 * (8 * 21 * 2) + 128;
       static bool raised[64] = {};
       int dev = 0;
       FT_HIP_CHECK(hipGetDevice(&dev));
@@ -1172,9 +1201,9 @@ extern "C" int ft_correlation_nhwc_fwd(const void* f1, const void* f2, void* y, 
         if (dev >= 0 && dev < 64) raised[dev] = true;
       }
       const int ngy = 2 * ceil_div((H + 1) / 2, R);
-      hipLaunchKernelGGL(k, dim3(ngy * B), dim3((!stg && w8) ? 512 : 256), ldst, as_stream(stream), static_cast<const half_t*>(f1),
+      hipLaunchKernelGGL(k, dim3(ngy * B), dim3(d6 ? 384 : ((!stg && w8) ? 512 : 256)), ldst, as_stream(stream), static_cast<const half_t*>(f1),
                          static_cast<const half_t*>(f2), static_cast<half_t*>(y), H, W, (unsigned)f_bytes, (unsigned)y_bytes,
-                         f_cstride, y_cstride, y_coff, act, slope, ngy);
+                         f_cstride, y_cstride, y_coff, act | (dir ? cdbg << 8 : 0), slope, ngy);
       FT_LAUNCH_CHECK("correlation_mfma_rows64_kernel");
       return FT_OK;
     }

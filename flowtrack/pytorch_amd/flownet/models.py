@@ -26,7 +26,7 @@ import torch.nn as nn
 from .. import _lib
 from ..engine import HipModule
 from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, Program, act_stride, new_act, new_rowpacked_act,
-                       record_upsample4x)
+                       record_upsample4x, round_up)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
 LEAK = 0.1
@@ -271,12 +271,25 @@ def _concat_buffers(B: int, H: int, W: int, dtype, device, b2: int = None):
             z(b2 or B, H // 4, W // 4, 194))
 
 
-def record_flownets(prog: Program, p: FlowNetS, x: ActView, prefix: str, mk: dict) -> torch.Tensor:
-    """FlowNetS.forward (FlowNetS.py:60-94) on an NHWC input view; returns flow2 NCHW fp32."""
-    B, H, W, dtype, device = x.N, x.H, x.W, mk["dtype"], mk["device"]
+def record_flownets(prog: Program, p: FlowNetS, x: ActView, prefix: str, mk: dict, mean_fold=None) -> torch.Tensor:
+    """FlowNetS.forward (FlowNetS.py:60-94) on an NHWC input view; returns flow2 NCHW fp32.
+    mean_fold (from _FlowBase._record_pack_fold): `x` is the UN-centred, physically padded frame pair [B, H + 6, W + 6] and
+    conv1 runs as a pad-0 conv on it with the per-sample shift that removes the rgb mean."""
+    B, dtype, device = x.N, mk["dtype"], mk["device"]
+    if mean_fold is not None:
+        H, W = x.H - 6, x.W - 6
+    else:
+        H, W = x.H, x.W
     cc5, cc4, cc3, cc2 = _concat_buffers(B, H, W, dtype, device)
     c1 = new_act(B, H // 2, W // 2, 64, dtype, device)
-    _fc(p.conv1, prefix + "conv1", mk).record(prog, x, c1)
+    if mean_fold is not None:
+        c = p.conv1[0]
+        bn = p.conv1[1].as_dict() if isinstance(p.conv1[1], BatchNormParams) else None
+        layer = mk["owner"].fused(prefix + "conv1.meanfold", c.weight, stride=c.stride, pad=0, bias=c.bias, bn=bn, act="leaky",
+                                  slope=LEAK, **_mk(mk))
+        layer.record(prog, x, c1, shift_n=mean_fold(c.weight))
+    else:
+        _fc(p.conv1, prefix + "conv1", mk).record(prog, x, c1)
     _fc(p.conv2, prefix + "conv2", mk).record(prog, c1, ActView(cc2, 128, 0))
     c3 = new_act(B, H // 8, W // 8, 256, dtype, device)
     _fc(p.conv3, prefix + "conv3", mk).record(prog, ActView(cc2, 128, 0), c3)
@@ -415,6 +428,9 @@ def record_flownetfusion(prog: Program, p: FlowNetFusion, x: ActView, prefix: st
 #: the sample's workgroups wait for each other between their read and their write phase), and a launch whose workgroups wait for
 #: each other is not worth carrying for nothing.  FT_FUSE_MEAN_PACK=1 records it (tests/test_flow_gpu.py covers it either way).
 FUSE_MEAN_PACK = os.environ.get("FT_FUSE_MEAN_PACK", "0") == "1"
+#: FlowNet2S: the rgb mean folded into conv1 (one pass over the frames instead of mean + pack: _FlowBase._record_pack_fold).
+#: FT_MEAN_FOLD=0 keeps the two launches.
+MEAN_FOLD = os.environ.get("FT_MEAN_FOLD", "1") != "0"
 
 
 class _FlowPlan:
@@ -469,6 +485,41 @@ class _FlowBase(HipModule):
             outs[i] = view
         return outs
 
+    def _record_pack_fold(self, prog: Program, x_static: torch.Tensor, dtype, device, pad: int = 3):
+        """The rgb mean folded into conv1 (include/flowtrack_hip.h, ft_flow_pack_pair_sums / ft_flow_mean_fold): ONE pass over the
+        frames writes x / rgb_max into a row- and column-padded view [B, H + 2 pad, W + 2 pad, 8] and the colour sums; returns
+        (view, hook) where hook(conv1_weight) is FusedConv.record's `shift_n` callable: it records the launch that finishes the
+        mean, fills the view's padding with it and writes the per-sample shift, right in front of conv1.  None when the shape
+        is not covered (fp16, W % 4 == 0 only)."""
+        B, _, _, H, W = x_static.shape
+        if dtype != torch.float16 or W % 4:
+            return None
+        lib = _lib.load()
+        Hp, Wp = H + 2 * pad, W + 2 * pad
+        wpitch = round_up(Wp, 2)
+        view = ActView(torch.zeros((B, Hp, wpitch, 8), dtype=dtype, device=device), 6, 0, 0, Wp)
+        nchunk = int(lib.ft_flow_pack_pair_sums_chunks(H))
+        partial = torch.empty((B * 3 * nchunk,), dtype=torch.float32, device=device)
+        mean = torch.empty((B * 3,), dtype=torch.float32, device=device)
+        prog.add("ft_flow_pack_pair_sums", x_static.data_ptr(), ctypes.c_float(self.rgb_max), view.t.data_ptr(), B, H, W, pad,
+                 wpitch, _lib.dtype_code(dtype), partial.data_ptr(), keep=(x_static, view.t, partial))
+
+        def hook_for(weight: torch.Tensor):
+            # the kernel window summed per input channel, over the fp16 values the matrix pipe multiplies
+            wsum = torch.zeros((weight.shape[0], 8), dtype=torch.float32)
+            wsum[:, :weight.shape[1]] = weight.detach().to(torch.float32).cpu().to(dtype).to(torch.float64).sum(dim=(2, 3)).float()
+            wsum = wsum.to(device)
+            shift_n = torch.empty((B, weight.shape[0]), dtype=torch.float32, device=device)
+
+            def hook(scale, shift):
+                prog.add("ft_flow_mean_fold", partial.data_ptr(), ctypes.c_float(self.rgb_max), view.t.data_ptr(), B, H, W, pad, wpitch,
+                         _lib.dtype_code(dtype), wsum.data_ptr(), scale.data_ptr() if scale is not None else None,
+                         shift.data_ptr() if shift is not None else None, weight.shape[0], shift_n.data_ptr(), mean.data_ptr(),
+                         keep=(partial, view.t, wsum, scale, shift, shift_n, mean))
+                return shift_n
+            return hook
+        return view, hook_for
+
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:  # pragma: no cover - abstract
         raise NotImplementedError
 
@@ -517,11 +568,32 @@ class FlowNet2S(FlowNetS, _FlowBase):
         prog = Program(self._side_stream(device))
         mk = dict(dtype=dtype, device=device, owner=self)
         x_static = torch.empty((B, 3, 2, H, W), dtype=torch.float32, device=device)
-        (x6,) = self._record_normalise(prog, x_static, (0,), dtype, device)
-        flow2 = record_flownets(prog, self, x6, "", mk)
+        fold = None
+        if MEAN_FOLD and self._fold_supported(B, H, W, dtype):
+            fold = self._record_pack_fold(prog, x_static, dtype, device)
+        if fold is not None:
+            flow2 = record_flownets(prog, self, fold[0], "", mk, mean_fold=fold[1])
+        else:
+            (x6,) = self._record_normalise(prog, x_static, (0,), dtype, device)
+            flow2 = record_flownets(prog, self, x6, "", mk)
         out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
         record_upsample4x(prog, flow2, out, self.div_flow)  # upsample1(flow2 * div_flow), models.py:292
         return _FlowPlan(prog, x_static, out)
+
+    def _fold_supported(self, B: int, H: int, W: int, dtype, pad: int = 3) -> bool:
+        """Whether conv1 on the padded view runs on the one kernel that takes a per-sample shift (fp16, large enough grids)."""
+        if dtype != torch.float16 or W % 4:
+            return False
+        d = _lib.ConvDesc()
+        d.dtype = _lib.dtype_code(dtype)
+        d.N, d.Hi, d.Wi, d.Cin, d.x_cstride = B, H + 2 * pad, W + 2 * pad, 6, 8
+        d.x_wpitch = round_up(W + 2 * pad, 2)
+        d.Cout, d.kh, d.kw, d.stride, d.pad = 64, 7, 7, 2, 0
+        d.Ho, d.Wo = H // 2, W // 2
+        d.y_cstride, d.out_layout = act_stride(64), _lib.FT_LAYOUT_NHWC
+        d.act, d.slope = _lib.FT_ACT_LEAKY, LEAK
+        d.shift_nstride = 64
+        return _lib.load().ft_conv_shift_nstride_supported(ctypes.byref(d)) == 0
 
 
 class FlowNet2C(FlowNetC, _FlowBase):

@@ -758,9 +758,13 @@ class FusedConv:
             return 2 * H, 2 * W
         return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
 
-    def record(self, prog: Program, x: ActView, y, residual: Optional[ActView] = None, pool: bool = False) -> None:
+    def record(self, prog: Program, x: ActView, y, residual: Optional[ActView] = None, pool: bool = False,
+               shift_n=None) -> None:
         """Append this layer to `prog`. y is an ActView (NHWC) or a contiguous NCHW fp32 tensor.
-        pool=True (the ResNet stem): the 3x3/s2/p1 max-pool runs inside the launch, y is the pooled map."""
+        pool=True (the ResNet stem): the 3x3/s2/p1 max-pool runs inside the launch, y is the pooled map.
+        shift_n: callable(scale, shift) -> fp32 [N, Cout] tensor of PER-SAMPLE shifts (ft_conv_desc.shift_nstride); it is
+        called with the layer's folded tables right before the conv launch is appended, so it can record the launch that
+        fills the tensor (FlowNet2S's rgb mean folded into conv1: ft_flow_mean_fold)."""
         if x.C != self.cin:
             raise FlowtrackHipError(f"{self.label}: input has {x.C} channels, layer expects {self.cin}")
         if x.t.dtype != self.dtype or not x.t.is_contiguous():
@@ -804,6 +808,13 @@ class FusedConv:
             d.tail_cout = self.tail_cout
             res_ptr = self._tail.data_ptr()
         w, _, scale, shift = self._packed_for(d)
+        if shift_n is not None:
+            d.shift_nstride = self.cout
+            if self.lib.ft_conv_shift_nstride_supported(ctypes.byref(d)) != 0:
+                raise FlowtrackHipError(f"{self.label}: per-sample shift is not supported for this layer / shape")
+            shift = shift_n(scale, shift)
+            if tuple(shift.shape) != (x.N, self.cout) or shift.dtype != torch.float32 or not shift.is_contiguous():
+                raise FlowtrackHipError(f"{self.label}: per-sample shift must be contiguous fp32 {(x.N, self.cout)}")
         flops = float(self.lib.ft_conv_flops(ctypes.byref(d)))
         ws = _direct_stream(self, d, w, x.t.device) if (self.k in (1, 3, 5) and isinstance(y, ActView) and not self.tail_cout and not pool) else None
         if ws is not None:

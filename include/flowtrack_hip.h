@@ -153,6 +153,10 @@ typedef struct ft_conv_desc {
    * Supported for the row-packed 7x7 / stride 2 fp16 stem with relu, 64 outputs and x_lpad >= pad + 2 (the pooled patch
    * starts one stem column further left); FT_ERR_UNSUPPORTED otherwise.  Bit-identical to conv + ft_maxpool3x3s2_fwd. */
   int pool;
+  /* 0: `shift` is one vector [Cout] shared by the batch.  > 0: `shift` is [N][shift_nstride] floats, sample n takes
+   * shift + n * shift_nstride — the fold of FlowNet2*'s per-sample rgb mean into conv1 (ft_flow_mean_fold below).
+   * Supported by the persistent row-packed 7x7 / stride 2 fp16 stem only; FT_ERR_UNSUPPORTED elsewhere. */
+  int shift_nstride;
 } ft_conv_desc;
 
 /* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,
@@ -351,6 +355,28 @@ int ft_flow_pack_pair(const float* inputs, const float* mean, float rgb_max,
  * private to this (B, H, W) from then on; its last word becomes non-zero if a workgroup ever timed out waiting for its sample's
  * sums (means are NaN then).  mean fp32 [B*3] is written as well.  Same arithmetic per element as ft_flow_pack_pair; the mean's
  * summation order differs from ft_flow_rgb_mean's (last-bit differences). */
+/* The mean folded into conv1 (FlowNet2S; lib/flownet/model/models.py:255-257 + FlowNetS.py:20 as ONE pass over the frames):
+ * conv_zero-padded((x - mean) / rgb_max) = conv_mean-padded(x / rgb_max) - (mean / rgb_max) . sum of the kernel, so
+ *  (1) ft_flow_pack_pair_sums writes the UN-centred pair y = fp16 [B, H + 2 pad, wpitch, 8] (pixel (yy, xx) at row pad + yy,
+ *      column pad + xx, channels (r0,g0,b0,r1,g1,b1,0,0) = x / rgb_max; padding pixels untouched) and per-chunk colour sums
+ *      partial fp32 [B*3][ft_flow_pack_pair_sums_chunks(H)] in the same pass (no dependency on the mean: the mean launch and
+ *      its second read of the frames disappear);
+ *  (2) ft_flow_mean_fold finishes the mean (fixed summation order), fills y's padding pixels with m16 = fp16(mean / rgb_max)
+ *      per colour (the reference's zero padding of the centred input) and writes the per-sample shift
+ *      shift_n[b][co] = shift[co] - scale[co] * sum_c m16[c % 3] * wsum[co][c]   (scale NULL = 1)
+ *      with wsum fp32 [Cout][8] = the fp16-rounded conv1 weights summed over the kernel window per input channel;
+ *  (3) conv1 runs as a pad-0 conv on the (H + 2 pad) x (W + 2 pad) row-packed view with ft_conv_desc.shift_nstride = Cout.
+ * Differences from the two-launch path: the input is rounded to fp16 before the mean is removed (|x / rgb_max| <= 1 instead
+ * of <= 0.5: one more bit of input rounding), and mean / rgb_max enters as its fp16 value.  W % 4 == 0, FT_F16 only. */
+#define FT_PACK_SUMS_ROWS 4
+int ft_conv_shift_nstride_supported(const ft_conv_desc* d);   /* FT_OK when ft_conv2d_fwd takes `d` with its shift_nstride */
+long long ft_flow_pack_pair_sums_chunks(int H);
+int ft_flow_pack_pair_sums(const float* inputs, float rgb_max, void* y, int B, int H, int W, int pad, int wpitch, int dtype,
+                           float* partial, ft_stream_t stream);
+int ft_flow_mean_fold(const float* partial, float rgb_max, void* y, int B, int H, int W, int pad, int wpitch, int dtype,
+                      const float* wsum, const float* scale, const float* shift, int Cout, float* shift_n, float* mean,
+                      ft_stream_t stream);
+
 long long ft_flow_mean_pack_pair_state_words(int B, int H, int W);
 int ft_flow_mean_pack_pair(const float* inputs, float rgb_max, void* y, int lpad, int wpitch, void* y3, int lpad3, int wpitch3,
                            int B, int H, int W, int dtype, unsigned long long* state, float* mean, ft_stream_t stream);

@@ -219,6 +219,93 @@ def test_fused_mean_pack_pair_matches_the_two_launches(hip_lib):
     assert int(hip_lib.ft_flow_mean_pack_pair_state_words(1, 2048, 2048)) == 0      # more than 42 workgroups per sample
 
 
+def test_mean_fold_pack_sums_and_fold_tables(hip_lib):
+    """ft_flow_pack_pair_sums + ft_flow_mean_fold (the rgb mean of models.py:255-257 folded into conv1): the padded view holds
+    fp16(x / rgb_max) inside and fp16(mean / rgb_max) in every padding pixel, the mean matches the fp64 one, the per-sample
+    shift is shift - scale * sum_c m16[c] * wsum[co][c]; ragged last row chunk, pitch wider than W + 2 pad."""
+    for (B, H, W, pad, extra) in ((3, 50, 72, 3, 0), (2, 64, 64, 3, 2), (16, 384, 512, 3, 0)):
+        pair = (synth.frame_pairs(77, B, H, W)).cuda()
+        wpitch = W + 2 * pad + extra
+        y = torch.full((B, H + 2 * pad, wpitch, 8), 9.0, dtype=torch.float16, device="cuda")
+        nchunk = int(hip_lib.ft_flow_pack_pair_sums_chunks(H))
+        assert nchunk == (H + 3) // 4
+        partial = torch.empty(B * 3 * nchunk, device="cuda")
+        check(hip_lib.ft_flow_pack_pair_sums(pair.data_ptr(), ctypes.c_float(255.0), y.data_ptr(), B, H, W, pad, wpitch, _lib.FT_F16,
+                                             partial.data_ptr(), _stream()))
+        g = torch.Generator().manual_seed(5)
+        wsum = torch.randn((64, 8), generator=g)
+        scale = torch.rand(64, generator=g) + 0.5
+        shift = torch.randn(64, generator=g)
+        wsum_g, scale_g, shift_g = wsum.cuda(), scale.cuda(), shift.cuda()
+        for use_scale in (True, False):
+            shn = torch.empty((B, 64), device="cuda")
+            mean = torch.empty(B * 3, device="cuda")
+            check(hip_lib.ft_flow_mean_fold(partial.data_ptr(), ctypes.c_float(255.0), y.data_ptr(), B, H, W, pad, wpitch, _lib.FT_F16,
+                                            wsum_g.data_ptr(), scale_g.data_ptr() if use_scale else None,
+                                            shift_g.data_ptr(), 64, shn.data_ptr(), mean.data_ptr(), _stream()))
+            torch.cuda.synchronize()
+            ref = pair.view(B, 3, -1).double().mean(-1)
+            assert (mean.view(B, 3).double() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+            m16 = (mean.view(B, 3) / 255.0).half()
+            got = y.cpu()
+            inner = got[:, pad:pad + H, pad:pad + W]
+            want = torch.cat((pair[:, :, 0], pair[:, :, 1]), 1).permute(0, 2, 3, 1).cpu()
+            assert torch.equal(inner[..., :6], (want / 255.0).half()) and torch.all(inner[..., 6:] == 0)
+            mask = torch.ones((H + 2 * pad, wpitch), dtype=torch.bool)
+            mask[pad:pad + H, pad:pad + W] = False
+            padpx = got[:, mask]                                      # [B, npad, 8]
+            want_pad = torch.cat((m16, m16, torch.zeros((B, 2), dtype=torch.float16, device="cuda")), 1).cpu()
+            assert torch.equal(padpx, want_pad[:, None, :].expand_as(padpx))
+            mf = m16.float().cpu().double()
+            corr = mf @ wsum[:, 0:3].double().t() + mf @ wsum[:, 3:6].double().t()            # [B, 64]
+            want_shn = shift.double()[None] - (scale.double()[None] if use_scale else 1.0) * corr
+            assert (shn.cpu().double() - want_shn).abs().max().item() <= 1e-5
+    # refused: W % 4 != 0, fp32
+    y = torch.empty((1, 14, 16, 8), dtype=torch.float16, device="cuda")
+    pair = synth.frame_pairs(1, 1, 8, 10).cuda()
+    partial = torch.empty(6, device="cuda")
+    assert hip_lib.ft_flow_pack_pair_sums(pair.data_ptr(), ctypes.c_float(255.0), y.data_ptr(), 1, 8, 10, 3, 16, _lib.FT_F16,
+                                          partial.data_ptr(), _stream()) == _lib.FT_ERR_UNSUPPORTED
+    assert hip_lib.ft_flow_pack_pair_sums(pair.data_ptr(), ctypes.c_float(255.0), y.data_ptr(), 1, 8, 8, 3, 16, _lib.FT_F32,
+                                          partial.data_ptr(), _stream()) == _lib.FT_ERR_UNSUPPORTED
+
+
+def test_mean_fold_flownet2s_matches_the_two_launch_path(hip_lib, monkeypatch):
+    """FlowNet2S fp16 with the rgb mean folded into conv1 (default where conv1 runs on the persistent stem) against the same
+    network on ft_flow_rgb_mean + ft_flow_pack_pair, both against the fp32 HIP path: the fold's plan really carries the fold
+    launches and no mean launch, the two fp16 flows agree to fp16 noise, neither is further from fp32 than the other by more
+    than that noise; also with BatchNorm (scale != 1 in the per-sample shift) and with a constant image (x - mean = 0: the
+    fold's cancellation case)."""
+    B, H, W = 4, 256, 256
+    for bn in (False, True):
+        pair = synth.frame_pairs(SEED + 9, B, H, W).cuda()
+        m32, _ = _build(models.FlowNet2S, SEED + 4, torch.float32, batchNorm=bn)
+        want = m32(pair).cpu()
+        monkeypatch.setattr(models, "MEAN_FOLD", True)
+        mf, _ = _build(models.FlowNet2S, SEED + 4, torch.float16, batchNorm=bn)
+        got_fold = mf(pair).cpu()
+        names = [c[0] for c in mf.plan_for(B, H, W).prog.calls]
+        assert "ft_flow_mean_fold" in names and "ft_flow_pack_pair_sums" in names and "ft_flow_rgb_mean" not in names
+        monkeypatch.setattr(models, "MEAN_FOLD", False)
+        m2, _ = _build(models.FlowNet2S, SEED + 4, torch.float16, batchNorm=bn)
+        got_two = m2(pair).cpu()
+        names = [c[0] for c in m2.plan_for(B, H, W).prog.calls]
+        assert "ft_flow_mean_fold" not in names and "ft_flow_rgb_mean" in names
+        mag = torch.norm(want, dim=1).mean().item()
+        e_fold, e_two, e_between = flow_ref.epe(got_fold, want), flow_ref.epe(got_two, want), flow_ref.epe(got_fold, got_two)
+        print("bn", bn, "EPE fold", e_fold, "two-launch", e_two, "between", e_between, "mean |flow|", mag)
+        bar = 0.02 * max(mag, 1.0) + 0.05
+        assert e_fold <= bar and e_two <= bar and e_between <= bar
+        assert e_fold <= 1.5 * e_two + 0.01
+        # graph replays are bit-identical
+        assert torch.equal(mf(pair).cpu(), got_fold)
+        # constant frames: the centred input is exactly zero in the reference
+        monkeypatch.setattr(models, "MEAN_FOLD", True)
+        flat = torch.full((B, 3, 2, H, W), 200.0, device="cuda")
+        f_fold, f_32 = mf(flat).cpu(), m32(flat).cpu()
+        assert flow_ref.epe(f_fold, f_32) <= bar
+
+
 def test_upsample_and_normalise(hip_lib, oracle_lib):
     x = synth.normal(6, "flow2", (2, 2, 6, 9)).numpy()
     y = torch.empty((2, 2, 24, 36), dtype=torch.float32, device="cuda")
