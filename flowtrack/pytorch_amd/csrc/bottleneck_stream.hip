@@ -1354,12 +1354,15 @@ static int bns_launch(const BnsParams& p, hipStream_t s) {
   return FT_OK;
 }
 
+#ifndef FT_BNS_SLOTS
+#define FT_BNS_SLOTS 4        // weight-step register slots of the full-width strips: 3 -> 4 = +0.9-1.2 % on the R50 batch-64 step (56.25 / 56.34 -> 56.74 / 57.01 k crops/s same box), 6: -4.5 %; the column-split form: no difference at 3 / 4 / 6 (tools/dev/ab/ns_ab.sh)
+#endif
 #ifndef FT_BNS_XH_SLOTS
 #define FT_BNS_XH_SLOTS 3
 #endif
 template <int MT1, int MT2, bool XH, int HEADC = 0>
 static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
-  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : 3, HEADC>;
+  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : FT_BNS_SLOTS, HEADC>;
   constexpr int lds = 81920 + 2 * MT2 * 32 * 512;
   static bool attr_done[64] = {};          // the LDS opt-in is per device
   int dev = 0;

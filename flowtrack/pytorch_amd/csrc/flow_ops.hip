@@ -459,7 +459,15 @@ typedef uint32_t corr_u2_t __attribute__((ext_vector_type(2)));
 // (i2 < 0 or >= 32: structural zeros the window form produced from its zero columns) are written by the lanes of the
 // columns i2 mod 32, which are out of band for that row: every lane slot with (c - i + DRAD) mod 32 < D stores, a real product
 // where the difference did not wrap, zero where it did.  NWV waves = NWV / 2 output rows x 2 column parities, one row per wave
-// (six waves / R = 3 give 256 workgroups at 16 x 48 rows, eight / R = 4 give 192).
+// (six waves / R = 3 give 256 workgroups at 16 x 48 rows, eight / R = 4 give 192).  62.4 -> 50.2-51.2 us at [16,256,48,64] (same box).
+// Ablations of this form (FT_CORR_DBG, same box): full 54.2 us; no band store instructions 37.5 (stores kept but all out of range:
+// 40.8 of 50.2); also no MFMAs 27.2; also no fragment reads 26.9; also no ring loads 20.4; also no barriers 17.7 (launch + the f1
+// fragments + 23 empty steps).  Three rewrites of the band's way out, each correct, none faster: (a) pairs of lanes packed into
+// aligned 4-byte stores (ds_bpermute for the neighbour, the odd element carried to the next dy): 70.0 us; (b) the band through
+// wave-private LDS tiles [32 px][8 dy x 21 dx] and out as 16-byte pieces (30 store instructions per wave instead of 336): 51.2-
+// 51.7 us — so it is neither the address unit's instruction rate nor the 2-byte granularity; (c) the epilogue of step jj - 1
+// woven between the MFMAs of step jj (one store per MFMA in the ISA): 56.8-57.9 vs 54.8-55.3 us.  What a step costs is spread
+// over products, epilogue ALU work, stores and the ring, none of them alone; (a)-(c) were removed again.
 template <int KS, int R, int DRAD, bool STAGED, int NRS, bool TR = false, bool DIRECT = false, int NWV = 4 * NRS>
 __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(const half_t* __restrict__ f1, const half_t* __restrict__ f2,
                                                                           half_t* __restrict__ y, int H, int W, unsigned f2_bytes,
@@ -503,6 +511,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(co
   const int Hq = (H - q + 1) >> 1;          // rows of this parity class
   const float inv_c = 1.0f / (float)C;
   constexpr unsigned kOOB = 0x80000000u;
+  // developer ablation (FT_CORR_DBG, DIRECT form, timing only): 1 = every band store out of range, 2 = no MFMAs, 4 = no fragment
+  // reads, 8 = no ring loads, 16 = no barriers, 32 = no band store instructions at all; 0 in production
+  const int cdbg = DIRECT ? act >> 8 : 0;
+  if constexpr (DIRECT) act &= 0xff;
 
   // f1 fragments of the R rows (operand A: row = f1 pixel of this column parity, k = channel)
   uint4_t a[RW][KS];
@@ -541,6 +553,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(co
     const int j = i0 - DRAD + jj;
     const bool row_ok = jj < NJ && (unsigned)j < (unsigned)Hq;
     const int soff = row_ok ? (2 * j + q) * row_bytes : 0;
+    if (cdbg & 8) return;
 #pragma unroll
     for (int t = 0; t < NL; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(t * NWV + wave < SLOT / 1024 ? smem + slot * SLOT + (t * NWV + wave) * 1024
@@ -560,8 +573,6 @@ __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(co
     if (dd == dr) realmask |= 1 << g;
   }
   // act(v) = max(v, s*v) for s in [0, 1] (relu: 0, leaky: slope, none: 1); the 1/C of the correlation rides along
-  const int cdbg = DIRECT ? act >> 8 : 0;      // developer ablation (FT_CORR_DBG): 1 = every band store out of range, 2 = no MFMAs; 0 in production
-  if constexpr (DIRECT) act &= 0xff;
   const float k_pos = inv_c, k_neg = inv_c * (act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f));
   const int yrow_bytes = W * y_cstride * 2;
   unsigned s_voff[(STAGED || TR) ? 1 : 16];      // !STAGED: the band leaves as 2-byte stores in the accumulator layout
@@ -592,12 +603,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(co
     if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((DEPTH - 1) * NL + 16 * RW * (jj < DEPTH ? jj : DEPTH)) : "memory");
     else if constexpr (STAGED || jj == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL + (TR ? 20 : 16) * RW) : "memory");
-    asm volatile("s_barrier" ::: "memory");               // everyone's has; everyone is done reading the slot refilled now
+    if (!(cdbg & 16)) asm volatile("s_barrier" ::: "memory");   // everyone's has; everyone is done reading the slot refilled now
     issue(jj + DEPTH, (jj + DEPTH) % NSLOT);
     const int j = i0 - DRAD + jj;
     const bool row_ok = (unsigned)j < (unsigned)Hq;
     uint4_t b[KS];
-    if (row_ok) {
+    if (cdbg & 4) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) b[s] = uint4_t{(unsigned)jj, 0u, 0u, 0u};
+    } else if (row_ok) {
       const char* st = smem + (in_img ? slot * SLOT : 0) + b_base;
 #pragma unroll
       for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const uint4_t*>(st + (((2 * s + h) ^ b_key) << 4));
@@ -656,13 +670,20 @@ __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(co
               acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[rw][s]), __builtin_bit_cast(half8_t, b[s]), acc, 0, 0, 0);
           }
           const int soff = (2 * (i0 + r) + q) * yrow_bytes + dyi * D * 2;
+          if (cdbg & 32) {
+            float keep = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) keep += acc[g];
+            if (keep == 12345.678f) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)1, rsrc_y, s_voff[0], soff, 0);
+          } else {
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
             half_t hv = (half_t)__builtin_fmaxf(acc[g] * k_pos, acc[g] * k_neg);
             if constexpr (DIRECT) hv = ((realmask >> g) & 1) ? hv : (half_t)0.f;
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rsrc_y, s_voff[g], soff, 0);
           }
-        } else {
+          }
+        } else if (!(cdbg & 32)) {
 #pragma unroll
           for (int g = 0; g < 16; ++g) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, rsrc_y, kOOB, 0, 0);
         }

@@ -369,3 +369,46 @@ def test_flownet_demo_pads_by_edge_replication():
     assert ims.min().item() >= 60.0, "zero padding leaked in"
     same = demo.pack_pair(np.zeros((64, 128, 3), np.uint8), np.ones((64, 128, 3), np.uint8))
     assert tuple(same.shape) == (1, 3, 2, 64, 128)
+
+
+def test_mean_fold_algebra_and_support_query(hip_lib):
+    """The identity behind ft_flow_pack_pair_sums / ft_flow_mean_fold (FlowNet2S's rgb mean folded into conv1,
+    lib/flownet/model/models.py:117-121 + FlowNetS.py:20): conv_zero-pad((x - m) / r) == conv_m-pad(x / r) - (m / r) . sum of the
+    kernel, here in torch on the CPU with the fp16 roundings the device path makes; and which descriptors
+    ft_conv_shift_nstride_supported accepts (no compute call)."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W, r = 2, 20, 24, 255.0
+    x = torch.rand((B, 3, 2, H, W), generator=g) * r
+    w = (torch.randn((8, 6, 7, 7), generator=g) * 0.05).half().float()
+    bias = torch.randn(8, generator=g)
+    mean = x.view(B, 3, -1).mean(-1)
+    ref_in = ((x - mean.view(B, 3, 1, 1, 1)) / r)
+    ref_in = torch.cat((ref_in[:, :, 0], ref_in[:, :, 1]), 1)                       # [B, 6, H, W]
+    want = torch.nn.functional.conv2d(ref_in, w, bias, stride=2, padding=3)
+    m16 = (mean / r).half().float()                                                  # what the padding pixels and the shift carry
+    xin = torch.cat((x[:, :, 0], x[:, :, 1]), 1) / r
+    xin = xin.half().float()
+    padded = m16.repeat(1, 2).view(B, 6, 1, 1).expand(B, 6, H + 6, W + 6).clone()
+    padded[:, :, 3:3 + H, 3:3 + W] = xin
+    wsum = w.sum(dim=(2, 3))                                                         # [Cout, 6]
+    shift_n = bias[None] - m16.repeat(1, 2) @ wsum.t()                               # [B, Cout]
+    got = torch.nn.functional.conv2d(padded, w, None, stride=2, padding=0) + shift_n[:, :, None, None]
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 2e-3                                   # input rounding to fp16, nothing structural
+
+    def fold_desc(N, H, W, **kw):
+        d = _desc(N=N, Hi=H + 6, Wi=W + 6, Cin=6, x_cstride=8, Cout=64, kh=7, kw=7, stride=2, pad=0, Ho=H // 2, Wo=W // 2,
+                  y_cstride=64, act=_lib.FT_ACT_LEAKY)
+        d.x_wpitch = W + 6
+        d.slope = 0.1
+        d.shift_nstride = 64
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(16, 384, 512))) == 0
+    assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(4, 256, 256))) == 0
+    assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(1, 64, 64))) == _lib.FT_ERR_UNSUPPORTED      # too few tiles for the persistent stem
+    assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(16, 384, 512, dtype=_lib.FT_F32))) == _lib.FT_ERR_UNSUPPORTED
+    assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(16, 384, 512, shift_nstride=62))) == _lib.FT_ERR_UNSUPPORTED
+    assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(16, 384, 512, pool=1))) == _lib.FT_ERR_UNSUPPORTED
+    assert int(hip_lib.ft_flow_pack_pair_sums_chunks(384)) == 96 and int(hip_lib.ft_flow_pack_pair_sums_chunks(50)) == 13
