@@ -66,6 +66,9 @@ __host__ __device__ constexpr int cd_sigma(int r) { return 16 * ((r >> 2) & 1) +
 template <int CPR>
 __device__ __forceinline__ int cd_key(int row) { return CPR < 16 ? ((row >> FT_CD_KEY_SHIFT) & (CPR - 1)) : (row & 15); }
 
+#ifndef FT_CD_WSLOTS
+#define FT_CD_WSLOTS 3
+#endif
 template <int KSPLIT>
 struct CdGeom {
   static constexpr int MT = 3, BP = 96;                       // pixel tiles per wave, pixels per workgroup
@@ -182,7 +185,10 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   };
   // weights of chunk c for this wave: 8 contiguous KiB at ((cb * nchunk + c) * 4 + wave) * 8 KiB; past the stream: zeros
   const unsigned lane16 = (unsigned)lane * 16u;
-  uint4_t areg[3][4][2];
+  // weight-step register slots: the K walk's look-ahead is WS - 1 chunks of 8 KiB per wave.  Three slots keep 64 KB per CU in
+  // flight; the unrolled walks (every wait a compile-time count) can take FT_CD_WSLOTS (A/B builds: -DFT_CD_WSLOTS=4)
+  constexpr int WS = NCH > 0 ? FT_CD_WSLOTS : 3;
+  uint4_t areg[WS][4][2];
   auto load_a = [&](auto slotc, int c) {
     constexpr int SL = decltype(slotc)::value;
     const int base = c < nchunk ? ((cb * nchunk + c) * 4 + wave) * 8192 : 0x7fff0000;
@@ -235,8 +241,7 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   issue_x(0, 0);
   issue_x(1, 1);
   issue_x(2, 2);
-  load_a(c0{}, 0);
-  load_a(c1{}, 1);
+  cd_unroll<WS - 1>([&](auto sc) { load_a(sc, decltype(sc)::value); });
 
   float16_t acc[2][MT];
 #pragma unroll
@@ -276,10 +281,10 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, kOOB, 0, 0, 0);
   };
   // one chunk (ring slot = register slot = c % 3): slice 0 of the pixel operand already sits in register set 0
-  auto chunk = [&](auto slotc, int c) {
-    constexpr int SL = decltype(slotc)::value;
-    using slot = std::integral_constant<int, SL>;
-    load_a(std::integral_constant<int, (SL + 2) % 3>{}, c + 2);
+  auto chunk = [&](auto slotc, auto wslotc, int c) {
+    constexpr int SL = decltype(slotc)::value, WL = decltype(wslotc)::value;
+    using slot = std::integral_constant<int, WL>;          // register slot of this chunk's weights; SL = its ring slot
+    load_a(std::integral_constant<int, (WL + WS - 1) % WS>{}, c + WS - 1);
     ldx(c1{}, SL, 1);
     mma(c0{}, slot{}, std::integral_constant<int, 0>{});
     ldx(c0{}, SL, 2);
@@ -288,8 +293,9 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
     mma(c0{}, slot{}, std::integral_constant<int, 2>{});
     if (c + 1 < nchunk) {
       // x chunk c+1 has landed and every read of chunk c's slot is complete: refill it with chunk c+3.  Younger than x chunk
-      // c+1 are the weights of chunk c+1 (needed next anyway), x chunk c+2 and the weights of chunk c+2.
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + 8) : "memory");
+      // c+1 are the weights of chunk c+1 (needed next anyway), x chunk c+2 and the weights of chunk c+2 (WS = 3; with more slots
+      // the weights of chunk c+1 are OLDER than x chunk c+1 and those of chunks c+2 .. c+WS-1 younger).
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + 8 * (WS - 2)) : "memory");
       CD_BARRIER();
       if (c + 3 < nchunk) issue_x(c + 3, SL);
       else issue_x_dummy(SL);
@@ -299,20 +305,20 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   };
 
   // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight chunks may fly
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 16) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 8 * (WS - 1)) : "memory");
   CD_BARRIER();
   CD_TS(1);
   ldx(c0{}, 0, 0);
   if constexpr (NCH > 0) {
     cd_unroll<NCH>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      chunk(std::integral_constant<int, c % 3>{}, c);
+      chunk(std::integral_constant<int, c % 3>{}, std::integral_constant<int, c % WS>{}, c);
     });
   } else {
     for (int c = 0; c < nchunk; c += 3) {
-      chunk(c0{}, c);
-      if (c + 1 < nchunk) chunk(c1{}, c + 1);
-      if (c + 2 < nchunk) chunk(c2{}, c + 2);
+      chunk(c0{}, c0{}, c);
+      if (c + 1 < nchunk) chunk(c1{}, c1{}, c + 1);
+      if (c + 2 < nchunk) chunk(c2{}, c2{}, c + 2);
     }
   }
   CD_TS(2);
