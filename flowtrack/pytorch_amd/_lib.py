@@ -37,7 +37,7 @@ class ConvDesc(ctypes.Structure):
         ("res_cstride", c_int), ("res_coff", c_int), ("act", c_int), ("slope", c_float),
         ("x_lpad", c_int), ("x_wpitch", c_int), ("tile_hint", c_int),
         ("x2_cin", c_int), ("x2_hi", c_int), ("x2_wi", c_int), ("x2_cstride", c_int), ("x2_coff", c_int), ("x2_stride", c_int),
-        ("tail_cout", c_int), ("pool", c_int), ("shift_nstride", c_int),
+        ("tail_cout", c_int), ("pool", c_int), ("shift_nstride", c_int), ("x_nchw_f32", c_int),
     ]
 
 

@@ -63,6 +63,8 @@ struct ConvParams {
   unsigned w_bytes;   // conv_igemm8_kernel: size of the packed weight set (all phases and channel tiles)
   int dbg;            // developer ablation (FT_CONV_DBG): 1 = no MFMA, 2 = no operand loads, 4 = no epilogue; 0 in production
   int shift_n;        // > 0: `shift` is per sample, [N][shift_n] floats (conv_stem_persist_kernel only)
+  int x_planar;       // 1: x is the NCHW fp32 network input (conv_stem_pool_kernel only); x_lpad / x_w / x_c: the virtual view's left pad, the planes' width, their count
+  int x_lpad, x_w, x_c;
 };
 
 template <typename T> struct Elem;

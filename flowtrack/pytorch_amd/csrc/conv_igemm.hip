@@ -1607,6 +1607,38 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
   constexpr unsigned kOOB = 0x80000000u;
 
   const int nchunks = PH * CPR;
+  if (p.x_planar) {
+    // ft_conv_desc.x_nchw_f32: the patch straight from the network's NCHW fp32 input.  Chunk gci = two pixels (8 bytes each: up to
+    // 4 channels as fp16) of patch row gci / CPR, at the LDS byte the packed view's chunk would have been DMA'd to; a lane reads
+    // its pixels' planes (lanes = consecutive pixel pairs: 160 contiguous bytes per plane and patch row), casts as
+    // pack_nchw_rows4_kernel does and writes 16 bytes.  Loads of all rounds first, then the casts and LDS writes.
+    constexpr int NR = 5;                      // rounds of 256 chunks: 39 rows x <= 32 chunks (the pose stem: 39 x 20 = 780)
+    const float* xf = reinterpret_cast<const float*>(p.x);
+    const size_t HW = (size_t)p.Hi * p.x_w;
+    float v[NR][2][3];
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const int gci = (t * NW + wave) * 64 + lane;
+      const int row = gci / CPR, ch = gci - row * CPR;
+      const int iy = iy_org + row, ix0 = col0 + 2 * ch - p.x_lpad;
+      const bool row_in = t < p.h_npww && gci < nchunks && (unsigned)iy < (unsigned)p.Hi;
+      const float* base = xf + (size_t)n * p.x_c * HW + (size_t)(row_in ? iy : 0) * p.x_w;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool in = row_in && (unsigned)(ix0 + e) < (unsigned)p.x_w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[t][e][c] = (in && c < p.x_c) ? base[(size_t)c * HW + ix0 + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      if (t < p.h_npww) {
+        const half8_t h8 = {(half_t)v[t][0][0], (half_t)v[t][0][1], (half_t)v[t][0][2], (half_t)0.f,
+                            (half_t)v[t][1][0], (half_t)v[t][1][1], (half_t)v[t][1][2], (half_t)0.f};
+        *reinterpret_cast<half8_t*>(patch + ((t * NW + wave) * 64 + lane) * 16) = h8;
+      }
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < NPLW_MAX; ++t) {
     if (t < p.h_npww) {
@@ -1618,6 +1650,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
         v = (unsigned)(((n * p.Hi + iy) * p.Wi + col0) * cpb + ch * 16);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr)(patch + (t * NW + wave) * 1024), 16, v, 0, 0, 0);
     }
+  }
   }
   unsigned a_voff[NIA];
   {
@@ -2429,7 +2462,7 @@ static int launch_stem_pool(ConvParams p, const ft_conv_desc* d, const Geometry&
   const int rb = 16 * d->stride * cpb + runb;            // bytes of one patch row (17 stem columns)
   p.h_pw = ceil_div(rb, 16);
   p.h_npww = ceil_div(ceil_div(39 * p.h_pw, 64), 4);
-  if (p.h_npww > 12) return FT_ERR_UNSUPPORTED;
+  if (p.h_npww > 12 || (p.x_planar && (p.h_npww > 5 || cpb != 8))) return FT_ERR_UNSUPPORTED;
   p.h_pb = p.h_npww * 4 * 1024;
   p.h_ty = ceil_div(Hp, 8);
   p.h_tx = ceil_div(Wp, 8);
@@ -2794,6 +2827,11 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   static const int dbg = env_int("FT_CONV_DBG");
   p.dbg = dbg;
   p.shift_n = d->shift_nstride;
+  p.x_planar = 0;
+  p.x_lpad = d->x_lpad;
+  p.x_w = d->Wi;
+  p.x_c = d->Cin;
+  if (d->x_nchw_f32 != 0 && (!d->pool || !g.rowpack || d->x_cstride != 4 || d->Cin > 3 || d->dtype != FT_F16)) return FT_ERR_UNSUPPORTED;
   p.epi_lds = d->dtype == FT_F16 && d->out_layout == FT_LAYOUT_NHWC && d->Cout % 8 == 0 && d->y_coff % 8 == 0 &&
               d->y_cstride % 8 == 0 && (!d->has_residual || (d->res_coff % 8 == 0 && d->res_cstride % 8 == 0));
   hipStream_t s = as_stream(stream);
@@ -2809,6 +2847,7 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   if (d->pool) {            // stem + max-pool: y is the pooled [N, Ho/2, Wo/2, Cout] map
     if (!g.rowpack || x_bytes >= (1ull << 31) || d->tail_cout > 0 || d->x2_cin > 0 || d->has_residual) return FT_ERR_UNSUPPORTED;
     p.x_bytes = (unsigned)x_bytes;
+    p.x_planar = d->x_nchw_f32 != 0;
     return launch_stem_pool(p, d, g, s);
   }
   if (d->tail_cout > 0) {   // conv + fused tail 1x1 conv: 128 pixels x all Cout channels per workgroup

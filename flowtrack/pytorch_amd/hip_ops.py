@@ -759,16 +759,25 @@ class FusedConv:
         return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
 
     def record(self, prog: Program, x: ActView, y, residual: Optional[ActView] = None, pool: bool = False,
-               shift_n=None) -> None:
+               shift_n=None, x_nchw: Optional[torch.Tensor] = None) -> None:
         """Append this layer to `prog`. y is an ActView (NHWC) or a contiguous NCHW fp32 tensor.
         pool=True (the ResNet stem): the 3x3/s2/p1 max-pool runs inside the launch, y is the pooled map.
         shift_n: callable(scale, shift) -> fp32 [N, Cout] tensor of PER-SAMPLE shifts (ft_conv_desc.shift_nstride); it is
         called with the layer's folded tables right before the conv launch is appended, so it can record the launch that
-        fills the tensor (FlowNet2S's rgb mean folded into conv1: ft_flow_mean_fold)."""
+        fills the tensor (FlowNet2S's rgb mean folded into conv1: ft_flow_mean_fold).
+        x_nchw (with pool=True): the network's NCHW fp32 input [N, Cin, H, W] itself (ft_conv_desc.x_nchw_f32) — `x` then is
+        only the GEOMETRY of the row-packed view the kernel builds in LDS (its tensor may live on the `meta` device) and no
+        pack launch is needed."""
         if x.C != self.cin:
             raise FlowtrackHipError(f"{self.label}: input has {x.C} channels, layer expects {self.cin}")
         if x.t.dtype != self.dtype or not x.t.is_contiguous():
             raise FlowtrackHipError(f"{self.label}: input buffer must be contiguous {self.dtype}")
+        if x_nchw is not None:
+            if not pool or not x.rowpacked or tuple(x_nchw.shape) != (x.N, self.cin, x.H, x.W) or x_nchw.dtype != torch.float32 \
+                    or not x_nchw.is_contiguous():
+                raise FlowtrackHipError(f"{self.label}: x_nchw must be the contiguous fp32 [N, Cin, H, W] input of a pooled stem")
+        elif x.t.device.type == "meta":
+            raise FlowtrackHipError(f"{self.label}: a geometry-only input view needs x_nchw")
         Ho, Wo = self.out_hw(x.H, x.W)
         d = ConvDesc()
         d.dtype = self.code
@@ -807,6 +816,9 @@ class FusedConv:
                 raise FlowtrackHipError(f"{self.label}: a fused tail excludes a residual input")
             d.tail_cout = self.tail_cout
             res_ptr = self._tail.data_ptr()
+        x_ptr, x_keep = x.t.data_ptr() if x_nchw is None else x_nchw.data_ptr(), x.t if x_nchw is None else x_nchw
+        if x_nchw is not None:
+            d.x_nchw_f32 = 1
         w, _, scale, shift = self._packed_for(d)
         if shift_n is not None:
             d.shift_nstride = self.cout
@@ -828,24 +840,27 @@ class FusedConv:
                      scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, res_ptr,
                      yt.data_ptr(), keep=(dd, x.t, yt, ws, scale, shift, residual.t if residual is not None else None))
             prog.option("igemm")
-        self._record_igemm(prog, d, x, w, scale, shift, res_ptr, yt, residual, flops)
+        self._record_igemm(prog, d, x, w, scale, shift, res_ptr, yt, residual, flops, x_ptr, x_keep)
         if ws is not None:
             prog.end_choice()
 
-    def _record_igemm(self, prog: Program, d: ConvDesc, x: ActView, w, scale, shift, res_ptr, yt, residual, flops: float) -> None:
+    def _record_igemm(self, prog: Program, d: ConvDesc, x: ActView, w, scale, shift, res_ptr, yt, residual, flops: float,
+                      x_ptr=None, x_keep=None) -> None:
+        x_ptr = x.t.data_ptr() if x_ptr is None else x_ptr
+        x_keep = x.t if x_keep is None else x_keep
         prog.flops += flops
         prog.conv_records.append((self.label, len(prog.calls), flops, d))
         if prog._side:     # side-branch launches may overlap main-branch ones: they must not share the plan's workspace
-            prog.add("ft_conv2d_fwd", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
+            prog.add("ft_conv2d_fwd", ctypes.byref(d), x_ptr, w.data_ptr(),
                      scale.data_ptr() if scale is not None else None,
                      shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(),
-                     keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
+                     keep=(d, x_keep, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
             return
         prog.need_workspace(self.lib.ft_conv_workspace_bytes(ctypes.byref(d)))
-        prog.add("ft_conv2d_fwd_ws", ctypes.byref(d), x.t.data_ptr(), w.data_ptr(),
+        prog.add("ft_conv2d_fwd_ws", ctypes.byref(d), x_ptr, w.data_ptr(),
                  scale.data_ptr() if scale is not None else None,
                  shift.data_ptr() if shift is not None else None, res_ptr, yt.data_ptr(), prog._ws_ptr, prog._ws_size,
-                 keep=(d, x.t, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
+                 keep=(d, x_keep, yt, w, scale, shift, residual.t if residual is not None else None, self._tail))
 
 
 #: 1x1 layers with few pixels and a long K run on ft_conv_direct_fwd (weights straight to registers); FT_CONV_DIRECT=0 keeps

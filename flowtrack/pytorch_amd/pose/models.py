@@ -68,6 +68,11 @@ class DeconvResnet(HipModule):
     fuse_bottleneck: bool = os.environ.get("FT_FUSE_BOTTLENECK", "1") != "0"
     #: the stem's max-pool inside the stem conv launch (ft_conv_desc.pool); FT_FUSE_STEM_POOL=0 keeps the two launches
     fuse_stem_pool: bool = os.environ.get("FT_FUSE_STEM_POOL", "1") != "0"
+    #: FT_FUSE_STEM_PACK=1: the fused stem reads the NCHW fp32 input itself (ft_conv_desc.x_nchw_f32): no pack launch, no packed copy,
+    #: bit-identical results.  Measured at batch 64 x 256x192 (same box): pack 18.4 us + stem 42.5 us -> stem 66.0 us, graph replay
+    #: 1.210 -> 1.227 ms: the gather (30 predicated 4-byte loads per lane where the packed view is four 16-byte LDS-DMA loads) costs
+    #: more than the launch it removes.  Off by default; kept as a tested alternative.
+    fuse_stem_pack: bool = os.environ.get("FT_FUSE_STEM_PACK", "0") == "1"
     #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
     #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
     keypoints_in_plan = None
@@ -149,17 +154,20 @@ class DeconvResnet(HipModule):
         # (ft_conv_desc.pool; its patch starts one stem column further left: 5 physical pad columns instead of 3) and the
         # [B, H/2, W/2, 64] stem map never exists
         pool_in_stem = self.fuse_stem_pool and dtype == torch.float16
-        a_in = new_rowpacked_act(B, H, W, 3, 5 if pool_in_stem else 3, dtype, device)
-        record_pack_input(prog, x_static, a_in)
+        planar_in = pool_in_stem and self.fuse_stem_pack      # the stem gathers its patches from x_static: a_in is geometry only
+        a_in = new_rowpacked_act(B, H, W, 3, 5 if pool_in_stem else 3, dtype, "meta" if planar_in else device)
+        if not planar_in:
+            record_pack_input(prog, x_static, a_in)
+        xs = (lambda lo, hi: x_static[lo:hi]) if planar_in else (lambda lo, hi: None)
 
         stem = self.fused("conv1" + ("+maxpool" if pool_in_stem else ""), self.conv1.weight, stride=2, pad=3, bn=self.bn1.as_dict(),
                           act="relu", **mk)
         cur = new_act(B, H // 4, W // 4, 64, dtype, device)
         split = self.split_lanes if (dtype == torch.float16 and B % 2 == 0 and B >= 32 and pool_in_stem) else 0
         if split == 2:
-            stem.record(prog, a_in.batch_slice(0, B // 2), cur.batch_slice(0, B // 2), pool=True)     # (the other half: on the second lane)
+            stem.record(prog, a_in.batch_slice(0, B // 2), cur.batch_slice(0, B // 2), pool=True, x_nchw=xs(0, B // 2))     # (the other half: on the second lane)
         elif pool_in_stem:
-            stem.record(prog, a_in, cur, pool=True)
+            stem.record(prog, a_in, cur, pool=True, x_nchw=xs(0, B))
         else:
             a1 = new_act(B, H // 2, W // 2, 64, dtype, device)
             stem.record(prog, a_in, a1)
@@ -182,7 +190,7 @@ class DeconvResnet(HipModule):
                     if half == 1:
                         with prog.side():
                             if split == 2:      # half a block of useful delay: the lanes' memory and matrix phases interleave
-                                stem.record(prog, a_in.batch_slice(lo, hi), cur.batch_slice(lo, hi), pool=True)
+                                stem.record(prog, a_in.batch_slice(lo, hi), cur.batch_slice(lo, hi), pool=True, x_nchw=xs(lo, hi))
                             for name, blk, out_full in chain:
                                 o = out_full.batch_slice(lo, hi)
                                 self._record_block(prog, name, blk, c, o, dtype, device)

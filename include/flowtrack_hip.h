@@ -157,6 +157,12 @@ typedef struct ft_conv_desc {
    * shift + n * shift_nstride — the fold of FlowNet2*'s per-sample rgb mean into conv1 (ft_flow_mean_fold below).
    * Supported by the persistent row-packed 7x7 / stride 2 fp16 stem only; FT_ERR_UNSUPPORTED elsewhere. */
   int shift_nstride;
+  /* 1: `x` is the reference's NCHW fp32 network input [N, Cin, Hi, Wi] itself (Cin <= 4), not a packed copy: the stem kernel
+   * gathers its input patch from the planes, casts to fp16 and lays it out in LDS exactly as ft_pack_nchw_to_nhwc would have
+   * written it, so the pack launch and its [N, Hi, x_wpitch, 4] buffer disappear and the result is bit-identical.  x_cstride (4),
+   * x_lpad and x_wpitch then describe that VIRTUAL row-packed view.  Supported with pool = 1 (the fp16 ResNet stem,
+   * lib/pose/models/resnet.py:19-23) only; FT_ERR_UNSUPPORTED elsewhere. */
+  int x_nchw_f32;
 } ft_conv_desc;
 
 /* Packed-weight geometry (ft_conv_pack_geometry): w_packed is [nphases][cout_pad][kpad] of d->dtype,

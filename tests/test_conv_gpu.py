@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from flowtrack.pytorch_amd import synth
-from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv, act_stride
+from flowtrack.pytorch_amd.hip_ops import ActView, FlowtrackHipError, FusedConv, act_stride
 from util import make_program, nchw_to_view, run_program, view_to_nchw
 
 pytestmark = pytest.mark.gpu
@@ -444,6 +444,21 @@ def test_stem_with_fused_maxpool_matches_oracle_and_separate_launches(hip_lib, c
     pooled.t.fill_(7.0)
     run_program(prog)
     assert torch.equal(view_to_nchw(pooled), got)
+
+    # ft_conv_desc.x_nchw_f32: the same launch gathering its patches from the NCHW fp32 input itself (no pack launch, the packed
+    # view is geometry only): bit-identical
+    planar = new_act(N, Hp, Wp, 64, dtype, dev)
+    planar.t.fill_(5.0)
+    geom = new_rowpacked_act(N, H, W, 3, 5, dtype, "meta")
+    prog3 = make_program()
+    layer.record(prog3, geom, planar, pool=True, x_nchw=xs)
+    assert [c[0] for c in prog3.calls if not c[0].startswith("__")] in (["ft_conv2d_fwd_ws"], ["ft_conv2d_fwd"])
+    run_program(prog3)
+    assert torch.equal(view_to_nchw(planar), got), f"{name}: the stem on the NCHW input differs from pack + stem"
+    with pytest.raises(FlowtrackHipError):
+        layer.record(make_program(), geom, planar, pool=True)                        # geometry-only view without the input
+    with pytest.raises(FlowtrackHipError):
+        layer.record(make_program(), fused_in, planar, pool=True, x_nchw=xs[:, :2])  # wrong plane count
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 16, 24, 5), (1, 3, 9, 18, 3), (3, 2, 8, 32, 3), (2, 3, 6, 20, 3), (2, 3, 256, 192, 5)], ids=str)

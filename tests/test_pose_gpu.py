@@ -166,6 +166,24 @@ def test_cross_layer_fusions_do_not_change_the_network(hip_lib, shape):
     assert flips.float().mean().item() <= 0.1
 
 
+def test_stem_on_the_nchw_input_is_bit_identical_to_pack_plus_stem(hip_lib, monkeypatch):
+    """fp16 plan whose fused stem gathers its patches from the NCHW fp32 input (ft_conv_desc.x_nchw_f32: no pack launch, no packed
+    copy; resnet.py:19-23) vs the plan with ft_pack_nchw_to_nhwc in front of the same launch: with the tile picks shared, the
+    heat maps are bit-identical (the same fp16 cast of the same pixels into the same LDS bytes)."""
+    from flowtrack.pytorch_amd import hip_ops
+    monkeypatch.setattr(hip_ops, "benchmark", False)          # the recorder's heuristics on both sides: identical launch lists
+    x = synth.pose_crops(SEED + 5, 3, 256, 192).cuda()
+    a, _ = _model(50, torch.float16)
+    b, _ = _model(50, torch.float16)
+    a.fuse_stem_pack, b.fuse_stem_pack = True, False
+    ya, yb = a(x), b(x)
+    na, nb = [n for n, _ in a._last_plan.prog.calls], [n for n, _ in b._last_plan.prog.calls]
+    assert "ft_pack_nchw_to_nhwc" not in na and "ft_pack_nchw_to_nhwc" in nb, (na[:3], nb[:3])
+    assert len(na) + 1 == len(nb), (len(na), len(nb))
+    assert torch.equal(ya, yb), (ya.float() - yb.float()).abs().max().item()
+    assert torch.equal(a(x), ya)                               # graph replay
+
+
 def test_plan_alternatives_are_resolved_and_equivalent(hip_lib, monkeypatch):
     """A captured plan holds no unresolved choice (fused block vs three convs, direct vs implicit-GEMM 1x1): after the first
     call every alternative but one is gone, and forcing the OTHER option of every choice gives the same network to fp16
