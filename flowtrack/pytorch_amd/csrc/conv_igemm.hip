@@ -1607,35 +1607,30 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
   constexpr unsigned kOOB = 0x80000000u;
 
   const int nchunks = PH * CPR;
+  constexpr int NR = 5;                        // x_planar: rounds of 256 chunks: 39 rows x <= 32 chunks (the pose stem: 39 x 20 = 780)
+  float v[NR][2][3];
   if (p.x_planar) {
     // ft_conv_desc.x_nchw_f32: the patch straight from the network's NCHW fp32 input.  Chunk gci = two pixels (8 bytes each: up to
     // 4 channels as fp16) of patch row gci / CPR, at the LDS byte the packed view's chunk would have been DMA'd to; a lane reads
     // its pixels' planes (lanes = consecutive pixel pairs: 160 contiguous bytes per plane and patch row), casts as
-    // pack_nchw_rows4_kernel does and writes 16 bytes.  Loads of all rounds first, then the casts and LDS writes.
-    constexpr int NR = 5;                      // rounds of 256 chunks: 39 rows x <= 32 chunks (the pose stem: 39 x 20 = 780)
-    const float* xf = reinterpret_cast<const float*>(p.x);
-    const size_t HW = (size_t)p.Hi * p.x_w;
-    float v[NR][2][3];
+    // pack_nchw_rows4_kernel does and writes 16 bytes.  Loads of all rounds first; the casts and LDS writes follow the weight prologue below.
+    // (buffer loads with out-of-range offsets for everything outside the image: no branch per load — as predicated global loads
+    // every one of the 30 sat in its own divergent region behind a full wait: 66 us instead of 42.5 + 18.4 for pack + stem)
+    const __amdgpu_buffer_rsrc_t rsrc_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+    const int HWb = p.Hi * p.x_w * 4;
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
       const int gci = (t * NW + wave) * 64 + lane;
       const int row = gci / CPR, ch = gci - row * CPR;
       const int iy = iy_org + row, ix0 = col0 + 2 * ch - p.x_lpad;
       const bool row_in = t < p.h_npww && gci < nchunks && (unsigned)iy < (unsigned)p.Hi;
-      const float* base = xf + (size_t)n * p.x_c * HW + (size_t)(row_in ? iy : 0) * p.x_w;
+      const unsigned rbase = (unsigned)(((n * p.x_c * p.Hi + iy) * p.x_w + ix0) * 4);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const bool in = row_in && (unsigned)(ix0 + e) < (unsigned)p.x_w;
+        const unsigned vo = (row_in && (unsigned)(ix0 + e) < (unsigned)p.x_w) ? rbase + 4u * e : kOOB;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[t][e][c] = (in && c < p.x_c) ? base[(size_t)c * HW + ix0 + e] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NR; ++t) {
-      if (t < p.h_npww) {
-        const half8_t h8 = {(half_t)v[t][0][0], (half_t)v[t][0][1], (half_t)v[t][0][2], (half_t)0.f,
-                            (half_t)v[t][1][0], (half_t)v[t][1][1], (half_t)v[t][1][2], (half_t)0.f};
-        *reinterpret_cast<half8_t*>(patch + ((t * NW + wave) * 64 + lane) * 16) = h8;
+        for (int c = 0; c < 3; ++c)
+          v[t][e][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_f, c < p.x_c ? vo : kOOB, c * HWb, 0));
       }
     }
   } else {
@@ -1670,6 +1665,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
                                                live ? a_voff[t] : kOOB, live ? ky * RUNB : 0, 0, 0);
   };
   static_for<S - 1>([&](auto sc) { load_a(sc, decltype(sc)::value < KH, decltype(sc)::value); });
+  if (p.x_planar) {                            // the gathered pixels land in the patch while the first weight rows are on their way
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      if (t < p.h_npww) {
+        const half8_t h8 = {(half_t)v[t][0][0], (half_t)v[t][0][1], (half_t)v[t][0][2], (half_t)0.f,
+                            (half_t)v[t][1][0], (half_t)v[t][1][1], (half_t)v[t][1][2], (half_t)0.f};
+        *reinterpret_cast<half8_t*>(patch + ((t * NW + wave) * 64 + lane) * 16) = h8;
+      }
+    }
+  }
 
   const int r_a = wc * 32 + l31;
   const int a_off = r_a * RUNB + ((lhi ^ ((r_a / SWZ_DIV) % CH)) << 4);
@@ -2848,6 +2853,11 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
     if (!g.rowpack || x_bytes >= (1ull << 31) || d->tail_cout > 0 || d->x2_cin > 0 || d->has_residual) return FT_ERR_UNSUPPORTED;
     p.x_bytes = (unsigned)x_bytes;
     p.x_planar = d->x_nchw_f32 != 0;
+    if (p.x_planar) {       // the buffer descriptor then covers the fp32 planes
+      const unsigned long long pb = (unsigned long long)d->N * d->Cin * d->Hi * d->Wi * 4;
+      if (pb >= (1ull << 31)) return FT_ERR_UNSUPPORTED;
+      p.x_bytes = (unsigned)pb;
+    }
     return launch_stem_pool(p, d, g, s);
   }
   if (d->tail_cout > 0) {   // conv + fused tail 1x1 conv: 128 pixels x all Cout channels per workgroup

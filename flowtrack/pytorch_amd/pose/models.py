@@ -68,11 +68,11 @@ class DeconvResnet(HipModule):
     fuse_bottleneck: bool = os.environ.get("FT_FUSE_BOTTLENECK", "1") != "0"
     #: the stem's max-pool inside the stem conv launch (ft_conv_desc.pool); FT_FUSE_STEM_POOL=0 keeps the two launches
     fuse_stem_pool: bool = os.environ.get("FT_FUSE_STEM_POOL", "1") != "0"
-    #: FT_FUSE_STEM_PACK=1: the fused stem reads the NCHW fp32 input itself (ft_conv_desc.x_nchw_f32): no pack launch, no packed copy,
-    #: bit-identical results.  Measured at batch 64 x 256x192 (same box): pack 18.4 us + stem 42.5 us -> stem 66.0 us, graph replay
-    #: 1.210 -> 1.227 ms: the gather (30 predicated 4-byte loads per lane where the packed view is four 16-byte LDS-DMA loads) costs
-    #: more than the launch it removes.  Off by default; kept as a tested alternative.
-    fuse_stem_pack: bool = os.environ.get("FT_FUSE_STEM_PACK", "0") == "1"
+    #: the fused stem reads the NCHW fp32 input itself (ft_conv_desc.x_nchw_f32): no pack launch, no packed copy, bit-identical
+    #: results; FT_FUSE_STEM_PACK=0 keeps ft_pack_nchw_to_nhwc in front of it.  Batch 64 x 256x192, same box: pack 18.7 us + stem 38.5
+    #: us -> stem 46.2 us, 59.52 / 59.31 -> 59.71 / 59.61 k crops/s (the first version, predicated global loads instead of
+    #: out-of-range buffer loads, ran the stem at 66 us: every load in its own divergent region behind a full wait)
+    fuse_stem_pack: bool = os.environ.get("FT_FUSE_STEM_PACK", "1") != "0"
     #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
     #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
     keypoints_in_plan = None

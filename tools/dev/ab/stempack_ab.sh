@@ -6,4 +6,3 @@ for i in 1 2; do for f in 0 1; do
 done; done
 FT_FUSE_STEM_PACK=0 timeout 300 python tools/dev/net_bench.py resnet50 64 256 192 fp16 2>&1 | grep -E "^ +[0-2] |graph replay"
 FT_FUSE_STEM_PACK=1 timeout 300 python tools/dev/net_bench.py resnet50 64 256 192 fp16 2>&1 | grep -E "^ +[0-2] |graph replay"
-for f in 0 1; do echo "== R101 b16 FT_FUSE_STEM_PACK=$f"; FT_FUSE_STEM_PACK=$f timeout 300 python bench.py --backbone resnet101 --res 384x288 --batch 16 --no-extras --no-cpu-baseline --steps 400 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"; done
