@@ -31,6 +31,11 @@
 
 #include "ft_common.h"
 
+// cache-policy bits of the block input's LDS-DMA loads (read once per workgroup + its halo neighbours): 0 = default, 2 = nt (A/B
+// builds: tools/dev/build_variant.sh bnknt -DFT_BNK_XLOAD_AUX=2)
+#ifndef FT_BNK_XLOAD_AUX
+#define FT_BNK_XLOAD_AUX 0
+#endif
 namespace ft {
 namespace {
 
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
     for (int t = 0; t < 6; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(st + (t * 4 + wave) * 1024), 16, x_voff[t],
-                                               x_voff[t] == kOOB ? 0 : c * 128, 0, 0);
+                                               x_voff[t] == kOOB ? 0 : c * 128, 0, FT_BNK_XLOAD_AUX);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (lds_ptr)(st + kXChunk + (t * 4 + wave) * 1024), 16, w1_voff[t], c * 128, 0, 0);
