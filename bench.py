@@ -139,7 +139,7 @@ def conv_roofline(prog, dtype_name, iters=5):
         ms = times[call_idx][1]
         per_layer.append((label, fl, ms))
     return {
-        "bound": "mfma", "kernel": "every conv launch of the step (ft_conv2d_fwd / ft_conv_direct_fwd / ft_bottleneck_fwd / ft_bottleneck_stream_fwd): conv_igemm8_kernel (persistent 256x256 8-phase tile), conv_igemm_dma_kernel + its LDS-patch (halo / stem / pflow) and few-output variants, conv_direct / conv3x3_direct (weights straight to registers), the fused bottleneck kernels (LDS-resident and streamed weights)", "achieved": round(achieved, 2), "peak": peak,
+        "bound": "mfma", "kernel": "all conv launches of the step (DESIGN.md 3)", "achieved": round(achieved, 2), "peak": peak,
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
         "achieved_conv_kernels_only": round(achieved_conv, 2), "frac_conv_kernels_only": round(achieved_conv / peak, 4),
         "launches_per_step": n_conv, "flop_per_launch_avg": flops / max(n_conv, 1),
@@ -213,10 +213,24 @@ def cpu_baseline_pose(seconds=15.0):
         if el >= seconds or n >= 200:
             break
     return {"value": round(4 * n / el, 2), "unit": "crops/s", "cores": cores, "physical_cores": physical_cores(), "logical_cpus": avail,
-            "kind": "port",
-            "sample": f"{n} forwards of batch 4 x 3x256x192 fp32 (BASELINE configs[0]) in {el:.1f} s, torch CPU {torch.__version__}, "
-                      f"{cores} threads = `cores` (the fastest of the tried counts; the host has {physical_cores()} physical cores, "
-                      f"{avail} logical CPUs visible to this process)"}
+            "kind": "port", **_other_thread_counts(lambda: pose_ref.pose_forward(sd, x), 4, cores, avail),
+            "sample": f"{n} fwd of 4x3x256x192 fp32 (configs[0]) in {el:.1f} s, torch CPU, `cores` = fastest thread count tried"}
+
+
+def _other_thread_counts(fn, units, best, avail, budget_s=6.0):
+    """the CPU figure at ALL physical cores and at 1 thread beside the fastest count (`value`)."""
+    out = {}
+    for key, c in (("value_all_physical_cores", min(physical_cores() or avail, avail)), ("value_1_thread", 1)):
+        torch.set_num_threads(c)
+        fn()
+        t0, n = time.perf_counter(), 0
+        while n < 1 or (time.perf_counter() - t0 < budget_s / 2 and n < 20):
+            fn()
+            n += 1
+        out[key] = round(units * n / (time.perf_counter() - t0), 2)
+        out[key + "_threads"] = c
+    torch.set_num_threads(best)
+    return out
 
 
 def cpu_baseline_flow(seconds=15.0):
@@ -234,9 +248,8 @@ def cpu_baseline_flow(seconds=15.0):
         if el >= seconds or n >= 100:
             break
     return {"value": round(n / el, 2), "unit": "pairs/s", "cores": cores, "physical_cores": physical_cores(), "logical_cpus": avail,
-            "kind": "port",
-            "sample": f"{n} FlowNet2S forwards of 1 x 3x2x384x512 fp32 in {el:.1f} s, torch CPU, {cores} threads = `cores` "
-                      f"(fastest of the tried counts; {physical_cores()} physical cores, {avail} logical CPUs visible)"}
+            "kind": "port", **_other_thread_counts(lambda: flow_ref.flownet2s_forward(sd, x), 1, cores, avail, budget_s=4.0),
+            "sample": f"{n} FlowNet2S fwd of 1x3x2x384x512 fp32 in {el:.1f} s, torch CPU, `cores` = fastest thread count tried"}
 
 
 HBM_PEAK_TBS = 8.0   # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
@@ -411,16 +424,12 @@ def exact_argmax_record(model16, model32, x16, x32, device, steps, world):
     return {"value": round(B * world * steps / el, 2), "unit": "crops/s", "steps": steps, "repeats": rep, "ms_per_step": round(1e3 * el / steps, 4),
             "timed_region_s": round(tot, 4), "rel_bound": model16.exact_argmax_rel_bound,
             "no_rerun_path": {"value": round(B * world * steps / el0, 2), "unit": "crops/s", "ms_per_step": round(1e3 * el0 / steps, 4),
-                              "repeats": rep0, "timed_region_s": round(tot0, 4),
-                              "note": "screen bound 0: nothing flagged = the cost of the mode on single-peak heat maps"},
+                              "repeats": rep0, "timed_region_s": round(tot0, 4)},
             "rerun_frac": round(rerun["n"] / max(rerun["calls"] * B, 1), 4),
             "argmax_identical_frac": same_b, "argmax_identical_frac_1024_crops": round(same / max(total, 1), 6),
             "rerun_frac_1024_crops": round(flagged / 1024.0, 4),
             "crop_min_margin_quantiles_1024_crops": {q: float(np.quantile(np.concatenate(margins), float(q))) for q in ("0.1", "0.5", "0.9")},
-            "crops_below_margin_1024_crops": {str(t): round(float((np.concatenate(margins) < t).mean()), 4) for t in (1e-3, 2e-3, 4e-3, 8e-3)},
-            "note": "fp16 pass + device screen (E = rel_bound x range of the crop's maps; flagged: a top-1 / top-2 margin < 2 E, a maximum "
-                    "within E of 0, anything non-finite) + fp32 re-run of the flagged crops; identity is against the fp32 parity mode of "
-                    "the same weights; random weights give noise-like maps, so nearly every crop is flagged and `value` is the fp32 speed"}
+            "crops_below_margin_1024_crops": {str(t): round(float((np.concatenate(margins) < t).mean()), 4) for t in (1e-3, 2e-3, 4e-3, 8e-3)}}
 
 
 def clip_record(device, n_frames=300):
@@ -451,38 +460,38 @@ def clip_record(device, n_frames=300):
         torch.cuda.synchronize()
         dk = time.perf_counter() - t1
         multi[key] = {"frames_per_s_total": round(K * nf / dk, 1), "wall_s": round(dk, 4)}
-    return {"metric": "full FlowTrack pipeline frames/sec (detector boxes -> pose crops + FlowNet2S box propagation + id assignment)",
-            "clips": {"K": K, "frames_per_clip": nf, **multi,
-                      "note": "K independent clips on ONE GPU (configs[4] scaled out by clip: one process per GPU x K clips, no exchange): own "
-                              "the clips' batch-parallel phases first, then their sequential passes in lock-step in 2 groups: a group's crops of a "
-                              "round share ONE plan replay (own plan replicas, pinned slots and stream per group), the other group's host work "
-                              "overlaps it"},
+    return {"metric": "FlowTrack clip frames/sec (configs[4] on 1 GPU: R50 pose + FlowNet2S fp16, 300 synthetic frames)",
+            "clips": {"K": K, "frames_per_clip": nf, **multi},
             "frames": n_frames, "frame_hw": [int(frames.shape[1]), int(frames.shape[2])], "people": 5,
             "frames_per_s": round(n_frames / dt, 1), "wall_s": round(dt, 4), "flow_s": round(tm["flow_s"], 4),
             "pose_s": round(tm["pose_s"], 4), "pass_s": round(tm["track_s"], 4), "pass_frac": round(tm["track_s"] / dt, 3),
-            "boxes_per_frame_avg": round(sum(len(f["boxes"]) for f in res) / n_frames, 2),
-            "config": "BASELINE.json configs[4] on 1 GPU: ResNet-50 pose fp16 + FlowNet2S fp16, synthetic clip and weights, "
-                      "propagated boxes capped at 2x the detector boxes per frame (untrained pose net)"}
+            "boxes_per_frame_avg": round(sum(len(f["boxes"]) for f in res) / n_frames, 2)}
 
 
-def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B, force_gather=False):
-    """(model, x, step): the pose hot path on a batch resident in HBM, arg-max inside the plan's graph.  N > 1: the
-    [B,17,3] key-point rows of every rank are all-gathered (3.3 kB per rank) on a communication stream, one step behind
-    the compute stream (parallel.RowGatherer): step t's graph replays while step t-1's rows travel."""
+def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B, force_gather=False, rotate=1):
+    """(model, x, step): the pose hot path on batches resident in HBM, arg-max inside the plan's graph.  `rotate` > 1: that many
+    DIFFERENT batches are resident (one plan replica each: own input + activation buffers, shared packed weights) and the steps
+    go round them, so no step re-reads the bytes the previous one left in the 256-MB Infinity Cache.
+    N > 1: the [B,17,3] key-point rows of every rank are all-gathered (13 kB per rank) on a communication stream, one step
+    behind the compute stream (parallel.RowGatherer): step t's graph replays while step t-1's rows travel."""
     model = build_pose(device, dtype, backbone=backbone)
     model.keypoints_in_plan = True                          # arg-max + 0.25 px nudge run inside the plan's graph
-    x = model.static_input(B, H, W)                         # zero-copy binding: the batch is resident in HBM at the
-    x.copy_(synth.pose_crops(100 + rank, B, H, W))          # address the plan's graph reads, before the timed region
+    plans = [model.plan_for(B, H, W, r) for r in range(max(1, rotate))]
+    for r, pl in enumerate(plans):                          # zero-copy binding: each batch is resident in HBM at the address
+        pl.x_static.copy_(synth.pose_crops(100 + rank + 1000 * r, B, H, W))   # its plan's graph reads, before the timed region
+    x = plans[0].x_static
     kp_host = torch.empty((B, 17, 3), dtype=torch.float32).pin_memory()
     # force_gather (single-GPU tests): run the communication-stream path of the N > 1 step on one GPU
     gather = parallel.RowGatherer(B, (17, 3), torch.float32, device, force_stream=force_gather) if (world > 1 or force_gather) else None
-    state = {"pending": None}
+    state = {"pending": None, "i": 0}
 
     def consume(h):
         kp_host.copy_(gather.finish(h)[rank * B:(rank + 1) * B], non_blocking=True)   # (the consumer: the rank's own rows back on the host)
 
     def step():
-        rows = model.forward_keypoint_rows(x)                # [B,17,3] (x, y, score) rows written by the plan's last launch
+        plan = plans[state["i"] % len(plans)]
+        state["i"] = (state["i"] + 1) % len(plans)
+        rows = model.replay(plan).kp_rows                    # [B,17,3] (x, y, score) rows written by the plan's last launch
         if gather is None:
             kp_host.copy_(rows, non_blocking=True)
             return rows
@@ -497,17 +506,21 @@ def make_pose_runner(args, device, dtype, rank, world, backbone, H, W, B, force_
             consume(state["pending"])
             state["pending"] = None
     step.drain = drain
+    step.gather = gather
+    step.plans = plans
     return model, x, step
 
 
-def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sampled", force_gather=False):
+def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sampled", force_gather=False, rotate=1):
     """FlowNet on B frame pairs resident in HBM.  What leaves the GPU per step is what the consumer of the flow needs:
     the tracking glue reads the field at the previous frame's key points (lib/tracking/flow_utils.py:21-26), so by default
     the step samples the field at 8 x 17 points per pair and (N > 1) all-gathers those rows (1 kB per pair); `full`
     gathers the whole fields (1.57 MB per pair) instead."""
     model = build_flow(device, dtype, name=name)
-    x = model.static_input(B, 384, 512)                     # zero-copy binding (see the pose runner)
-    x.copy_(synth.frame_pairs(100 + rank, B))
+    plans = [model.plan_for(B, 384, 512, r) for r in range(max(1, rotate))]   # zero-copy binding, `rotate` resident batches (see the pose runner)
+    for r, pl in enumerate(plans):
+        pl.x_static.copy_(synth.frame_pairs(100 + rank + 1000 * r, B))
+    x = plans[0].x_static
     npts = 8 * 17
     pts = torch.from_numpy(synth.uniform01(7, "flow_sample_points", (npts,))).to(device)
     idx = (pts * (384 * 512 - 1)).long()
@@ -516,10 +529,12 @@ def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sam
     if (world > 1 or force_gather) and gather_mode != "none":
         gather = parallel.RowGatherer(B, (2, 384, 512) if full else (2, npts), torch.float32, device, force_stream=force_gather)
     samples = torch.empty((B, 2, npts), dtype=torch.float32, device=device)
-    state = {"pending": None}
+    state = {"pending": None, "i": 0}
 
     def step():
-        flow = model(x, copy_output=False)
+        plan = plans[state["i"] % len(plans)]
+        state["i"] = (state["i"] + 1) % len(plans)
+        flow = model.replay(plan).out
         if not full:
             torch.index_select(flow.flatten(2), 2, idx, out=samples)
         if gather is not None:
@@ -534,6 +549,8 @@ def make_flow_runner(args, device, dtype, rank, world, name, B, gather_mode="sam
             gather.finish(state["pending"])
             state["pending"] = None
     step.drain = drain
+    step.gather = gather
+    step.plans = plans
     return model, x, step
 
 
@@ -577,7 +594,13 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no flow / fp32_parity_mode / parity sub-records")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--rotate", type=int, default=4, help="resident batches the timed steps go round (1 = replay one batch)")
+    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
+                    help="c2 (default) = BASELINE configs[1] per GPU, weak; c3 = configs[2]: ResNet-101 384x288, 128 crops sharded over the "
+                         "N GPUs (128 / N per GPU: STRONG scaling); c5 = configs[4] by clip: every rank tracks its own clips")
     args = ap.parse_args()
+    if args.config == "c3":
+        args.backbone, args.res = "resnet101", "384x288"
 
     rank, local_rank, world = parallel.init_from_env()
     if world != args.gpus and world > 1:
@@ -588,36 +611,53 @@ def main():
     torch.cuda.set_device(device)
     dtype = torch.float16 if args.dtype == "fp16" else torch.float32
 
+    if args.config == "c5":
+        return main_clips(args, device, rank, world)
+    scaling = "weak"
     if args.workload == "pose":
         B = args.batch or 64
+        if args.config == "c3" and not args.batch:
+            if 128 % world:
+                raise SystemExit("--config c3 shards 128 crops: --gpus must divide 128")
+            B, scaling = 128 // world, "strong"
         H, W = (int(v) for v in args.res.lower().split("x"))
         depth = args.backbone[len("resnet"):]
         default_cfg = args.backbone == "resnet50" and (H, W) == (256, 192)
-        model, x, step = make_pose_runner(args, device, dtype, rank, world, args.backbone, H, W, B)
+        model, x, step = make_pose_runner(args, device, dtype, rank, world, args.backbone, H, W, B, rotate=args.rotate)
         unit, metric = "crops/s", f"pose crops/sec (ResNet-{depth} + 3-deconv head, {H}x{W})"
         cfg = "configs[1]" if default_cfg else ("configs[2]" if (args.backbone, H, W) == ("resnet101", 384, 288) else "variant")
         workload = f"ResNet-{depth} pose head {args.dtype}, batch {B} x {H}x{W} synthetic crops per GPU (BASELINE.json {cfg})"
     else:
         B = args.batch or 16
         default_cfg = args.flow_model == "FlowNet2S"
-        model, x, step = make_flow_runner(args, device, dtype, rank, world, args.flow_model, B, args.gather)
+        model, x, step = make_flow_runner(args, device, dtype, rank, world, args.flow_model, B, args.gather, rotate=args.rotate)
         unit, metric = "pairs/s", f"flow frame-pairs/sec ({args.flow_model}, 512x384)"
         workload = (f"{args.flow_model} {args.dtype}, batch {B} x 512x384 synthetic frame pairs per GPU "
                     f"(BASELINE.json configs[3]{'' if default_cfg else ' shape, other stack'})")
 
+    rccl = parallel.verify_gather(step.gather, rank) if (world > 1 and step.gather is not None) else None
     elapsed, repeats, total_s = measure(step, args.steps, args.warmup, device, args.fixed_warmup)
     value = B * world * args.steps / elapsed
     out = {
         "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "repeats": repeats, "timed_region_s": round(total_s, 4),
-        "timing": f"median of {repeats} blocks of exactly {args.steps} steps, each bracketed by barrier + synchronize (max over ranks)",
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic (counter-hash crops ~N(0,1) / translated-texture frame pairs, He-scaled random weights); "
-                                     "the same HBM-resident batch is processed every step",
-        "config": {"workload": workload, "per_gpu_batch": B,
+        "timing": f"median of {repeats} blocks of exactly {args.steps} steps, barrier + synchronize around each, max over ranks",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": args.dtype, "data": f"synthetic crops / frame pairs and random weights; {max(1, args.rotate)} different HBM-resident "
+                                     "batches in rotation",
+        "config": {"workload": workload, "per_gpu_batch": B, "resident_batches": max(1, args.rotate),
                    "parallelism": f"dp{world}: batch sharded, one process per GPU" +
                                   (", RCCL all-gather of the output rows on a comm stream, one step behind" if world > 1 else "")},
     }
+    if rccl is not None:
+        out["rccl"] = rccl
+    if args.rotate > 1 and not args.fixed_warmup:
+        # the same step replaying ONE resident batch (what rounds 1-4 reported): the A/B for the cache effect of rotation
+        keep = list(step.plans)
+        step.plans[:] = keep[:1]
+        el1, rep1, _ = measure(step, args.steps, 2, device)
+        step.plans[:] = keep
+        out["same_batch_replay"] = {"value": round(B * world * args.steps / el1, 2), "ms_per_step": round(1e3 * el1 / args.steps, 4), "repeats": rep1}
     if rank == 0:
         plan = next(iter(model._plans.values()))
         out["gflop_per_unit"] = round(plan.prog.flops / B / 1e9, 3)
@@ -641,16 +681,19 @@ def main():
     if extras:
         # (1) FlowNet2S fp16 on configs[3]'s pairs, every rank, same protocol; sized for >= ~1 s like the headline
         fsteps = max(20, min(args.steps, 1200))
-        fmodel, fx, fstep = make_flow_runner(args, device, torch.float16, rank, world, "FlowNet2S", 16, args.gather)
+        fmodel, fx, fstep = make_flow_runner(args, device, torch.float16, rank, world, "FlowNet2S", 16, args.gather, rotate=args.rotate)
+        frccl = parallel.verify_gather(fstep.gather, rank) if (world > 1 and fstep.gather is not None) else None
         fel, frep, ftot = measure(fstep, fsteps, args.warmup, device)
         if rank == 0:
             fplan = next(iter(fmodel._plans.values()))
             fval = 16 * world * fsteps / fel
             rec = {"metric": "flow frame-pairs/sec (FlowNet2S, 512x384)", "value": round(fval, 2), "unit": "pairs/s", "steps": fsteps,
                    "ms_per_step": round(1e3 * fel / fsteps, 4), "repeats": frep, "timed_region_s": round(ftot, 4), "dtype": "fp16",
-                   "config": {"workload": "FlowNet2S fp16, batch 16 x 512x384 synthetic frame pairs per GPU (BASELINE.json configs[3])",
-                              "per_gpu_batch": 16},
+                   "config": {"workload": "FlowNet2S fp16, 16 x 512x384 pairs per GPU (configs[3])", "per_gpu_batch": 16,
+                              "resident_batches": max(1, args.rotate)},
                    "gflop_per_unit": round(fplan.prog.flops / 16 / 1e9, 3)}
+            if frccl is not None:
+                rec["rccl"] = frccl
             if not args.no_roofline:
                 froof, _ = conv_roofline(fplan.prog, "fp16")
                 froof["traffic"], froof["traffic_source"] = pmc_traffic("flow")
@@ -670,7 +713,7 @@ def main():
             pval = 64 * world * psteps / pel
             rec = {"value": round(pval, 2), "unit": "crops/s", "steps": psteps, "ms_per_step": round(1e3 * pel / psteps, 4),
                    "repeats": prep, "timed_region_s": round(ptot, 4), "dtype": "fp32",
-                   "note": "same workload in the parity arithmetic: heat maps <= 1e-3 and arg-max identical vs the CPU reference"}
+                   }
             if not args.no_roofline:
                 proof, _ = conv_roofline(pplan.prog, "fp32")
                 rec["roofline"] = {k: proof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
@@ -682,14 +725,14 @@ def main():
         # (3b) BASELINE configs[2]'s PER-GPU shape: ResNet-101, 16 x 384x288 crops per GPU (128 crops over 8 GPUs) — what each rank
         # of the 8-GPU run executes; same protocol
         csteps = max(10, min(args.steps // 2, 400))
-        cmodel, cx, cstep = make_pose_runner(args, device, torch.float16, rank, world, "resnet101", 384, 288, 16)
+        cmodel, cx, cstep = make_pose_runner(args, device, torch.float16, rank, world, "resnet101", 384, 288, 16, rotate=args.rotate)
         cel, crep, ctot = measure(cstep, csteps, 3, device)
         if rank == 0:
             cplan = next(iter(cmodel._plans.values()))
             rec = {"metric": "pose crops/sec (ResNet-101 + 3-deconv head, 384x288)", "value": round(16 * world * csteps / cel, 2), "unit": "crops/s",
                    "steps": csteps, "repeats": crep, "ms_per_step": round(1e3 * cel / csteps, 4), "timed_region_s": round(ctot, 4), "dtype": "fp16",
-                   "config": {"workload": "ResNet-101 pose head fp16, batch 16 x 384x288 synthetic crops per GPU (BASELINE.json configs[2]: "
-                                          "128 crops sharded over 8 GPUs = this per-GPU shape)", "per_gpu_batch": 16},
+                   "config": {"workload": "ResNet-101 fp16, 16 x 384x288 crops per GPU (configs[2]'s per-GPU shape: 128 / 8)", "per_gpu_batch": 16,
+                              "resident_batches": max(1, args.rotate)},
                    "gflop_per_unit": round(cplan.prog.flops / 16 / 1e9, 3)}
             if not args.no_roofline:
                 croof, _ = conv_roofline(cplan.prog, "fp16")
@@ -705,7 +748,56 @@ def main():
     if extras and world == 1 and rank == 0:
         out["clip"] = clip_record(device)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["summary"] = summary_of(out)                    # LAST key: the sub-records' numbers in a few hundred characters
+        print(json.dumps(out, separators=(",", ":")), flush=True)
+    parallel.barrier()
+
+
+def summary_of(out):
+    """The numbers of the line a reader wants first, flat and short (the driver keeps only the tail of long lines)."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    s = {"pose_crops_s": out.get("value"), "pose_frac": g(out, "roofline", "frac"), "pose_same_batch_crops_s": g(out, "same_batch_replay", "value"),
+         "flow_pairs_s": g(out, "flow", "value"), "flow_frac": g(out, "flow", "roofline", "frac"),
+         "c3_crops_s": g(out, "c3_per_gpu", "value"), "c3_frac": g(out, "c3_per_gpu", "roofline", "frac"),
+         "fp32_crops_s": g(out, "fp32_parity_mode", "value"), "fp32_frac": g(out, "fp32_parity_mode", "roofline", "frac"),
+         "fp16_argmax_identical": g(out, "parity", "fp16", "argmax_identical_frac"), "fp16_heatmap_err": g(out, "parity", "fp16", "heatmap_max_abs_err"),
+         "fp16_mAP_OKS": g(out, "parity", "fp16", "mAP_at_OKS"), "fp32_argmax_identical": g(out, "parity", "fp32", "argmax_identical_frac"),
+         "exact_argmax_crops_s": g(out, "fp16_exact_argmax", "value"), "exact_no_rerun_crops_s": g(out, "fp16_exact_argmax", "no_rerun_path", "value"),
+         "clip_frames_s": g(out, "clip", "frames_per_s"), "clips8_frames_s": g(out, "clip", "clips", "interleaved", "frames_per_s_total"),
+         "cpu_crops_s": g(out, "cpu_baseline", "value"), "cpu_pairs_s": g(out, "flow", "cpu_baseline", "value"),
+         "rccl_ranks_verified": g(out, "rccl", "ranks_verified")}
+    for row in g(out, "flow", "roofline_ops") or []:
+        s[row["kernel"].replace("ft_", "").replace("_fwd", "") + "_frac"] = row["frac"]
+    return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items() if v is not None}
+
+
+def main_clips(args, device, rank, world):
+    """--config c5 = BASELINE configs[4] scaled out BY CLIP: every rank tracks its own K synthetic clips through
+    tools/tracking/demo.run_clips (no exchange between ranks at all: a clip's sequential pass cannot be sharded, clips can);
+    value = all ranks' frames / the slowest rank's wall time."""
+    from tools.tracking import demo
+    targs = types.SimpleNamespace(pose_backbone=50, pose_model="", flow_net="FlowNet2S", flow_model="", fp16=True)
+    pose, flow = demo.build_nets(targs, device)
+    K, nf = 8, 150
+    clips = [demo.synthetic_clip(nf, seed=rank * K + c) for c in range(K)]
+    demo.run_clips(clips, pose, flow, max_boxes="2x")       # builds every plan / graph
+    steps = max(1, min(args.steps, 3))
+    parallel.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        demo.run_clips(clips, pose, flow, max_boxes="2x")
+    torch.cuda.synchronize(); parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    if rank == 0:
+        print(json.dumps({"metric": "FlowTrack clip frames/sec (configs[4] by clip: R50 pose + FlowNet2S fp16, 8 clips x 150 frames per GPU)",
+                          "value": round(world * K * nf * steps / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": 1,
+                          "ms_per_step": round(1e3 * dt / steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "fp16", "data": "synthetic clips and weights", "config": {"workload": "BASELINE.json configs[4], one process per GPU x 8 clips",
+                                                                                               "clips_per_gpu": K, "frames_per_clip": nf}},
+                         separators=(",", ":")), flush=True)
     parallel.barrier()
 
 

@@ -129,6 +129,8 @@ _PROTOTYPES = {
     "ft_crop_affine_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p]),
     "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "ft_crop_affine_cv2_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                       c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

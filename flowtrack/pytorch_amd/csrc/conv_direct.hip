@@ -1249,6 +1249,7 @@ struct C3Plan {
 
 static int c3_plan(const ft_conv_desc* d, C3Plan* out) {
   if (!d) return FT_ERR_INVALID_ARG;
+  if (d->act == FT_ACT_LEAKY && !(d->slope >= 0.f && d->slope <= 1.f)) return FT_ERR_UNSUPPORTED;   // epilogues use max(v, k * v): valid for 0 <= k <= 1 only
   if (d->dtype != FT_F16 || d->transposed || d->kh != 3 || d->kw != 3 || (d->stride != 1 && d->stride != 2) || d->pad != 1) return FT_ERR_UNSUPPORTED;
   if (d->tail_cout || d->pool || d->x_wpitch || d->x2_cin || d->has_residual || d->out_layout != FT_LAYOUT_NHWC) return FT_ERR_UNSUPPORTED;
   if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0) return FT_ERR_UNSUPPORTED;
@@ -1543,6 +1544,7 @@ struct CdPlan {
 
 static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
   if (!d) return FT_ERR_INVALID_ARG;
+  if (d->act == FT_ACT_LEAKY && !(d->slope >= 0.f && d->slope <= 1.f)) return FT_ERR_UNSUPPORTED;   // epilogues use max(v, k * v): valid for 0 <= k <= 1 only
   if (d->dtype != FT_F16 || d->transposed) return FT_ERR_UNSUPPORTED;
   const bool taps = d->kh != 1 || d->kw != 1;
   if (taps) {        // the gather form: 3x3, stride 1 or 2, pad 1, no second input, no residual

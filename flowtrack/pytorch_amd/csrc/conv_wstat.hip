@@ -328,6 +328,7 @@ int ws_plan(const ft_conv_desc* d, WsPlan* out) {
   if (!d || !out) return FT_ERR_INVALID_ARG;
   static const int off = getenv("FT_CD_NO_WSTAT") ? atoi(getenv("FT_CD_NO_WSTAT")) : 0;
   if (off) return FT_ERR_UNSUPPORTED;
+  if (d->act == FT_ACT_LEAKY && !(d->slope >= 0.f && d->slope <= 1.f)) return FT_ERR_UNSUPPORTED;   // epilogues use max(v, k * v): valid for 0 <= k <= 1 only
   if (d->dtype != FT_F16 || d->transposed || d->kh != 5 || d->kw != 5 || d->stride != 2 || d->pad != 2 || d->Cin != 64) return FT_ERR_UNSUPPORTED;
   if (d->x2_cin || d->has_residual || d->tail_cout || d->pool || d->x_wpitch || d->out_layout != FT_LAYOUT_NHWC) return FT_ERR_UNSUPPORTED;
   if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Cout <= 0 || d->Cout % 64 || d->Cout > 2048) return FT_ERR_UNSUPPORTED;

@@ -523,11 +523,13 @@ class _FlowBase(HipModule):
     def _build_plan(self, B, H, W, device, dtype) -> _FlowPlan:  # pragma: no cover - abstract
         raise NotImplementedError
 
-    def plan_for(self, B: int, H: int, W: int) -> _FlowPlan:
+    def plan_for(self, B: int, H: int, W: int, replica: int = 0) -> _FlowPlan:
+        """`replica` > 0: an independent copy of the plan (own input / activation buffers and graph, same packed weights) for
+        callers that keep several batches of one shape resident (bench.py's rotation; as DeconvResnet.plan_for)."""
         device, dtype = self._resolve()
         if H % 64 or W % 64:
             raise FlowtrackHipError(f"frame size {H}x{W}: FlowNet needs multiples of 64")
-        key = (B, H, W, device, dtype)
+        key = (B, H, W, device, dtype) + ((replica,) if replica else ())
         plan = self._plans.get(key)
         if plan is None:
             with torch.no_grad():
@@ -555,6 +557,14 @@ class _FlowBase(HipModule):
         self._run_plan(plan.prog, first=plan.runs == 0)
         plan.runs += 1
         return plan.out.clone() if copy_output else plan.out
+
+    @torch.no_grad()
+    def replay(self, plan: _FlowPlan) -> _FlowPlan:
+        """Run a plan whose static input the caller filled in place (plan_for(...).x_static); the flow is plan.out."""
+        self._check_eval()
+        self._run_plan(plan.prog, first=plan.runs == 0)
+        plan.runs += 1
+        return plan
 
 
 class FlowNet2S(FlowNetS, _FlowBase):

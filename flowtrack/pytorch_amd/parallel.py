@@ -122,6 +122,30 @@ class RowGatherer:
         return self.recv[k]
 
 
+def verify_gather(gather: "RowGatherer", rank: int, device=None) -> dict:
+    """Evidence that the exchange of the N > 1 step really moved every rank's rows (bench.py prints it as `rccl`): each rank
+    stamps its row block with (rank + 1) + a per-row ramp, ONE RowGatherer round (start -> finish, the same code path the
+    timed steps use), then every rank checks all N blocks of what it received and the verdicts are MIN-reduced.  Outside
+    any timed region.  Returns {"world", "ranks_verified" (on the worst rank), "backend"}."""
+    world, n = gather.world, gather.n_local
+    send = gather.send[0]
+    ramp = torch.arange(n, dtype=torch.float32, device=send.device).view((n,) + (1,) * (send.dim() - 1)) / 1024.0
+    rows = (torch.full(send.shape, float(rank + 1), dtype=torch.float32, device=send.device) + ramp).to(send.dtype)
+    got = gather.finish(gather.start(rows))
+    if gather.cuda:
+        torch.cuda.current_stream(send.device).synchronize()
+    ok = 0
+    for r in range(world):
+        want = (torch.full(send.shape, float(r + 1), dtype=torch.float32, device=send.device) + ramp).to(send.dtype)
+        ok += int(torch.equal(got[r * n:(r + 1) * n], want))
+    if dist.is_initialized() and world > 1:
+        t = torch.tensor([ok], dtype=torch.int64, device=send.device if gather.cuda else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    return {"world": world, "ranks_verified": ok, "backend": dist.get_backend() if dist.is_initialized() else "none",
+            "bytes_per_rank": send.numel() * send.element_size()}
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

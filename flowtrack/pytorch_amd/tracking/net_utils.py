@@ -42,15 +42,58 @@ def boxes_to_center_scale(boxes: np.ndarray, inp_res=(256, 192)):
     return centers, scales
 
 
-def crop_boxes(frame_dev: torch.Tensor, centers: np.ndarray, scales: np.ndarray, inp_res=(256, 192), normalize=True):
+def cv2_crop_matrices(centers: np.ndarray, scales: np.ndarray, inp_res=(256, 192), out: np.ndarray = None) -> np.ndarray:
+    """Per box the dst -> src 2x3 map `cv2.warpAffine(img, t[:2], ...)` works with, float64 [N,6]: t = get_transform(center,
+    scale, res) (lib/pose/utils/transforms.py:173-184, rot = 0) and then the inversion cv::warpAffine performs on the matrix it
+    is handed (imgwarp.cpp: D = M0 * M4 - M1 * M3; D = 1 / D; ...), every operation in double and in the same order, so the
+    fixed-point coordinates the kernel derives are cv2's to the last bit.  With rot = 0: M1 = M3 = 0."""
+    c = np.asarray(centers, dtype=np.float64).reshape(-1, 2)
+    sc = np.asarray(scales, dtype=np.float64).reshape(-1)
+    h, w = float(inp_res[0]), float(inp_res[1])
+    m0 = h / sc                                             # t[0,0] = t[1,1] = res_ / scale
+    m2 = -h * c[:, 0] / sc + 0.5 * w                        # t[0,2]
+    m5 = -h * c[:, 1] / sc + 0.5 * h                        # t[1,2]
+    zero = np.zeros_like(m0)
+    D = m0 * m0 - zero * zero
+    with np.errstate(divide="ignore", invalid="ignore"):
+        D = np.where(D != 0, 1.0 / D, 0.0)
+    a11, a22 = m0 * D, m0 * D
+    n1, n3 = zero * -D, zero * -D
+    M = np.empty((len(sc), 6), dtype=np.float64) if out is None else out
+    M[:, 0], M[:, 1], M[:, 3], M[:, 4] = a11, n1, n3, a22
+    M[:, 2] = -a11 * m2 - n1 * m5
+    M[:, 5] = -n3 * m2 - a22 * m5
+    return M
+
+
+def crop_boxes(frame_dev: torch.Tensor, centers: np.ndarray, scales: np.ndarray, inp_res=(256, 192), normalize=True,
+               cv2_exact: bool = False, return_u8: bool = False):
     """frame_dev: uint8 [H,W,3] (BGR) on the GPU -> crops [N,3,h,w] fp32 on the GPU in one launch
-    (ft_crop_affine_fwd; replaces N x cv2.warpAffine + N H2D copies, net_utils.py:49-57)."""
+    (ft_crop_affine_fwd; replaces N x cv2.warpAffine + N H2D copies, net_utils.py:49-57).
+    cv2_exact: the crops are cv2.warpAffine's uint8 values bit for bit (ft_crop_affine_cv2_fwd: OpenCV's fixed-point
+    INTER_LINEAR) before the normalisation; return_u8 additionally returns them as uint8 [N,h,w,3] = cv2's return value."""
     require_gpu(frame_dev.device)
     if frame_dev.dtype != torch.uint8 or frame_dev.dim() != 3 or not frame_dev.is_contiguous():
         raise ValueError("frame must be a contiguous uint8 [H,W,C] device tensor")
     lib = _lib.load()
     H, W, C = frame_dev.shape
     n = len(scales)
+    if cv2_exact or return_u8:
+        minv = torch.from_numpy(cv2_crop_matrices(centers, scales, inp_res)).to(frame_dev.device)
+        out = torch.empty((n, C, inp_res[0], inp_res[1]), dtype=torch.float32, device=frame_dev.device)
+        u8 = torch.empty((n, inp_res[0], inp_res[1], C), dtype=torch.uint8, device=frame_dev.device) if return_u8 else None
+        mean = inv_std = None
+        pre = 1.0
+        if normalize:
+            mean = torch.tensor(BGR_MEAN[:C], dtype=torch.float32, device=frame_dev.device)
+            inv_std = torch.tensor([1.0 / s for s in BGR_STD[:C]], dtype=torch.float32, device=frame_dev.device)
+            pre = 1.0 / 255.0
+        check(lib.ft_crop_affine_cv2_fwd(frame_dev.data_ptr(), H, W, C, minv.data_ptr(), n, inp_res[0], inp_res[1],
+                                         mean.data_ptr() if mean is not None else None,
+                                         inv_std.data_ptr() if inv_std is not None else None, pre,
+                                         u8.data_ptr() if u8 is not None else None, out.data_ptr(),
+                                         current_stream_handle()), "ft_crop_affine_cv2_fwd")
+        return (out, u8) if return_u8 else out
     params = torch.from_numpy(np.concatenate((np.asarray(centers, np.float32).reshape(n, 2),
                                               np.asarray(scales, np.float32).reshape(n, 1)), axis=1)).to(frame_dev.device)
     out = torch.empty((n, C, inp_res[0], inp_res[1]), dtype=torch.float32, device=frame_dev.device)
@@ -124,11 +167,13 @@ class PoseRunner:
     plan look-up per call (tools/dev/clip_profile.py: 0.21 -> ~0.1 ms per frame)."""
     BUCKETS = (4, 8, 16, 32, 64, 128, 256)
 
-    def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None):
+    def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None, cv2_exact: bool = False):
         """replica / stream: a runner of its own plan copies (DeconvResnet.plan_for(..., replica)) whose launches go to
-        `stream` — several runners on one net then overlap on the GPU (one per clip, tools/tracking/demo.run_clips)."""
+        `stream` — several runners on one net then overlap on the GPU (one per clip, tools/tracking/demo.run_clips).
+        cv2_exact: crops are cv2.warpAffine's uint8 values bit for bit (ft_crop_affine_cv2_fwd) instead of the fp32 bilinear."""
         self.net, self.inp_res = net, inp_res
         self.replica, self.stream = int(replica), stream
+        self.cv2_exact = bool(cv2_exact)
         self.K = _num_joints(net)
         self.dev = next(net.parameters()).device
         require_gpu(self.dev)
@@ -145,6 +190,7 @@ class PoseRunner:
         self.slots = {}
         self._plans = {}                                   # bucket -> (plan, the net's plan dict it came from)
         self._calls = 0
+        self._checks = None
 
     def _stream_handle(self):
         """The stream the runner's launches go to, as the C ABI takes it: its own, else torch's current one."""
@@ -157,7 +203,7 @@ class PoseRunner:
         if sl is None:
             # box parameters live in pinned host memory the crop kernel reads directly (host allocations are mapped into the
             # device's address space at the same address): no H2D copy op on the stream, no staging tensor
-            ph = torch.zeros((bucket, 3), dtype=torch.float32).pin_memory()
+            ph = (torch.zeros((bucket, 6), dtype=torch.float64) if self.cv2_exact else torch.zeros((bucket, 3), dtype=torch.float32)).pin_memory()
             rh = torch.zeros((bucket, self.K, 3), dtype=torch.float32).pin_memory()
             ev = ctypes.c_void_p()
             check(self.lib.ft_event_create(ctypes.byref(ev)), "ft_event_create")
@@ -171,8 +217,11 @@ class PoseRunner:
 
     def _fill_params(self, sl, centers, scales, n, bucket):
         pn = sl["params_np"]
-        pn[:n, :2] = centers
-        pn[:n, 2] = scales
+        if self.cv2_exact:
+            cv2_crop_matrices(centers, scales, self.inp_res, out=pn[:n])
+        else:
+            pn[:n, :2] = centers
+            pn[:n, 2] = scales
         if n < bucket:
             pn[n:] = pn[0]                                 # padding crops repeat box 0 (their rows are dropped)
 
@@ -180,13 +229,44 @@ class PoseRunner:
         """The bucket's plan without the model's per-call bookkeeping: DeconvResnet.plan_for() re-derives device / dtype and
         sums the version counters of every parameter (~25 us; the whole host side of a submit is ~100 us and sits on the critical
         path of the tracking pass).  The runner keeps the plan and goes back to plan_for() when the model dropped its plans
-        (load_state_dict / .to() / refresh()) and on every 32nd call, which is when an in-place parameter edit is noticed."""
+        (load_state_dict / .to() / refresh() / an in-place parameter edit).  The version-counter check itself
+        (HipModule._check_fingerprint, ~20 us) and the eval-mode check run on EVERY submit (skipping them let up to
+        31 submits replay graphs built from edited weights); a changed fingerprint swaps net._plans, which the identity test
+        below sees."""
         self._calls += 1
+        if self._checks is None:                            # (stand-in nets of the tests implement plan_for / replay only)
+            self._checks = tuple(f for f in (getattr(self.net, "_check_eval", None), getattr(self.net, "_check_fingerprint", None)) if f)
+        for f in self._checks:
+            f()
         ent = self._plans.get(bucket)
-        if ent is None or ent[1] is not self.net._plans or (self._calls & 31) == 0:
+        if ent is None or ent[1] is not self.net._plans:
             plan = self.net.plan_for(bucket, self.inp_res[0], self.inp_res[1], self.replica)
             ent = self._plans[bucket] = (plan, self.net._plans)
         return ent[0]
+
+    def _crop(self, frame_ptr, H, W, C, params_ptr, n, x_ptr, sh):
+        """One crop launch: n boxes of one frame into the plan's input at x_ptr."""
+        if self.cv2_exact:
+            check(self.lib.ft_crop_affine_cv2_fwd(frame_ptr, H, W, C, params_ptr, n, self.inp_res[0], self.inp_res[1], self.mean_ptr,
+                                                  self.inv_std_ptr, self.pre, None, x_ptr, sh), "ft_crop_affine_cv2_fwd")
+        else:
+            check(self.lib.ft_crop_affine_fwd(frame_ptr, H, W, C, params_ptr, n, self.inp_res[0], self.inp_res[1], self.mean_ptr,
+                                              self.inv_std_ptr, self.pre, x_ptr, sh), "ft_crop_affine_fwd")
+
+    def close(self) -> None:
+        """Destroy the slots' events (ft_event_destroy) and drop the pinned buffers; the runner is unusable afterwards."""
+        for sl in self.slots.values():
+            if sl["pending"]:
+                self.lib.ft_event_synchronize(sl["event"])
+            self.lib.ft_event_destroy(sl["event"])
+        self.slots = {}
+        self._plans = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _launch(self, sl, plan, sh):
         """Plan replay + rows back into the pinned buffer + event, all through the C ABI on stream `sh`: a captured plan is one
@@ -215,16 +295,14 @@ class PoseRunner:
         bucket = next((b for b in self.BUCKETS if b >= n), None)
         if bucket is None:                                  # more boxes than the largest plan: chunks, each waited for in turn
             big = self.BUCKETS[-1]
-            return ("chunks", [self.result(self.submit(frame_dev, boxes[lo:lo + big])) for lo in range(0, n, big)])
+            return ("chunks", [PoseRunner.result(self, PoseRunner.submit(self, frame_dev, boxes[lo:lo + big])) for lo in range(0, n, big)])
         centers, scales = boxes_to_center_scale(boxes, self.inp_res)
         sl = self._slot(bucket)
         self._fill_params(sl, centers, scales, n, bucket)
         H, W, C = frame_dev.shape
         plan = self._plan(bucket)
         sh = self._stream_handle()
-        check(self.lib.ft_crop_affine_fwd(frame_dev.data_ptr(), H, W, C, sl["params_ptr"], bucket, self.inp_res[0],
-                                          self.inp_res[1], self.mean_ptr, self.inv_std_ptr, self.pre,
-                                          plan.x_static.data_ptr(), sh), "ft_crop_affine_fwd")
+        self._crop(frame_dev.data_ptr(), H, W, C, sl["params_ptr"], bucket, plan.x_static.data_ptr(), sh)
         self._launch(sl, plan, sh)
         return (sl, n, centers, scales, (plan.heatmaps.shape[2], plan.heatmaps.shape[3]))
 
@@ -234,18 +312,18 @@ class PoseRunner:
         plan's input.  result() returns the rows of all boxes in order."""
         if self.stream is not None and torch.cuda.current_stream(self.dev) != self.stream:
             with torch.cuda.stream(self.stream):
-                return self.submit_frames(frames_dev, boxes_list)
+                return PoseRunner.submit_frames(self, frames_dev, boxes_list)
         per = [np.asarray(b, dtype=np.float64).reshape(-1, 4) for b in boxes_list]
         total = sum(len(b) for b in per)
         if total == 0:
             return None
         bucket = next((b for b in self.BUCKETS if b >= total), None)
         if bucket is None:                                  # split the frame list in halves until each fits a plan
-            if len(per) == 1:
-                return self.submit(frames_dev[0], per[0])
+            if len(per) == 1:                               # (the base-class forms: GroupPoseRunner overrides submit / result)
+                return PoseRunner.submit(self, frames_dev[0], per[0])
             h = len(per) // 2
-            return ("chunks", [self.result(self.submit_frames(frames_dev[:h], per[:h])),
-                               self.result(self.submit_frames(frames_dev[h:], per[h:]))])
+            return ("chunks", [PoseRunner.result(self, PoseRunner.submit_frames(self, frames_dev[:h], per[:h])),
+                               PoseRunner.result(self, PoseRunner.submit_frames(self, frames_dev[h:], per[h:]))])
         allb = np.concatenate(per)
         centers, scales = boxes_to_center_scale(allb, self.inp_res)
         sl = self._slot(bucket)
@@ -260,9 +338,7 @@ class PoseRunner:
             if len(b) == 0:
                 continue
             H, W, C = frame.shape
-            check(self.lib.ft_crop_affine_fwd(frame.data_ptr(), H, W, C, sl["params_host"][lo:].data_ptr(), len(b), self.inp_res[0],
-                                              self.inp_res[1], self.mean_ptr, self.inv_std_ptr, self.pre,
-                                              x[lo:].data_ptr(), sh), "ft_crop_affine_fwd")
+            self._crop(frame.data_ptr(), H, W, C, sl["params_host"][lo:].data_ptr(), len(b), x[lo:].data_ptr(), sh)
             lo += len(b)
         self._launch(sl, plan, sh)
         return (sl, total, centers, scales, (plan.heatmaps.shape[2], plan.heatmaps.shape[3]))
@@ -291,8 +367,8 @@ class GroupPoseRunner(PoseRunner):
     Protocol per round: member submits (any subset of the members, each at most once) -> flush() -> ... -> results.  A
     result() of a round that was not flushed yet flushes it (a member alone behaves like a plain runner)."""
 
-    def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None):
-        super().__init__(net, inp_res, normalize, replica, stream)
+    def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None, cv2_exact: bool = False):
+        super().__init__(net, inp_res, normalize, replica, stream, cv2_exact)
         self._pending = []                                 # [frame_dev, boxes [n,4]] of the round being collected
         self._round = {"handle": None, "cuts": None}       # the collecting round; replaced at flush
 

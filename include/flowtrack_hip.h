@@ -457,6 +457,16 @@ int ft_crop_affine_fwd(const uint8_t* img, int H, int W, int C, const float* box
                        const float* mean, const float* inv_std, float pre_scale, float* out,
                        ft_stream_t stream);
 
+/* The same crop as cv2 RETURNS it for a uint8 frame, bit for bit (round 5): OpenCV's fixed-point INTER_LINEAR
+ * (imgwarp.cpp cv::warpAffine / WarpAffineInvoker / remapBilinear<FixedPtCast<int, uchar, 15>>; the third-party
+ * dependency behind lib/pose/utils/transforms.py:238).  minv: double[nb*6], per box the dst -> src 2x3 map that
+ * cv::warpAffine derives from the matrix it is handed (the caller inverts in double, cv2's operation order:
+ * tracking.net_utils.cv2_crop_matrices).  out_u8: NHWC uint8 [nb, rh, rw, C] = cv2's return value (may be NULL);
+ * out: NCHW fp32 [nb, C, rh, rw] = (float(u8) * pre_scale - mean[c]) * inv_std[c] (may be NULL; not both). */
+int ft_crop_affine_cv2_fwd(const uint8_t* img, int H, int W, int C, const double* minv, int nb, int rh, int rw,
+                           const float* mean, const float* inv_std, float pre_scale, uint8_t* out_u8, float* out,
+                           ft_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

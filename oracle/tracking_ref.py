@@ -3,7 +3,19 @@
 Independent CPU restatements for the tracking glue ("next" rows N1/N2):
   crop_affine_ref      the crop geometry of lib/pose/utils/transforms.py:173-184,231-240 (cv2.warpAffine with
                        t = get_transform(center, scale, res): inverse map, bilinear, constant-0 border), in
-                       float64 numpy.  cv2 is absent here and quantises weights to 1/32 px => UNPINNED.
+                       float64 numpy: the IDEAL bilinear crop (what `ft_crop_affine_fwd` computes in fp32).
+  warp_affine_cv2_ref  what the reference's `cv2.warpAffine(img_u8, t[:2], (w, h))` RETURNS for a uint8 frame: OpenCV's
+                       fixed-point INTER_LINEAR (round 5).  cv2 is a third-party dependency that is absent from this image
+                       and that the reference does not pin (no requirements file); restated from the published algorithm of
+                       OpenCV 2.4 ... 4.10, modules/imgproc/src/imgwarp.cpp: `cv::warpAffine` (matrix inversion in double),
+                       `WarpAffineInvoker::operator()` (AB_BITS = 10 fixed-point inverse map, round_delta, 1/32-px
+                       fractional index), `initInterTab2D` (the 32 x 32 table of 15-bit bilinear weights),
+                       `remapBilinear<FixedPtCast<int, uchar, 15>, ...>` ((sum + 2^14) >> 15, constant-0 border taps).
+                       OpenCV >= 4.11 is reported to route INTER_LINEAR through new floating-point SIMD kernels whose
+                       last bit can differ; the restatement is of the classic path.  No cv2 here => checked against
+                       hand-derived known answers only (tests/test_oracle_cpu.py): parity UNPINNED, integer-exact by
+                       construction.  `ft_crop_affine_cv2_fwd` must reproduce it BIT FOR BIT.
+  cv2_crop_matrix      get_transform (transforms.py:173-184, rot = 0) + the inversion of `cv::warpAffine`, in float64.
   nms_ref              literal loop restatement of lib/detection/nms/src/nms.c:33-64 (IoU >= thresh, +1 widths)
                        with the score-descending order of pth_nms.py:16.
   box_propagation_ref  intended semantics of lib/tracking/flow_utils.py:7-35, per person / per joint loops
@@ -41,6 +53,111 @@ def crop_affine_ref(img: np.ndarray, center, scale, res, mean=None, inv_std=None
     if inv_std is not None:
         out = out * np.asarray(inv_std)
     return out.transpose(2, 0, 1).astype(np.float32)
+
+
+# ---- OpenCV's uint8 warpAffine / INTER_LINEAR, restated (see the header) ---------------------------------------------
+INTER_BITS = 5                      # imgproc.hpp: INTER_BITS, INTER_TAB_SIZE = 32
+INTER_TAB_SIZE = 1 << INTER_BITS
+INTER_REMAP_COEF_BITS = 15          # imgproc.hpp: INTER_REMAP_COEF_SCALE = 1 << 15
+AB_BITS = 10                        # imgwarp.cpp WarpAffineInvoker: AB_BITS = MAX(10, INTER_BITS)
+
+
+def get_transform_ref(center, scale, res):
+    """lib/pose/utils/transforms.py:173-184 with factor = 1, rot = 0, delta = 0, same float64 operation order."""
+    t = np.eye(3)
+    res_ = res[0] * 1
+    t[0, 0] = res_ / scale
+    t[1, 1] = res_ / scale
+    t[0, 2] = -res_ * center[0] / scale + 0.5 * res[1] + 0
+    t[1, 2] = -res_ * center[1] / scale + 0.5 * res[0] + 0
+    return t
+
+
+def cv2_invert_affine(M):
+    """`cv::warpAffine` without WARP_INVERSE_MAP: the 2x3 matrix is inverted in double, in this operation order
+    (imgwarp.cpp, cv::warpAffine: `double D = M[0]*M[4] - M[1]*M[3]; D = D != 0 ? 1./D : 0; ...`)."""
+    M = [float(v) for v in np.asarray(M, dtype=np.float64).reshape(6)]
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11 = M[4] * D
+    A22 = M[0] * D
+    M[0] = A11
+    M[1] *= -D
+    M[3] *= -D
+    M[4] = A22
+    b1 = -M[0] * M[2] - M[1] * M[5]
+    b2 = -M[3] * M[2] - M[4] * M[5]
+    M[2] = b1
+    M[5] = b2
+    return np.asarray(M, dtype=np.float64)
+
+
+def cv2_crop_matrix(center, scale, res):
+    """The dst -> src map cv2 uses for the reference's crop: invert(get_transform(...)[:2]) -> float64[6]."""
+    return cv2_invert_affine(get_transform_ref(center, scale, res)[:2])
+
+
+def cv2_bilinear_tab():
+    """`initInterTab2D(INTER_LINEAR, fixpt = true)`: [1024][4] 15-bit integer weights (w00, w01, w10, w11) for the
+    fractional index fy * 32 + fx.  Every weight is (a / 32)(b / 32) * 2^15 = a * b * 32, exact; the only entry whose
+    rounding matters is (0, 0): 1.0 * 2^15 saturates to short 32767, the table's sum-to-2^15 fix-up then adds the
+    missing 1 to the largest weight it scans, which for the 2 x 2 kernel is the w11 slot (its scan starts at
+    [ksize/2][ksize/2] = [1][1]) -> (32767, 0, 0, 1).  For uint8 pixels both forms of that entry give the same
+    result (checked exhaustively in tests/test_oracle_cpu.py), so nothing below depends on this reading."""
+    tab = np.zeros((INTER_TAB_SIZE * INTER_TAB_SIZE, 4), dtype=np.int64)
+    for fy in range(INTER_TAB_SIZE):
+        for fx in range(INTER_TAB_SIZE):
+            tab[fy * INTER_TAB_SIZE + fx] = [(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32]
+    tab[0] = [32767, 0, 0, 1]
+    return tab
+
+
+def _cv_round(v):
+    """cvRound(double) = lrint: round half to even; out-of-range values give INT_MIN like cvtsd2si."""
+    r = np.rint(np.asarray(v, dtype=np.float64))
+    bad = ~(np.abs(r) < 2147483648.0)
+    return np.where(bad, -2147483648, np.where(bad, 0, r)).astype(np.int64)
+
+
+def _wrap32(v):
+    return ((np.asarray(v, dtype=np.int64) + 2147483648) & 0xFFFFFFFF) - 2147483648
+
+
+def warp_affine_cv2_ref(img: np.ndarray, Minv, dsize_hw, tab=None) -> np.ndarray:
+    """img [H,W,C] uint8, Minv = float64[6] dst -> src map (cv2_invert_affine of the matrix handed to cv2.warpAffine)
+    -> [h, w, C] uint8, INTER_LINEAR, BORDER_CONSTANT 0."""
+    assert img.dtype == np.uint8 and img.ndim == 3
+    H, W, C = img.shape
+    h, w = dsize_hw
+    M = np.asarray(Minv, dtype=np.float64).reshape(6)
+    AB_SCALE = float(1 << AB_BITS)
+    round_delta = (1 << AB_BITS) // INTER_TAB_SIZE // 2                  # 16
+    xs = np.arange(w, dtype=np.float64)
+    ys = np.arange(h, dtype=np.float64)
+    adelta = _cv_round(M[0] * xs * AB_SCALE)                              # WarpAffineInvoker: adelta[x], bdelta[x]
+    bdelta = _cv_round(M[3] * xs * AB_SCALE)
+    X0 = _wrap32(_cv_round((M[1] * ys + M[2]) * AB_SCALE) + round_delta)  # per row
+    Y0 = _wrap32(_cv_round((M[4] * ys + M[5]) * AB_SCALE) + round_delta)
+    X = _wrap32(X0[:, None] + adelta[None, :]) >> (AB_BITS - INTER_BITS)
+    Y = _wrap32(Y0[:, None] + bdelta[None, :]) >> (AB_BITS - INTER_BITS)
+    sx = np.clip(X >> INTER_BITS, -32768, 32767)                          # saturate_cast<short>
+    sy = np.clip(Y >> INTER_BITS, -32768, 32767)
+    fxy = (Y & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (X & (INTER_TAB_SIZE - 1))
+    wt = (cv2_bilinear_tab() if tab is None else tab)[fxy]               # [h, w, 4]
+    f = img.astype(np.int64)
+
+    def tap(yy, xx):                                                      # remapBilinear, BORDER_CONSTANT: cval = 0
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        return np.where(ok[..., None], f[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], 0)
+    acc = tap(sy, sx) * wt[..., 0:1] + tap(sy, sx + 1) * wt[..., 1:2] + tap(sy + 1, sx) * wt[..., 2:3] + tap(sy + 1, sx + 1) * wt[..., 3:4]
+    out = (acc + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS  # FixedPtCast<int, uchar, 15>
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def crop_cv2_ref(img: np.ndarray, center, scale, res) -> np.ndarray:
+    """`transform_image(img, center, scale, res)` of the reference for a uint8 HWC frame -> [C, h, w] uint8
+    (transforms.py:231-240: warpAffine, then HWC -> CHW)."""
+    return warp_affine_cv2_ref(img, cv2_crop_matrix(center, scale, res), res).transpose(2, 0, 1)
 
 
 def nms_ref(dets: np.ndarray, thresh: float):

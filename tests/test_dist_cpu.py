@@ -64,6 +64,16 @@ def _gather_worker(rank, world, port, q):
             got = g.finish(h)
             want = torch.cat([torch.full((3, 17, 3), float(100 * st + r)) for r in range(world)])
             ok = ok and torch.equal(got, want)
+    # the bench line's `rccl` evidence (bench.py, N > 1): every rank's stamped block arrives on every rank; and it DETECTS a
+    # gather that did not move a rank's rows (a gatherer whose exchange is replaced by a local copy verifies < world ranks)
+    ev = parallel.verify_gather(g, rank)
+    ok = ok and ev == {"world": world, "ranks_verified": world, "backend": "gloo", "bytes_per_rank": 3 * 17 * 3 * 4}
+    broken = parallel.RowGatherer(3, (17, 3), torch.float32, "cpu", depth=2)
+    broken._exchange = lambda k: broken.recv[k][:3].copy_(broken.send[k]) if rank == 0 else dist.barrier  # noqa: E731 (rank 0's block only)
+    broken.recv[0].zero_(); broken.recv[1].zero_()
+    ok = ok and parallel.verify_gather(broken, rank)["ranks_verified"] < world
+    # --config c3 (BASELINE configs[2]): 128 crops split over the ranks, equal contiguous shards
+    ok = ok and parallel.shard_range(128, rank, world) == (rank * 128 // world, (rank + 1) * 128 // world)
     parallel.barrier()
     q.put((rank, ok))
     dist.destroy_process_group()

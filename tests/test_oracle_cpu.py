@@ -232,3 +232,70 @@ def test_remaining_evaluation_helpers_match_reference_golden():
     assert np.allclose(ev.compute_pck(g["pck_pred"], g["pck_anno"], g["pck_scale"], 0.5), g["pck"])
     acc, avg, cnt, pred = ev.accuracy(torch.from_numpy(g["acc_out"]), torch.from_numpy(g["acc_tgt"]))
     assert np.allclose(acc, g["acc"]) and abs(avg - float(g["acc_avg"])) < 1e-12 and cnt == int(g["acc_cnt"])
+
+
+# ---- N2: OpenCV's uint8 warpAffine, restated (oracle/tracking_ref.py::warp_affine_cv2_ref) ---------------------------------
+def test_cv2_warp_restatement_known_answers():
+    """Hand-derived expectations of OpenCV's fixed-point INTER_LINEAR (no cv2 in this image: these pin the restatement's
+    rounding, border and table behaviour, not cv2 itself).  Half-pixel taps have weight 2^14 each: (a + b + 1) >> 1;
+    a quarter pixel is 3/4 : 1/4 -> (3a + b + 2) >> 2; integer shifts and the identity copy pixels; outside = 0."""
+    from oracle import tracking_ref as T
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    ident = T.warp_affine_cv2_ref(img, T.cv2_invert_affine([1, 0, 0, 0, 1, 0]), (23, 31))
+    assert np.array_equal(ident, img)
+    sh = T.warp_affine_cv2_ref(img, T.cv2_invert_affine([1, 0, 3, 0, 1, 2]), (23, 31))       # dst(x, y) = src(x - 3, y - 2)
+    assert np.array_equal(sh[2:, 3:], img[:-2, :-3]) and not sh[:2].any() and not sh[:, :3].any()
+    a, b = img[:, :-1].astype(int), img[:, 1:].astype(int)
+    half = T.warp_affine_cv2_ref(img, T.cv2_invert_affine([1, 0, 0.5, 0, 1, 0]), (23, 31))   # src x = x - 0.5
+    assert np.array_equal(half[:, 1:], (a + b + 1) >> 1)
+    assert np.array_equal(half[:, 0], (img[:, 0].astype(int) + 1) >> 1)                       # left tap outside: constant 0
+    quarter = T.warp_affine_cv2_ref(img, T.cv2_invert_affine([1, 0, 0.75, 0, 1, 0]), (23, 31))  # src x = x - 0.75: 1/4 left... 3/4 : 1/4
+    assert np.array_equal(quarter[:, 1:], (3 * a + b + 2) >> 2)
+    up = T.warp_affine_cv2_ref(img, T.cv2_invert_affine([2, 0, 0, 0, 2, 0]), (46, 62))       # x2 zoom: src = dst / 2
+    assert np.array_equal(up[::2, ::2], img)
+    assert np.array_equal(up[::2, 1:-1:2], (a + b + 1) >> 1)
+    both = (img[:-1, :-1].astype(int) + img[:-1, 1:] + img[1:, :-1] + img[1:, 1:] + 2) >> 2    # four taps of 2^13
+    assert np.array_equal(up[1:-1:2, 1:-1:2], both)
+    # the snap to 1/32 px: 1/64 px to the right of an integer position rounds half up to the next 1/32 step (round_delta = 16)
+    eps = T.warp_affine_cv2_ref(img, T.cv2_invert_affine([1, 0, -1.0 / 64, 0, 1, 0]), (23, 31))
+    assert np.array_equal(eps[:, :-1], (31 * a + b + 16) >> 5)
+    # far outside the frame and a degenerate (singular) matrix: constant border / src pixel (0, 0) everywhere
+    assert not T.warp_affine_cv2_ref(img, T.cv2_invert_affine([1, 0, 500, 0, 1, 500]), (8, 8)).any()
+    assert np.array_equal(T.warp_affine_cv2_ref(img, T.cv2_invert_affine([0, 0, 0, 0, 0, 0]), (4, 4)), np.broadcast_to(img[0, 0], (4, 4, 3)))
+
+
+def test_cv2_weight_table_entry_00_is_immaterial_for_uint8():
+    """initInterTab2D's entry for (fx, fy) = (0, 0) is (32767, 0, 0, 1) after short saturation + sum fix-up; for uint8 taps it
+    gives what the ideal (32768, 0, 0, 0) gives, for every pair of values — the restatement does not hinge on that reading."""
+    s00, s11 = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    assert np.array_equal((s00 * 32767 + s11 + (1 << 14)) >> 15, (s00 * 32768 + (1 << 14)) >> 15)
+    from oracle import tracking_ref as T
+    tab = T.cv2_bilinear_tab()
+    assert (tab.sum(1) == 1 << 15).all() and tab.min() >= 0 and tab.max() <= 32767
+    ideal = tab.copy()
+    ideal[0] = [32768, 0, 0, 0]
+    img = np.random.default_rng(2).integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    M = T.cv2_crop_matrix((20.0, 20.0), 32.0, (32, 24))       # scale == crop height: every source coordinate is an integer
+    assert np.array_equal(T.warp_affine_cv2_ref(img, M, (32, 24)), T.warp_affine_cv2_ref(img, M, (32, 24), tab=ideal))
+
+
+def test_cv2_crop_is_the_ideal_bilinear_crop_up_to_its_quantisation():
+    """The uint8 crop vs the float64 bilinear crop of the same geometry: at most half a grey level of output rounding plus the
+    effect of the 1/32-px coordinate snap (|d src| <= 1/64 + 2^-11 px per axis times the local gradient).  On a smooth image the
+    two agree to ~0.6 grey levels; and the host-side matrices (tracking.net_utils.cv2_crop_matrices) are the oracle's bit for bit."""
+    from oracle import tracking_ref as T
+    from flowtrack.pytorch_amd.tracking import net_utils
+    yy, xx = np.meshgrid(np.arange(120), np.arange(160), indexing="ij")
+    smooth = np.stack([(127 + 100 * np.sin(xx / 17.0) * np.cos(yy / 13.0)), (xx + yy) * 0.9, 255 - xx * 1.5], -1).clip(0, 255).astype(np.uint8)
+    centers = np.array([[80.0, 60.0], [5.3, 10.7], [150.5, 110.25], [33.333, 71.1]])
+    scales = np.array([100.0, 64.0, 300.0, 47.7])
+    Ms = net_utils.cv2_crop_matrices(centers, scales, (64, 48))
+    for i in range(4):
+        assert np.array_equal(Ms[i], T.cv2_crop_matrix(centers[i], scales[i], (64, 48)))
+        got = T.crop_cv2_ref(smooth, centers[i], scales[i], (64, 48)).astype(np.float64)
+        ideal = T.crop_affine_ref(smooth, centers[i], scales[i], (64, 48)).astype(np.float64)
+        ys, xs = np.meshgrid(np.arange(64), np.arange(48), indexing="ij")       # away from the frame's edge (a 255-level step
+        sx, sy = Ms[i][0] * xs + Ms[i][2], Ms[i][4] * ys + Ms[i][5]             # there turns the 1/64-px snap into 4 levels)
+        inside = (sx >= 1) & (sx <= 158) & (sy >= 1) & (sy <= 118)
+        assert inside.sum() > 500 and np.abs(got - ideal)[:, inside].max() <= 1.6, (i, np.abs(got - ideal)[:, inside].max())

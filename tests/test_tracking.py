@@ -153,6 +153,115 @@ def test_crop_kernel_matches_oracle(hip_lib):
 
 
 @pytest.mark.gpu
+def test_crop_cv2_exact_kernel_is_bit_exact(hip_lib):
+    """ft_crop_affine_cv2_fwd == OpenCV's uint8 warpAffine as restated in oracle/tracking_ref.py::warp_affine_cv2_ref, BIT FOR
+    BIT (integer work): boxes inside, across and beyond the frame's edges, up- and down-scaling, 1 / 3 / 4 channels, and
+    general (rotated / sheared) matrices through the C ABI; the fp32 output is the normalised uint8 value."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    lib = hip_lib
+    for (H, W, C) in ((120, 160, 3), (67, 45, 1), (90, 130, 4)):
+        img = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+        dev = torch.from_numpy(img).cuda()
+        centers = np.concatenate((rng.uniform(-20, [W + 20, H + 20], (12, 2)), [[W / 2, H / 2], [0.0, 0.0], [W - 1.0, H - 1.0], [-500.0, -500.0]]))
+        scales = np.concatenate((rng.uniform(8, 400, 12), [64.0, 64.0, 1000.0, 64.0]))
+        if C == 3:
+            f32, u8 = net_utils.crop_boxes(dev, centers, scales, (64, 48), normalize=True, cv2_exact=True, return_u8=True)
+            f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
+        else:
+            minv = torch.from_numpy(net_utils.cv2_crop_matrices(centers, scales, (64, 48))).cuda()
+            u8t = torch.empty((len(scales), 64, 48, C), dtype=torch.uint8, device="cuda")
+            assert lib.ft_crop_affine_cv2_fwd(dev.data_ptr(), H, W, C, minv.data_ptr(), len(scales), 64, 48, None, None, ctypes.c_float(1.0),
+                                              u8t.data_ptr(), None, None) == 0
+            torch.cuda.synchronize()
+            u8 = u8t.cpu().numpy()
+        for i in range(len(scales)):
+            want = tracking_ref.crop_cv2_ref(img, centers[i], scales[i], (64, 48))               # [C, h, w] uint8
+            assert np.array_equal(u8[i].transpose(2, 0, 1), want), (H, W, C, i)
+            if C == 3:
+                norm = (want.astype(np.float32) * np.float32(1 / 255.0) - np.asarray(net_utils.BGR_MEAN, np.float32)[:, None, None]) \
+                    * (1 / np.asarray(net_utils.BGR_STD, np.float32))[:, None, None]
+                assert np.abs(f32[i] - norm).max() <= 2e-6
+        assert not u8[-1].any()
+    # general 2x3 matrices (rotation + shear + zoom), handed over as cv2 would invert them
+    img = rng.integers(0, 256, (80, 100, 3), dtype=np.uint8)
+    dev = torch.from_numpy(img).cuda()
+    mats = []
+    for k in range(6):
+        th = rng.uniform(-np.pi, np.pi)
+        z = rng.uniform(0.3, 3.0)
+        mats.append(tracking_ref.cv2_invert_affine([z * np.cos(th), -z * np.sin(th) + 0.1, rng.uniform(-30, 60), z * np.sin(th), z * np.cos(th), rng.uniform(-30, 60)]))
+    minv = torch.from_numpy(np.stack(mats)).cuda()
+    u8t = torch.empty((6, 50, 70, 3), dtype=torch.uint8, device="cuda")
+    assert lib.ft_crop_affine_cv2_fwd(dev.data_ptr(), 80, 100, 3, minv.data_ptr(), 6, 50, 70, None, None, ctypes.c_float(1.0), u8t.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    for k in range(6):
+        assert np.array_equal(u8t[k].cpu().numpy(), tracking_ref.warp_affine_cv2_ref(img, mats[k], (50, 70))), k
+    assert lib.ft_crop_affine_cv2_fwd(dev.data_ptr(), 80, 100, 3, minv.data_ptr(), 6, 50, 70, None, None, ctypes.c_float(1.0), None, None, None) != 0
+
+
+@pytest.mark.gpu
+def test_pose_runner_cv2_exact_crops_feed_the_net_and_keypoints_agree(hip_lib):
+    """PoseRunner(cv2_exact=True): the plan's input is the normalised cv2-exact uint8 crop (bit for bit the values crop_boxes
+    gives), and — the condition for keeping the fp32 crop as the fast default — the key points of the two crop forms agree to a
+    small fraction of a heat-map pixel on a smooth frame (the two crops differ by <= ~0.6 grey levels there)."""
+    from flowtrack.pytorch_amd.pose import models as pose_models
+    from flowtrack.pytorch_amd.tracking import PoseRunner
+    dev = torch.device("cuda", 0)
+    net = pose_models.deconv("resnet50", num_classes=17, pretrained=False)
+    net.load_state_dict(synth.fill_pose_state_dict(net.state_dict(), 3))
+    net = net.to(dev).eval()
+    net.compute_dtype = torch.float32
+    yy, xx = np.meshgrid(np.arange(384), np.arange(512), indexing="ij")
+    frame_np = np.stack([127 + 100 * np.sin(xx / 37.0) * np.cos(yy / 29.0), (xx + yy) * 0.28, 255 - xx * 0.45], -1).clip(0, 255).astype(np.uint8)
+    frame = torch.from_numpy(frame_np).to(dev)
+    boxes = np.array([[30, 40, 130, 300], [200, 10, 330, 380], [400, 100, 500, 250], [5, 5, 60, 90], [250, 200, 300, 260]], dtype=np.float64)
+    exact, fast = PoseRunner(net, cv2_exact=True), PoseRunner(net)
+    h = exact.submit(frame, boxes)
+    kp_exact = exact.result(h)
+    centers, scales = net_utils.boxes_to_center_scale(boxes)
+    want_x = net_utils.crop_boxes(frame, centers, scales, cv2_exact=True)
+    plan = net.plan_for(8, 256, 192)
+    assert torch.equal(plan.x_static[:5], want_x)
+    u8 = net_utils.crop_boxes(frame, centers, scales, return_u8=True)[1].cpu().numpy()
+    assert np.array_equal(u8[1].transpose(2, 0, 1), tracking_ref.crop_cv2_ref(frame_np, centers[1], scales[1], (256, 192)))
+    kp_fast = fast(frame, boxes)
+    hm_px = (scales / 64.0)[:, None]                                            # one heat-map pixel in image pixels, per box
+    d = np.abs(kp_exact[..., :2] - kp_fast[..., :2]).max(-1) / hm_px
+    assert np.median(d) <= 0.26 and np.isfinite(kp_exact).all(), (np.median(d), d.max())
+    exact.close()
+    fast.close()
+    assert exact.slots == {} and fast.slots == {}
+
+
+@pytest.mark.gpu
+def test_group_runner_more_boxes_than_the_largest_bucket(hip_lib):
+    """the > largest-bucket fallbacks of submit / submit_frames must use the BASE-class submit / result — in a
+    GroupPoseRunner the overridden submit() only collects.  257 boxes of one frame (and 5 + 6 over two frames with tiny buckets)
+    through a group runner == the plain runner's rows."""
+    from flowtrack.pytorch_amd.pose import models as pose_models
+    from flowtrack.pytorch_amd.tracking import GroupPoseRunner, PoseRunner
+    dev = torch.device("cuda", 0)
+    net = pose_models.deconv("resnet50", num_classes=17, pretrained=False)
+    net.load_state_dict(synth.fill_pose_state_dict(net.state_dict(), 3))
+    net = net.to(dev).eval()
+    net.compute_dtype = torch.float16
+    frame = torch.from_numpy((synth.uniform01(6, "frame", (384, 512, 3)) * 255).astype(np.uint8)).to(dev)
+    base = np.array([[30, 40, 130, 300], [200, 10, 330, 380], [400, 100, 500, 250], [5, 5, 60, 90], [250, 200, 300, 260]], dtype=np.float64)
+    grp, ref = GroupPoseRunner(net, replica=1, stream=torch.cuda.Stream(device=dev)), PoseRunner(net)
+    grp.BUCKETS = ref.BUCKETS = (4, 8)
+    many = np.concatenate([base + k for k in range(4)])[:17]                    # 17 > 8: chunks of 8, 8, 1
+    h = grp.submit(frame, many)
+    grp.flush()
+    got = grp.result(h)
+    want = ref(frame, many)
+    assert got.shape == (17, 17, 3) and np.array_equal(got, want)
+    h1, h2 = grp.submit(frame, base), grp.submit(frame, (base + 3.0)[:4])        # 9 boxes over two members: split by frame list
+    r1, r2 = grp.result(h1), grp.result(h2)
+    assert np.array_equal(r1, ref(frame, base)) and np.array_equal(r2, ref(frame, (base + 3.0)[:4]))
+
+
+@pytest.mark.gpu
 def test_clip_pipeline_runs_and_tracks(hip_lib):
     """End-to-end plumbing of the video pipeline (synthetic weights: geometry is checked, not pose quality)."""
     import types

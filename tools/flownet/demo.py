@@ -84,6 +84,11 @@ def main(argv=None):
     os.makedirs(args.save, exist_ok=True)
     if args.number_gpus < 1:
         raise SystemExit('the HIP path needs a GPU (--number_gpus >= 1)')
+    if args.number_gpus > 1:
+        # the reference wraps the model in nn.DataParallel (tools/flownet/demo.py:75), which scatters dim 0: a one-pair batch
+        # runs on GPU 0 there as well.  Here multi-GPU is one process per GPU (torchrun + bench.py / parallel.py).
+        print('[demo] --number_gpus %d: one frame pair cannot be sharded, it runs on GPU 0 (as under the reference\'s '
+              'DataParallel); batches shard one process per GPU via torchrun, see bench.py' % args.number_gpus, file=sys.stderr)
     model = model.cuda()
     if args.fp16:
         model = model.half()

@@ -248,6 +248,8 @@ def run_clip(frames, dets, pose_net, flow_net, rank=0, world=1, thresh=0.3, flow
         pose_boxes = lambda t, boxes: pose_fn(fr[t], boxes)  # noqa: E731
     out = tracking_pass(dets, [kp_all[t, :len(dets[t])] for t in range(T)], flows_np, pose_boxes, thresh, max_boxes)
     tm["track_s"] = time.perf_counter() - t0
+    if runner is not None:
+        runner.close()
     return out, tm
 
 
@@ -380,6 +382,8 @@ def run_clips(clips, pose_net, flow_net, thresh=0.3, flow_batch=16, pose_frames=
                 group_runners[g].flush()                     # (first-frame submits of the clips staged above)
     _sync(dev)
     tm["wall_s"] = time.perf_counter() - t0
+    for r in [shared] + group_runners:                       # slot events / pinned buffers (they leaked per call)
+        r.close()
     return results, tm
 
 
