@@ -94,7 +94,7 @@ def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int
 # --------------------------------------------------------------------------------------------
 def is_conv_call(name: str) -> bool:
     """Launches whose work is convolution MACs (the roofline's kernels): ft_conv2d_fwd[_ws] and ft_bottleneck_fwd."""
-    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd", "ft_conv_direct_fwd")
+    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd", "ft_bottleneck_cluster_fwd", "ft_conv_direct_fwd")
 
 
 def _on_plan_device(fn):
@@ -1154,8 +1154,38 @@ def record_bottleneck_entry(prog: Program, c1: "FusedConv", c2: "FusedConv", sc:
              y.t.data_ptr(), keep=(d, x.t, y.t, w1, w2, w3, table))
 
 
+def bottleneck_cluster_supported(x: ActView, y: ActView, planes: int) -> bool:
+    """True when ft_bottleneck_cluster_fwd covers this identity block (fp16, 256 planes, a whole map of <= 192 pixels per
+    cluster of four workgroups: layer3 of the ResNets at 256 x 192)."""
+    if x.t.dtype != torch.float16 or x.rowpacked or not FUSE_BOTTLENECK_STREAM:
+        return False
+    d = _bottleneck_desc(x, y, planes)
+    return _lib.load().ft_bottleneck_cluster_supported(ctypes.byref(d)) == 0
+
+
+def _bottleneck_stream_operands(c1: "FusedConv", d, x: ActView, planes: int, p1, p2, p3):
+    """(weight stream, folded-BN tables) of ft_bottleneck_stream_fwd / ft_bottleneck_cluster_fwd, built once per weight set."""
+    lib = _lib.load()
+    (w1, s1, b1), (w2, s2, b2), (w3, s3, b3) = p1, p2, p3
+    key = ("bns_stream", x.N, x.H, x.W)
+    cached = c1._packed.get(key) if hasattr(c1, "_packed") else None
+    if cached is None:
+        nbytes = int(lib.ft_bottleneck_stream_weight_bytes(ctypes.byref(d)))
+        wstream = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
+        check(lib.ft_bottleneck_stream_pack(ctypes.byref(d), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), wstream.data_ptr(),
+                                            current_stream_handle(x.t.device)), "ft_bottleneck_stream_pack")
+        torch.cuda.current_stream(x.t.device).synchronize()     # plan-build time: the plan may replay on another stream
+        P = planes
+        tables = torch.cat([s1.flatten()[:P], b1.flatten()[:P], s2.flatten()[:P], b2.flatten()[:P]] +
+                           [t.flatten()[q * P:(q + 1) * P] for q in range(4) for t in (s3, b3)]).float().contiguous()
+        cached = (wstream, tables)
+        if hasattr(c1, "_packed"):
+            c1._packed[key] = cached
+    return cached
+
+
 def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
-                      label: str) -> None:
+                      label: str, cluster: bool = False) -> None:
     """conv1 + bn1 + relu -> conv2 + bn2 + relu -> conv3 + bn3 + residual(x) + relu as ONE launch (ft_bottleneck_fwd);
     the packed weights / folded BN are those the three FusedConv layers would use on channel-aligned views."""
     lib = _lib.load()
@@ -1171,23 +1201,22 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
         # 128 / 256 planes: the streamed-weights kernel; its weight stream is built once per weight set by the library
         check(lib.ft_bottleneck_stream_supported(ctypes.byref(d)), "ft_bottleneck_stream_supported")
         flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
-        key = ("bns_stream", x.N, x.H, x.W)
-        cached = c1._packed.get(key) if hasattr(c1, "_packed") else None
-        if cached is None:
-            nbytes = int(lib.ft_bottleneck_stream_weight_bytes(ctypes.byref(d)))
-            wstream = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
-            check(lib.ft_bottleneck_stream_pack(ctypes.byref(d), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), wstream.data_ptr(),
-                                                current_stream_handle(x.t.device)), "ft_bottleneck_stream_pack")
-            torch.cuda.current_stream(x.t.device).synchronize()     # plan-build time: the plan may replay on another stream
-            P = planes
-            tables = torch.cat([s1.flatten()[:P], b1.flatten()[:P], s2.flatten()[:P], b2.flatten()[:P]] +
-                               [t.flatten()[q * P:(q + 1) * P] for q in range(4) for t in (s3, b3)]).float().contiguous()
-            cached = (wstream, tables)
-            if hasattr(c1, "_packed"):
-                c1._packed[key] = cached
-        wstream, tables = cached
+        wstream, tables = _bottleneck_stream_operands(c1, d, x, planes, (w1, s1, b1), (w2, s2, b2), (w3, s3, b3))
         prog.flops += flops
         prog.fused_records.append((label, len(prog.calls), flops))
+        if cluster:
+            # the CLUSTER form (csrc/bottleneck_cluster.hip): four workgroups per image exchange t1 / t2 inside the launch;
+            # same weight stream and tables.  Its workspace (exchange buffers + the clusters' monotonic arrival counters, zeroed
+            # ONCE) is shared by every cluster block of the plan: the launches of a plan are serialised on its stream.
+            check(lib.ft_bottleneck_cluster_supported(ctypes.byref(d)), "ft_bottleneck_cluster_supported")
+            nbytes = int(lib.ft_bottleneck_cluster_workspace_bytes(ctypes.byref(d)))
+            pool = prog.__dict__.setdefault("_cluster_ws", {})
+            ws = pool.get((x.N, x.H, x.W))
+            if ws is None or ws.numel() < nbytes:
+                ws = pool[(x.N, x.H, x.W)] = torch.zeros(nbytes, dtype=torch.uint8, device=x.t.device)
+            prog.add("ft_bottleneck_cluster_fwd", ctypes.byref(d), x.t.data_ptr(), wstream.data_ptr(), tables.data_ptr(), y.t.data_ptr(),
+                     ws.data_ptr(), keep=(d, x.t, y.t, wstream, tables, ws))
+            return
         prog.add("ft_bottleneck_stream_fwd", ctypes.byref(d), x.t.data_ptr(), wstream.data_ptr(), tables.data_ptr(), y.t.data_ptr(),
                  keep=(d, x.t, y.t, wstream, tables))
         return

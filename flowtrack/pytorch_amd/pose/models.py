@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ..engine import HipModule
 from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable,
-                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_head_stream_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head, record_bottleneck_head_stream,
+                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_cluster_supported, bottleneck_head_stream_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head, record_bottleneck_head_stream,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -271,6 +271,10 @@ class DeconvResnet(HipModule):
             forms = (("fused", fused_form), ("convs", conv_form))
             if not bottleneck_prefers_fused(cur, planes):
                 forms = forms[::-1]
+            if self.cluster_kernels and bottleneck_cluster_supported(cur, out, planes):
+                # round 5: the same block shared by a cluster of four workgroups per image (t1 / t2 exchanged inside the
+                # launch): a third recorded form, kept where the first-call benchmark measures it faster
+                forms = forms + (("cluster", lambda: record_bottleneck(prog, c1, c2, c3, cur, out, name + ".cluster", cluster=True)),)
             prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
             for form_name, form in forms:
                 prog.option(form_name)
@@ -325,6 +329,11 @@ class DeconvResnet(HipModule):
         if whole:
             prog.end_choice()
 
+
+    #: offer the cluster form of the 256-plane identity blocks (ft_bottleneck_cluster_fwd) to the first-call benchmark.  Its
+    #: workgroups wait for each other inside the launch; set False for plans whose launches may share the GPU with another
+    #: stream's cluster launches for long stretches (nothing deadlocks — spins are bounded — but a timed-out hand-off is wrong)
+    cluster_kernels: bool = os.environ.get("FT_CLUSTER_KERNELS", "1") != "0"
 
     def plan_for(self, B: int, H: int, W: int, replica: int = 0) -> _PosePlan:
         """The plan (launch list + activation buffers + graph) of one input shape.  `replica` > 0 gives an independent copy

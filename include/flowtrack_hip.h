@@ -282,6 +282,20 @@ int ft_bottleneck_stream_pack(const ft_bottleneck_desc* d, const void* w1, const
 int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
                              ft_stream_t stream);
 
+/* CLUSTER form of the same block for the 256-plane stage on maps of <= 192 pixels (fp16, P = 256, C = 1024, stride 1;
+ * layer3.1+ of the ResNets at 256 x 192; csrc/bottleneck_cluster.hip, round 5): the work of one image is shared by four
+ * workgroups that exchange t1 / t2 through `workspace` INSIDE the launch (agent-scope hand-off, bounded spins), so a CU
+ * streams about half the weight bytes of the strip form and no MFMA tile is padded.  Same wstream / tables as
+ * ft_bottleneck_stream_fwd.  workspace: ft_bottleneck_cluster_workspace_bytes(d) bytes, ZEROED ONCE by the caller and
+ * then left alone (it holds monotonic per-cluster arrival counters across calls); one workspace must not be used by two
+ * launches that may run concurrently.  The 32-bit word at ft_bottleneck_cluster_status_offset(d) becomes non-zero if a
+ * hand-off ever timed out (a member was not resident in time: the output of that call is wrong). */
+int ft_bottleneck_cluster_supported(const ft_bottleneck_desc* d);
+long long ft_bottleneck_cluster_workspace_bytes(const ft_bottleneck_desc* d);
+long long ft_bottleneck_cluster_status_offset(const ft_bottleneck_desc* d);
+int ft_bottleneck_cluster_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
+                              void* workspace, ft_stream_t stream);
+
 /* ---- layout / pooling helpers -------------------------------------------- */
 /* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,wpitch,cpad]: pixel x lands in column lpad + x, channels
  * >= C and all other columns are zeroed (wpitch = W, lpad = 0: plain NHWC; cpad multiple of 4).

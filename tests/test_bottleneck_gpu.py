@@ -161,6 +161,94 @@ def test_stream_256_variants_match_oracle_and_each_other(hip_lib, case, variant,
         assert (diff > 0).float().mean().item() < 0.05, "the two forms should agree bit for bit almost everywhere"
 
 
+CLUSTER_CASES = [
+    ("c256_r50_16x12", 5, 16, 12, 1024, 0, 256),          # layer3 of R50 at 256 x 192: 4 rows per member, six full pixel tiles
+    ("c256_r50_b64", 64, 16, 12, 1024, 0, 256),           # the benchmarked batch: 256 workgroups = one per CU
+    ("c256_recycle_b100", 100, 16, 12, 1024, 0, 256),     # 416 workgroups: clusters of the second round start as slots free up
+    ("c256_view_offset_10x7", 3, 10, 7, 1056, 32, 256),   # ragged rows (3 + 3 + 3 + 1), 70 pixels, input a channel slice
+    ("c256_tiny_6x3", 1, 6, 3, 1024, 0, 256),             # two rows per member: member 3 owns none
+    ("c256_12x15", 9, 12, 15, 1024, 0, 256),              # 180 pixels: last tile ragged, widest supported row
+]
+
+
+@pytest.mark.parametrize("case", CLUSTER_CASES, ids=[c[0] for c in CLUSTER_CASES])
+def test_cluster_256_matches_oracle_and_the_strip_form(hip_lib, case):
+    """ft_bottleneck_cluster_fwd (four workgroups per image, t1 / t2 exchanged through global memory inside the launch) vs the
+    CPU oracle and vs ft_bottleneck_stream_fwd on the same weight stream: same fp16 roundings of t1 / t2, only the fp32
+    summation order of conv2 differs (its K halves meet in LDS).  Five runs with poisoned outputs and exchange buffers in
+    between: the hand-off must never read a stale line; the workspace's status word must stay 0 (no spin timed out)."""
+    import ctypes
+    from flowtrack.pytorch_amd import _lib
+    from flowtrack.pytorch_amd.hip_ops import _bottleneck_desc, bottleneck_cluster_supported
+    name, N, H, W, xcs, xoff, P = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 29
+    C = 4 * P
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+    t2 = F.relu(_bnf(F.conv2d(t1, w2, padding=1), bn2))
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + x)
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    c3 = FusedConv(w3, bn=bn3, label="conv3", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    if xoff:
+        xv.t[..., :xoff] = 7.0
+    y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
+    assert bottleneck_cluster_supported(xv, y, P)
+    prog = make_program()
+    record_bottleneck(prog, c1, c2, c3, xv, y, name, cluster=True)
+    assert prog.calls[0][0] == "ft_bottleneck_cluster_fwd"
+    run_program(prog)
+    got = view_to_nchw(y)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: cluster form vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    assert torch.all(y.t[..., :32] == 3.0), "channels outside the output slice were written"
+    ws = prog._cluster_ws[(N, H, W)]
+    d = _bottleneck_desc(xv, y, P)
+    soff = int(_lib.load().ft_bottleneck_cluster_status_offset(ctypes.byref(d)))
+    for k in range(5):
+        y.t.fill_(5.0)
+        ws[:soff - 64 * ((N + 7) // 8 * 8)].fill_(0x3C)       # poison the exchange buffers (not the counters)
+        run_program(prog)
+        assert torch.equal(view_to_nchw(y), got), f"{name}: run {k + 2} differs from the first"
+    assert int(ws[soff:soff + 4].view(torch.int32).item()) == 0, "a cluster hand-off timed out"
+    ys = ActView(torch.zeros((N, H, W, C), dtype=dtype, device=dev), C, 0)
+    prog_s = make_program()
+    record_bottleneck(prog_s, c1, c2, c3, xv, ys, name)
+    assert prog_s.calls[0][0] == "ft_bottleneck_stream_fwd"
+    run_program(prog_s)
+    diff = (got - view_to_nchw(ys)).abs()
+    assert diff.max().item() <= 1e-2 * scale, f"{name}: cluster vs strip form max abs diff {diff.max().item():.3e}"
+    assert (diff > 0).float().mean().item() < 0.05, "the two forms should agree bit for bit almost everywhere"
+
+
+def test_cluster_rejects_other_shapes(hip_lib):
+    import ctypes
+    from flowtrack.pytorch_amd import _lib
+    lib = _lib.load()
+
+    def desc(N=2, H=16, W=12, C=1024, P=256, dtype=torch.float16, **kw):
+        d = _lib.BottleneckDesc()
+        d.dtype = _lib.dtype_code(dtype)
+        d.N, d.H, d.W, d.C, d.P = N, H, W, C, P
+        d.x_cstride, d.x_coff, d.y_cstride, d.y_coff = C, 0, C, 0
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    assert lib.ft_bottleneck_cluster_supported(ctypes.byref(desc())) == 0
+    assert lib.ft_bottleneck_cluster_workspace_bytes(ctypes.byref(desc())) > 2 * 2 * 192 * 512
+    for bad in (desc(H=24, W=18), desc(P=128, C=512), desc(dtype=torch.float32), desc(head_only=1), desc(stride=2), desc(H=16, W=16),
+                desc(H=8, W=20), desc(H=9, W=7)):
+        assert lib.ft_bottleneck_cluster_supported(ctypes.byref(bad)) != 0
+        assert lib.ft_bottleneck_cluster_workspace_bytes(ctypes.byref(bad)) == 0
+
+
 S128 = [c for c in STREAM_CASES if c[6] == 128] + [
     ("s128_r101_b16_48x36", 16, 48, 36, 512, 0, 128),    # configs[2] per-GPU shape: 160 strips of 5 rows -> 256 strips of 3 rows
     ("s128_recycle_small", 40, 48, 36, 512, 0, 128),     # 640 small strips: LDS reuse across workgroups
