@@ -88,22 +88,25 @@ constexpr int kZROW = kT1ROWS * kROWB, kTABS = kZROW + 2048, kLdsBytes = kTABS +
 static_assert(kLdsBytes <= 163840, "LDS map");
 
 // Cluster barrier: see the header.  Precondition: every wave that stored payload has executed s_waitcnt vmcnt(0).
-__device__ __forceinline__ void bnc_arrive_wait(unsigned* cnt, unsigned target, unsigned* status, int tid, bool skip) {
+// `prefetch` (register loads of the next phase's first operands) is issued between the arrival and the end of the wait: by
+// waves 1..3 at once, by wave 0 only after its lane 0 has seen the counter (its polls must not queue behind those loads).
+template <typename F>
+__device__ __forceinline__ void bnc_arrive_wait(unsigned* cnt, unsigned target, unsigned* status, int tid, int wave, bool skip, F&& prefetch) {
   BNC_BARRIER();
-  if (tid == 0) {
+  if (tid == 0) __hip_atomic_fetch_add((gu32*)(uintptr_t)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wave != 0) prefetch();
+  if (tid == 0 && !skip) {
     gu32* c = (gu32*)(uintptr_t)cnt;
-    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!skip) {
-      unsigned spins = 0;
-      while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 19)) {
-          __hip_atomic_store((gu32*)(uintptr_t)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 19)) {
+        __hip_atomic_store((gu32*)(uintptr_t)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
       }
     }
   }
+  if (wave == 0) prefetch();
   BNC_BARRIER();
 }
 
@@ -151,10 +154,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_cluster_kernel(const BncPar
   // has landed while the weight loads of later steps stay in flight).  Measured with tools/dev/bnc_stress.py (x rows
   // cache-cold: torch kernels stream hundreds of MB between runs): 15 of 16 runs WRONG; with an extra `s_waitcnt vmcnt(2)` in
   // front of the barrier still 12 of 16; with the rows past the member's 48 pixels clamped to a valid address instead of an
-  // out-of-range offset 0 of 16.  A wave whose LDS-DMA load is entirely out of range evidently retires it ahead of its older
-  // loads, and every counted wait behind it then covers one load less than it assumes (the strip kernels issue such loads
-  // too; their x is L2-hot, which hides it: see profiles/README.md).  Rather than rely on counting across two kinds of
-  // loads, every load of this loop is a register load: all vmcnt waits are hipcc's own.
+  // out-of-range offset 0 of 16; with a full drain + barrier per chunk 0 of 16.  The mechanism was not isolated further (the
+  // strip / patch kernels, which issue the same kind of fully out-of-range wave loads for their padding rows, pass the same
+  // cold-cache stress: tools/dev/lds_dma_oob_stress.py, 0 of 20 runs each) — so this loop does not count across two kinds of
+  // loads at all: every load in it is a register load and every vmcnt wait is hipcc's own.
   unsigned x_goff[LX];
   int x_loff[LX];
 #pragma unroll
@@ -291,7 +294,42 @@ __global__ __launch_bounds__(256, 1) void bottleneck_cluster_kernel(const BncPar
     *reinterpret_cast<uint4_t*>(smem + row * kROWB + cpos * 16) = uint4_t{0u, 0u, 0u, 0u};
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  bnc_arrive_wait(cnt, base + 4u, p.status, tid, p.dbg & 1);
+  const int ct = wave & 1, kh = wave >> 1;
+  constexpr int NS2 = FT_BNC_SLOTS2, D2 = NS2 - 1;
+  uint4_t a2[NS2][2];
+  auto load_a2 = [&](auto slotc, int s) {       // conv2 step s (tap s / 4, K chunk s % 4): this wave's two K16 slices of tile 2 m + ct
+    constexpr int SL = decltype(slotc)::value;   // (past the last step: conv3's first steps, valid bytes, never multiplied)
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq)
+      a2[SL][kq] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, (kG2 + s) * kWSTEP + ((2 * kh + kq) * kNCT + 2 * m + ct) * 1024, 0);
+  };
+  int m_out[kMT], edge[kMT];
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) {
+    m_out[j] = j * 32 + l31;
+    const int ox = m_out[j] % W;
+    edge[j] = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+  }
+  // the residual of phase 3 (this member's 256 channels of x at all pixels, in the accumulator layout: 16 consecutive channels
+  // per lane, 96 registers) is fetched HERE, two phases ahead: loaded inside phase 3 its HBM latency was exposed once per
+  // pixel pass (phase 3 took 21 k cycles for 6 k cycles of MFMA)
+  uint4_t res[2][2][3][2];
+  auto load_res = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          const int hp = m_out[3 * ps + jj] < HW ? m_out[3 * ps + jj] : HW - 1;     // (padding pixels: any valid address)
+          const unsigned vo = (unsigned)(((n * HW + hp) * p.x_cstride + p.x_coff + m * kP + (2 * wave + i) * 32 + 16 * lhi) * 2);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) res[ps][i][jj][h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo + (unsigned)(h * 16), 0, 0);
+        }
+  };
+  bnc_arrive_wait(cnt, base + 4u, p.status, tid, wave, p.dbg & 1, [&] {
+    bnc_unroll<D2>([&](auto sc) { load_a2(sc, decltype(sc)::value); });    // phase 2's first weight steps
+  });
   BNC_TS(2);
   // gather the image's t1: LDS row W + hp <- T1X row hp, 512 bytes each, two rows per wave load; sc1: not through this CU's L1
   {
@@ -303,30 +341,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_cluster_kernel(const BncPar
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t1, (lds_ptr)(smem + (W + 2 * t) * kROWB), 16, vo, 0, 0, 16);
     }
   }
-  // the gather has landed (a full drain, not a counted wait with the first weight loads in flight behind it: see phase 1),
-  // then phase 2's first weight steps
+  // the gather has landed (a full drain, not a counted wait with register loads in flight behind it: see phase 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   BNC_BARRIER();
-  const int ct = wave & 1, kh = wave >> 1;
-  constexpr int NS2 = FT_BNC_SLOTS2, D2 = NS2 - 1;
-  uint4_t a2[NS2][2];
-  auto load_a2 = [&](auto slotc, int s) {       // conv2 step s (tap s / 4, K chunk s % 4): this wave's two K16 slices of tile 2 m + ct
-    constexpr int SL = decltype(slotc)::value;   // (past the last step: conv3's first steps, valid bytes, never multiplied)
-#pragma unroll
-    for (int kq = 0; kq < 2; ++kq)
-      a2[SL][kq] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, (kG2 + s) * kWSTEP + ((2 * kh + kq) * kNCT + 2 * m + ct) * 1024, 0);
-  };
-  bnc_unroll<D2>([&](auto sc) { load_a2(sc, decltype(sc)::value); });
+  load_res();
   BNC_TS(3);
 
   // ================= phase 2: t2 channels [64 m, 64 m + 64) on all pixels ====================================================
-  int m_out[kMT], edge[kMT];
-#pragma unroll
-  for (int j = 0; j < kMT; ++j) {
-    m_out[j] = j * 32 + l31;
-    const int ox = m_out[j] % W;
-    edge[j] = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
-  }
   {
     float16_t acc2[kMT];
 #pragma unroll
@@ -401,14 +422,15 @@ __global__ __launch_bounds__(256, 1) void bottleneck_cluster_kernel(const BncPar
   // exchange is in flight
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every storing wave drains (and: the K-half exchange has been read)
   uint4_t a3[kKC][4][2];
+  bnc_arrive_wait(cnt, base + 8u, p.status, tid, wave, p.dbg & 1, [&] {
 #pragma unroll
-  for (int kc = 0; kc < kKC; ++kc)
+    for (int kc = 0; kc < kKC; ++kc)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a3[kc][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, (kG3 + m * kKC + kc) * kWSTEP + (kk * kNCT + 2 * wave + i) * 1024, 0);
-  bnc_arrive_wait(cnt, base + 8u, p.status, tid, p.dbg & 1);
+        for (int i = 0; i < 2; ++i)
+          a3[kc][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, (kG3 + m * kKC + kc) * kWSTEP + (kk * kNCT + 2 * wave + i) * 1024, 0);
+  });
   BNC_TS(5);
   {
     const int nload = HW >> 1;
@@ -434,17 +456,6 @@ __global__ __launch_bounds__(256, 1) void bottleneck_cluster_kernel(const BncPar
         for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc3[i][jj][r] = 0.f;
-      // the residual of this pass, in the accumulator layout (16 consecutive channels per lane), behind the MFMAs' shadow
-      uint4_t res[2][3][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-          const int hp = m_out[3 * ps + jj] < HW ? m_out[3 * ps + jj] : HW - 1;     // (padding pixels: any valid address)
-          const unsigned vo = (unsigned)(((n * HW + hp) * p.x_cstride + p.x_coff + m * kP + (2 * wave + i) * 32 + 16 * lhi) * 2);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) res[i][jj][h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo + (unsigned)(h * 16), 0, 0);
-        }
 #pragma unroll
       for (int kc = 0; kc < kKC; ++kc)
 #pragma unroll
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_cluster_kernel(const BncPar
           const unsigned vo = hp < HW ? (unsigned)(((n * HW + hp) * p.y_cstride + p.y_coff + m * kP + ch) * 2) : kOOB;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const half8_t rs = __builtin_bit_cast(half8_t, res[i][jj][h]);
+            const half8_t rs = __builtin_bit_cast(half8_t, res[ps][i][jj][h]);
             half8_t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {

@@ -330,10 +330,11 @@ class DeconvResnet(HipModule):
             prog.end_choice()
 
 
-    #: offer the cluster form of the 256-plane identity blocks (ft_bottleneck_cluster_fwd) to the first-call benchmark.  Its
-    #: workgroups wait for each other inside the launch; set False for plans whose launches may share the GPU with another
-    #: stream's cluster launches for long stretches (nothing deadlocks — spins are bounded — but a timed-out hand-off is wrong)
-    cluster_kernels: bool = os.environ.get("FT_CLUSTER_KERNELS", "1") != "0"
+    #: offer the cluster form of the 256-plane identity blocks (ft_bottleneck_cluster_fwd) to the first-call benchmark
+    #: (FT_CLUSTER_KERNELS=1).  OFF by default: measured in situ at R50 batch 64 it takes 50-52 us per block against the strip
+    #: form's 48 (each of its two in-launch hand-offs costs 4-5 us: profiles/README.md, round 5), and its workgroups wait for
+    #: each other inside the launch (bounded spins: nothing deadlocks, but a timed-out hand-off gives a wrong block).
+    cluster_kernels: bool = os.environ.get("FT_CLUSTER_KERNELS", "0") == "1"
 
     def plan_for(self, B: int, H: int, W: int, replica: int = 0) -> _PosePlan:
         """The plan (launch list + activation buffers + graph) of one input shape.  `replica` > 0 gives an independent copy
