@@ -390,6 +390,22 @@ def exact_argmax_record(model16, model32, x16, x32, device, steps, world):
     model16.exact_argmax_rel_bound = 0.0
     try:
         el0, rep0, tot0 = measure(lambda: model16.forward_keypoint_rows_exact(x16), steps, 3, device)
+        # the same regime WITHOUT a host read inside the step (round 5: exact_submit / exact_finish, finished one step late)
+        state = {"h": None}
+
+        def lagged():
+            h = model16.exact_submit(x16)
+            if state["h"] is not None:
+                model16.exact_finish(state["h"])
+            state["h"] = h
+
+        def drain():
+            if state["h"] is not None:
+                model16.exact_finish(state["h"])
+                state["h"] = None
+        lagged.drain = drain
+        el0d, rep0d, tot0d = measure(lagged, steps, 3, device)
+        drain()
     finally:
         model16.exact_argmax_rel_bound = keep_bound
 
@@ -425,6 +441,8 @@ def exact_argmax_record(model16, model32, x16, x32, device, steps, world):
             "timed_region_s": round(tot, 4), "rel_bound": model16.exact_argmax_rel_bound,
             "no_rerun_path": {"value": round(B * world * steps / el0, 2), "unit": "crops/s", "ms_per_step": round(1e3 * el0 / steps, 4),
                               "repeats": rep0, "timed_region_s": round(tot0, 4)},
+            "no_rerun_path_device_decision": {"value": round(B * world * steps / el0d, 2), "unit": "crops/s", "ms_per_step": round(1e3 * el0d / steps, 4),
+                                              "repeats": rep0d, "timed_region_s": round(tot0d, 4)},
             "rerun_frac": round(rerun["n"] / max(rerun["calls"] * B, 1), 4),
             "argmax_identical_frac": same_b, "argmax_identical_frac_1024_crops": round(same / max(total, 1), 6),
             "rerun_frac_1024_crops": round(flagged / 1024.0, 4),
@@ -766,6 +784,7 @@ def summary_of(out):
          "fp16_argmax_identical": g(out, "parity", "fp16", "argmax_identical_frac"), "fp16_heatmap_err": g(out, "parity", "fp16", "heatmap_max_abs_err"),
          "fp16_mAP_OKS": g(out, "parity", "fp16", "mAP_at_OKS"), "fp32_argmax_identical": g(out, "parity", "fp32", "argmax_identical_frac"),
          "exact_argmax_crops_s": g(out, "fp16_exact_argmax", "value"), "exact_no_rerun_crops_s": g(out, "fp16_exact_argmax", "no_rerun_path", "value"),
+         "exact_no_rerun_device_decision_crops_s": g(out, "fp16_exact_argmax", "no_rerun_path_device_decision", "value"),
          "clip_frames_s": g(out, "clip", "frames_per_s"), "clips8_frames_s": g(out, "clip", "clips", "interleaved", "frames_per_s_total"),
          "cpu_crops_s": g(out, "cpu_baseline", "value"), "cpu_pairs_s": g(out, "flow", "cpu_baseline", "value"),
          "rccl_ranks_verified": g(out, "rccl", "ranks_verified")}

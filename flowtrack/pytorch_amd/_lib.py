@@ -129,6 +129,7 @@ _PROTOTYPES = {
     "ft_crop_affine_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p]),
     "ft_flow_warp_concat": (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "ft_gather_flagged_rows": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_cluster_supported": (c_int, [c_void_p]),
     "ft_bottleneck_cluster_workspace_bytes": (ctypes.c_longlong, [c_void_p]),
     "ft_bottleneck_cluster_status_offset": (ctypes.c_longlong, [c_void_p]),

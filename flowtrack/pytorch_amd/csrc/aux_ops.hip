@@ -295,6 +295,52 @@ __global__ __launch_bounds__(256) void heatmap_argmax_screen_kernel(const float*
   }
 }
 
+// Compaction + gather of the flagged crops ON THE DEVICE (round 5): block (k, part) finds the k-th set flag (every block
+// recomputes the small prefix: N <= 1024 flags) and copies that crop's row to slot k of `dst`; block (0, 0) also writes the
+// header = {count, idx[0], idx[1], ...}.  With nothing flagged every block exits after reading the flags.
+__global__ __launch_bounds__(256) void gather_flagged_rows_kernel(const int32_t* __restrict__ flags, int N, const uint4_t* __restrict__ src,
+                                                                  size_t row16, uint4_t* __restrict__ dst, int32_t* __restrict__ header) {
+  __shared__ int s_cnt[4];
+  __shared__ int s_idx;
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // thread t owns flags [4 t, 4 t + 4): running count over threads by wave ballots of per-thread counts
+  int f[4], mine = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * threadIdx.x + e;
+    f[e] = (i < N && flags[i] != 0) ? 1 : 0;
+    mine += f[e];
+  }
+  int incl = mine;                         // inclusive scan inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_cnt[wave] = incl;
+  if (threadIdx.x == 0) s_idx = -1;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_cnt[w];
+  const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  int before = base + incl - mine;         // flagged crops in front of this thread's four
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (f[e]) {
+      if (before == k) s_idx = 4 * threadIdx.x + e;
+      if (blockIdx.x == 0 && blockIdx.y == 0) header[1 + before] = 4 * threadIdx.x + e;     // (block (0, 0) writes the whole list)
+      ++before;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) header[0] = total;
+  __syncthreads();
+  const int idx = s_idx;
+  if (idx < 0) return;                     // fewer than k + 1 flagged crops
+  const uint4_t* s = src + (size_t)idx * row16;
+  uint4_t* d = dst + (size_t)k * row16;
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < row16; i += (size_t)gridDim.y * 256) d[i] = s[i];
+}
+
 // ---- FlowNet2* rgb mean: stage 1 partial sums, stage 2 finish -----------------------------------
 __global__ __launch_bounds__(256) void rgb_partial_sum_kernel(const float* __restrict__ x, size_t L,
                                                               float* __restrict__ partial) {
@@ -884,6 +930,18 @@ extern "C" int ft_heatmap_argmax_screen(const float* heatmaps, int N, int K, int
   if (K > 256) return FT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(heatmap_argmax_screen_kernel, dim3(N), dim3(256), 0, as_stream(stream), heatmaps, K, H * W, rel_bound, flags, stats);
   FT_LAUNCH_CHECK("heatmap_argmax_screen_kernel");
+  return FT_OK;
+}
+
+extern "C" int ft_gather_flagged_rows(const int32_t* flags, int N, const void* src, long long row_bytes, void* dst, int32_t* header,
+                                      ft_stream_t stream) {
+  if (!flags || !src || !dst || !header || N <= 0 || row_bytes <= 0) return FT_ERR_INVALID_ARG;
+  if (N > 1024 || row_bytes % 16 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return FT_ERR_UNSUPPORTED;
+  const size_t row16 = (size_t)row_bytes / 16;
+  const unsigned parts = (unsigned)((row16 + 256 * 16 - 1) / (256 * 16));      // ~16 pieces of 16 bytes per thread
+  hipLaunchKernelGGL(gather_flagged_rows_kernel, dim3(N, parts < 1 ? 1 : (parts > 64 ? 64 : parts)), dim3(256), 0, as_stream(stream), flags, N,
+                     static_cast<const uint4_t*>(src), row16, static_cast<uint4_t*>(dst), header);
+  FT_LAUNCH_CHECK("gather_flagged_rows_kernel");
   return FT_OK;
 }
 

@@ -399,6 +399,109 @@ class DeconvResnet(HipModule):
         return self._last_plan.kp_rows
 
 
+    # ---- the exact-arg-max mode without a host read inside the step (round 5) -------------------------------------------------
+    # forward_keypoint_rows_exact() reads the B flags on the host between the fp16 plan and the re-run: with nothing flagged that
+    # read (a stream synchronisation per step) cost 10 % of the step.  Here the step ends on the device: fp16 plan -> screen ->
+    # ft_gather_flagged_rows (flag compaction + copy of the flagged crops' INPUTS into a staging slot, all on the device) -> an
+    # asynchronous copy of the small header {count, indices} to pinned memory -> event.  exact_finish(), called one step later
+    # (or whenever the caller needs the rows), waits for that event — long past — and only if the count is non-zero runs the fp32
+    # plan on the staged crops and patches their rows.  The caller's x may be overwritten as soon as exact_submit() returns.
+    def _exact_slots(self, B: int, H: int, W: int, device):
+        key = (B, H, W, str(device))
+        st = self.__dict__.setdefault("_exact_state", {})
+        ent = st.get(key)
+        if ent is None:
+            import ctypes
+            from .. import _lib
+            lib = _lib.load()
+            slots = []
+            for _ in range(2):
+                ev = ctypes.c_void_p()
+                if lib.ft_event_create(ctypes.byref(ev)) != 0:
+                    raise FlowtrackHipError("ft_event_create failed")
+                slots.append({"stage": torch.empty((B, 3, H, W), dtype=torch.float32, device=device),
+                              "flags": torch.empty(B, dtype=torch.int32, device=device), "stats": torch.empty((B, 4), dtype=torch.float32, device=device),
+                              "header": torch.zeros(1 + B, dtype=torch.int32, device=device),
+                              "header_host": torch.zeros(1 + B, dtype=torch.int32).pin_memory(), "event": ev, "busy": False})
+            ent = st[key] = {"slots": slots, "next": 0}
+        return ent
+
+    @torch.no_grad()
+    def exact_submit(self, x: torch.Tensor) -> "_ExactHandle":
+        """First half of the exact-arg-max step (see above): everything is queued on the current stream, nothing is waited for."""
+        if self.keypoints_in_plan is None:
+            raise FlowtrackHipError("set model.keypoints_in_plan = True / False (adjust_coords) before exact_submit()")
+        import ctypes
+        from .. import _lib
+        from ..hip_ops import check, current_stream_handle
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        if B > 1024:
+            raise FlowtrackHipError("exact_submit: at most 1024 crops per call")
+        ent = self._exact_slots(B, H, W, x.device)
+        sl = ent["slots"][ent["next"]]
+        if sl["busy"]:
+            raise FlowtrackHipError("exact_submit: both staging slots are in flight: call exact_finish() on the older handle first")
+        want = self.compute_dtype
+        self.compute_dtype = torch.float16
+        try:
+            rows = self.forward_keypoint_rows(x).clone()
+            hm = self._last_plan.heatmaps
+        finally:
+            self.compute_dtype = want
+        sh = current_stream_handle(x.device)
+        check(lib.ft_heatmap_argmax_screen(hm.data_ptr(), B, hm.shape[1], hm.shape[2], hm.shape[3], ctypes.c_float(self.exact_argmax_rel_bound),
+                                           sl["flags"].data_ptr(), sl["stats"].data_ptr(), sh), "ft_heatmap_argmax_screen")
+        xin = self._last_plan.x_static          # (fp32 NCHW: the plan's own copy of the batch)
+        check(lib.ft_gather_flagged_rows(sl["flags"].data_ptr(), B, xin.data_ptr(), 3 * H * W * 4, sl["stage"].data_ptr(), sl["header"].data_ptr(), sh),
+              "ft_gather_flagged_rows")
+        check(lib.ft_memcpy_async(sl["header_host"].data_ptr(), sl["header"].data_ptr(), (1 + B) * 4, sh), "ft_memcpy_async")
+        check(lib.ft_event_record(sl["event"], sh), "ft_event_record")
+        sl["busy"] = True
+        self._last_screen_stats = sl["stats"]
+        h = _ExactHandle()
+        h.rows, h.slot, h.B, h.H, h.W, h.done = rows, ent["next"], B, H, W, False
+        ent["next"] ^= 1
+        return h
+
+    @torch.no_grad()
+    def exact_finish(self, h: "_ExactHandle"):
+        """Second half: (rows [B,K,3] with the parity mode's arg-max, number of crops re-run in fp32)."""
+        if h.done:
+            raise FlowtrackHipError("exact_finish: handle already finished")
+        from .. import _lib
+        from ..hip_ops import check
+        lib = _lib.load()
+        dev = h.rows.device
+        ent = self._exact_slots(h.B, h.H, h.W, dev)
+        sl = ent["slots"][h.slot]
+        check(lib.ft_event_synchronize(sl["event"]), "ft_event_synchronize")
+        hdr = sl["header_host"]
+        n = int(hdr[0])
+        h.done = True
+        if n:
+            idx = hdr[1:1 + n].to(torch.int64).to(dev)
+            want = self.compute_dtype
+            self.compute_dtype = torch.float32
+            try:
+                lo = 0
+                while lo < n:
+                    m = min(n - lo, h.B)
+                    bucket = next(b for b in (8, 16, 32, 64, 128, 256, 1 << 30) if b >= m or b >= h.B)
+                    bucket = min(bucket, max(h.B, 8))
+                    xb = self.static_input(bucket, h.H, h.W)
+                    take = min(m, bucket)
+                    xb[:take].copy_(sl["stage"][lo:lo + take])
+                    if take < bucket:
+                        xb[take:].zero_()
+                    r32 = self.forward_keypoint_rows(xb)
+                    h.rows.index_copy_(0, idx[lo:lo + take], r32[:take])
+                    lo += take
+            finally:
+                self.compute_dtype = want
+        sl["busy"] = False
+        return h.rows, n
+
     @torch.no_grad()
     def forward_keypoint_rows_exact(self, x: torch.Tensor):
         """Key-point rows [B,K,3] with the arg-max of the fp32 parity mode at (mostly) fp16 speed — north_star's "keypoint
@@ -453,6 +556,10 @@ class DeconvResnet(HipModule):
         finally:
             self.compute_dtype = want
         return rows, n
+
+
+class _ExactHandle:
+    __slots__ = ("rows", "slot", "B", "H", "W", "done")
 
 
 def deconv(backbone: str, num_classes: int, pretrained: bool) -> DeconvResnet:

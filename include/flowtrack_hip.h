@@ -351,6 +351,13 @@ int ft_heatmap_min_margin(const float* heatmaps, int N, int K, int H, int W, flo
 int ft_heatmap_argmax_screen(const float* heatmaps, int N, int K, int H, int W, float rel_bound, int32_t* flags, float* stats,
                              ft_stream_t stream);
 
+/* The re-run set of that screen, built ON THE DEVICE (round 5; DeconvResnet.exact_submit / exact_finish): header[0] = number
+ * of set flags, header[1 + j] = index of the j-th flagged row, and row idx[j] of `src` ([N] rows of row_bytes, a multiple of
+ * 16) is copied to row j of `dst`.  No host read sits between the screen and the gather: the host looks at `header` one step
+ * later, behind an event, and only then decides whether a re-run is needed.  N <= 1024; header: int32 [1 + N]. */
+int ft_gather_flagged_rows(const int32_t* flags, int N, const void* src, long long row_bytes, void* dst, int32_t* header,
+                           ft_stream_t stream);
+
 /* ---- F1: FlowNet2* input normalisation ------------------------------------
  * rgb_mean over (pair,H,W) per (b,colour) then (x - mean) / rgb_max
  * (lib/flownet/model/models.py:255-257).  inputs: fp32 [B,3,2,H,W].

@@ -134,6 +134,19 @@ def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
     check(hip_lib.ft_channelnorm_fwd(gimg.data_ptr(), nrm.data_ptr(), B, C, H, W, _stream()))
     torch.cuda.synchronize()
     assert np.abs(nrm.cpu().numpy() - ops_ref.channelnorm_c(img)).max() <= 1e-6
+    # both ChannelNorm kernels: HW % 4 == 0 takes the 16-byte form (C = 3 with all loads in flight, other C in a loop), anything
+    # else (odd plane size, a misaligned plane pointer) the one-pixel form; same per-pixel arithmetic: identical bits
+    for (b2, c2, h2, w2, off) in ((2, 3, 12, 20, 0), (1, 5, 8, 12, 0), (2, 3, 7, 9, 0), (1, 3, 8, 8, 1), (3, 1, 4, 4, 0)):
+        im = synth.normal(8, f"cn{c2}{h2}{w2}", (b2 * c2 * h2 * w2 + 4,))
+        g = im.cuda()
+        o = torch.full((b2 * h2 * w2 + 4,), -1.0, device="cuda")
+        check(hip_lib.ft_channelnorm_fwd(g.data_ptr() + 4 * off, o.data_ptr() + 4 * off, b2, c2, h2, w2, _stream()))
+        torch.cuda.synchronize()
+        src = im[off:off + b2 * c2 * h2 * w2].reshape(b2, c2, h2, w2).numpy()
+        want_n = ops_ref.channelnorm_c(src).reshape(-1)
+        got_n = o[off:off + b2 * h2 * w2].cpu().numpy()
+        assert np.abs(got_n - want_n).max() <= 1e-6, (b2, c2, h2, w2, off)
+        assert float(o[off + b2 * h2 * w2:].max()) == -1.0 and (off == 0 or float(o[0]) == -1.0)
     # the other kernel forms: a width that is no multiple of 4 and more than 4 channels (one pixel per thread), 1 / 2 / 4
     # channels (four pixels per thread); out-of-frame flows in every case
     for (b2, c2, h2, w2) in ((1, 3, 10, 13), (1, 5, 8, 12), (2, 1, 9, 16), (1, 2, 7, 8), (1, 4, 6, 20)):

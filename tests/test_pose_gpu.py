@@ -410,3 +410,58 @@ def test_fp16_exact_argmax_mode_has_the_fp32_argmax(hip_lib):
         assert int((~untouched).sum()) <= n
     assert 0 < reran <= 192, f"{reran} of 192 crops re-run"       # noise-like maps (random weights): nearly all of them
     print("fp16 arg-max flips without the screen:", flips16, "of", 192 * 17, "- crops re-run:", reran)
+
+
+def test_exact_argmax_submit_finish_equals_the_blocking_form(hip_lib):
+    """DeconvResnet.exact_submit / exact_finish (round 5: screen -> flag compaction -> gather of the flagged crops, all on the
+    device; the host looks at the count one step later) give the rows of forward_keypoint_rows_exact bit for bit, for a bound that
+    flags nothing, one that flags about half of the crops and the default (noise-like maps: nearly all); two steps are kept in
+    flight and finished late, with the input buffer overwritten in between; ft_gather_flagged_rows itself is checked on a
+    planted flag vector."""
+    m16, _ = _model(50, torch.float16)
+    m16.keypoints_in_plan = True
+    xa, xb = synth.pose_crops(SEED + 70, 64).cuda(), synth.pose_crops(SEED + 71, 64).cuda()
+    # a bound that splits the batch: the median of the per-crop ratio (smallest margin / (2 R))
+    m16.forward_keypoint_rows_exact(xa)
+    st = m16._last_screen_stats.cpu()
+    mid = float((st[:, 0] / (2 * st[:, 1])).median())
+    keep = m16.exact_argmax_rel_bound
+    try:
+        for bound, lo, hi in ((0.0, 0, 0), (mid, 8, 56), (keep, 32, 64)):
+            m16.exact_argmax_rel_bound = bound
+            want_a, na = m16.forward_keypoint_rows_exact(xa)
+            want_b, nb = m16.forward_keypoint_rows_exact(xb)
+            want_a, want_b = want_a.clone(), want_b.clone()
+            assert lo <= na <= hi, (bound, na)
+            x = xa.clone()
+            ha = m16.exact_submit(x)
+            x.copy_(xb)                                  # the caller's buffer is free as soon as submit returns
+            hb = m16.exact_submit(x)
+            x.zero_()
+            with pytest.raises(Exception):
+                m16.exact_submit(x)                      # both staging slots in flight
+            rows_a, ga = m16.exact_finish(ha)
+            rows_b, gb = m16.exact_finish(hb)
+            assert (ga, gb) == (na, nb)
+            assert torch.equal(rows_a, want_a) and torch.equal(rows_b, want_b), bound
+            with pytest.raises(Exception):
+                m16.exact_finish(ha)
+    finally:
+        m16.exact_argmax_rel_bound = keep
+    # the gather alone: rows 3, 4, 17, 63 of 64 flagged
+    import ctypes
+    from flowtrack.pytorch_amd.hip_ops import current_stream_handle
+    flags = torch.zeros(64, dtype=torch.int32, device="cuda")
+    flags[[3, 4, 17, 63]] = 1
+    src = torch.arange(64 * 48, dtype=torch.float32, device="cuda").reshape(64, 48)
+    dst = torch.full((64, 48), -1.0, device="cuda")
+    hdr = torch.full((65,), -7, dtype=torch.int32, device="cuda")
+    assert hip_lib.ft_gather_flagged_rows(flags.data_ptr(), 64, src.data_ptr(), 48 * 4, dst.data_ptr(), hdr.data_ptr(), current_stream_handle()) == 0
+    torch.cuda.synchronize()
+    assert hdr[:5].tolist() == [4, 3, 4, 17, 63] and int(hdr[5]) == -7
+    assert torch.equal(dst[:4], src[[3, 4, 17, 63]]) and float(dst[4:].max()) == -1.0
+    flags.zero_()
+    assert hip_lib.ft_gather_flagged_rows(flags.data_ptr(), 64, src.data_ptr(), 48 * 4, dst.data_ptr(), hdr.data_ptr(), current_stream_handle()) == 0
+    torch.cuda.synchronize()
+    assert int(hdr[0]) == 0
+    assert hip_lib.ft_gather_flagged_rows(flags.data_ptr(), 2000, src.data_ptr(), 48 * 4, dst.data_ptr(), hdr.data_ptr(), current_stream_handle()) != 0
