@@ -127,9 +127,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
   const int qy0 = tyi * TH, qx0 = txi * TW;
 
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, kP * NCH * 128, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, kP * 9 * kP * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, FULL ? kC * kP * (PROJ ? 4 : 2) : 0, 0x00020000);
+  // (dbg & 64, dev: every weight load out of range = no traffic, zeros: the kernel's time without its 136 KB of weights per patch)
+  const bool now = p.dbg & 64;
+  const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, now ? 0 : kP * NCH * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, now ? 0 : kP * 9 * kP * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, (FULL && !now) ? kC * kP * (PROJ ? 4 : 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, FULL ? 3072 : 1024, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 

@@ -176,7 +176,10 @@ class DeconvResnet(HipModule):
         # FT_SPLIT_LANES=1 (dev, measured in profiles/README.md): layer1 + layer2 as TWO half-batch lanes (parallel graph branches).
         # Their fused blocks are phase-locked across the chip — every workgroup reads its input, then multiplies, then writes, at
         # the same time, so HBM idles while the matrix pipe runs and vice versa; two lanes half a block apart overlap them.
+        stages = {"stem": cur}         # activation views behind each stage (diagnostics: tests/error_budget.py)
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), start=1):
+            if li > 1:
+                stages[f"layer{li - 1}"] = cur
             if split and li == 1:
                 chain = []
                 hh, ww = cur.H, cur.W
@@ -214,6 +217,7 @@ class DeconvResnet(HipModule):
         # head: 3 x (ConvTranspose 4/2/1 + bn + relu), then the 1x1 heatmap conv (pose_deconv.py:43-45) — fused behind
         # the last deconv as its tail in fp16 mode: the [B, 64, 48, 256] map, the largest tensor of the head, never
         # reaches HBM
+        stages["layer4"] = cur
         fuse_tail = self.fuse_heatmap and dtype == torch.float16 and self.num_classes <= 32 and self.deconv[6].cout in (64, 128, 256)
         heatmaps = None
         for i in (0, 3, 6):
@@ -227,11 +231,13 @@ class DeconvResnet(HipModule):
                 nxt = new_act(B, cur.H * 2, cur.W * 2, dc.cout, dtype, device)
                 dc.record(prog, cur, nxt)
                 cur = nxt
+                stages[f"deconv.{i}"] = cur
         if heatmaps is None:
             hm = self.fused("heatmap", self.heatmap.weight, bias=self.heatmap.bias, act=None, **mk)
             heatmaps = torch.empty((B, self.num_classes, cur.H, cur.W), dtype=torch.float32, device=device)
             hm.record(prog, cur, heatmaps)
         plan = _PosePlan(prog, x_static, heatmaps)
+        plan.stages = stages
         if self.keypoints_in_plan is not None:
             # max_preds (+ the 0.25 px nudge of final_preds) as the last launch of the plan: no extra stream work per call
             K, hh, hw = self.num_classes, heatmaps.shape[2], heatmaps.shape[3]

@@ -30,23 +30,33 @@ def _bottleneck(sd, p, x, stride):
     return F.relu(out + residual)
 
 
+STAGES = ("input", "stem", "layer1", "layer2", "layer3", "layer4", "deconv.0", "deconv.3", "deconv.6")
+
+
 @torch.no_grad()
-def pose_forward(sd, x, depth=50, return_features=False):
-    """sd: state_dict of deconv('resnet<depth>', K) (fp32 CPU tensors); x [B,3,H,W] -> [B,K,H/4,W/4]."""
+def pose_forward(sd, x, depth=50, return_features=False, start="input"):
+    """sd: state_dict of deconv('resnet<depth>', K) (fp32 CPU tensors); x [B,3,H,W] -> [B,K,H/4,W/4].
+    start (tests/error_budget.py): `x` is the activation BEHIND that stage (one of STAGES, NCHW) and the forward continues from
+    there — the same calls in the same order, only the earlier ones skipped."""
     sd = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
     x = x.float()
     feats = {}
-    x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))
-    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    at = STAGES.index(start)
+    if at < 1:
+        x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     feats["stem"] = x
     for li, nblocks in enumerate(RESNET_LAYERS[depth], start=1):
-        for bi in range(nblocks):
-            stride = 2 if (bi == 0 and li > 1) else 1
-            x = _bottleneck(sd, f"layer{li}.{bi}", x, stride)
+        if at < 1 + li:
+            for bi in range(nblocks):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                x = _bottleneck(sd, f"layer{li}.{bi}", x, stride)
         feats[f"layer{li}"] = x
-    for i in (0, 3, 6):
-        x = F.conv_transpose2d(x, sd[f"deconv.{i}.weight"], stride=2, padding=1)
-        x = F.relu(_bn(sd, f"deconv.{i + 1}", x))
+    for j, i in enumerate((0, 3, 6)):
+        if at < 6 + j:
+            x = F.conv_transpose2d(x, sd[f"deconv.{i}.weight"], stride=2, padding=1)
+            x = F.relu(_bn(sd, f"deconv.{i + 1}", x))
+        feats[f"deconv.{i}"] = x
     feats["deconv"] = x
     x = F.conv2d(x, sd["heatmap.weight"], sd["heatmap.bias"])
     return (x, feats) if return_features else x
