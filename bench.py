@@ -299,14 +299,19 @@ def flow_op_rooflines(device, B=16, H=384, W=512, iters=20):
              _lib.FT_ACT_LEAKY, ctypes.c_float(0.1), f16, keep=(c3, cin31))
     x6 = new_rowpacked_act(B, H, W, 6, 3, torch.float16, device)
     x6.t.normal_()
+    # two flow fields: per-pixel independent noise (sigma 4 px: every lane's taps sit in their own cache lines, the WORST case of
+    # a gather; what rounds 2-4 reported) and a SMOOTH field of the kind a flow network emits (a 12 x 16 grid of sigma-6-px
+    # vectors, bilinearly upsampled: neighbouring pixels sample neighbouring texels)
     flow = torch.randn((B, 2, H, W), device=device) * 4
+    smooth = torch.nn.functional.interpolate(torch.randn((B, 2, 12, 16), device=device) * 6, size=(H, W), mode="bilinear", align_corners=True).contiguous()
     cat1 = new_rowpacked_act(B, H, W, 12, 3, torch.float16, device)
-    prog.add("ft_flow_warp_concat", x6.t.data_ptr(), flow.data_ptr(), ctypes.c_float(20.0), cat1.t.data_ptr(), B, H, W, x6.lpad,
-             x6.wpitch, cat1.lpad, cat1.wpitch, f16, keep=(x6.t, flow, cat1.t))
     img = torch.randn((B, 3, H, W), device=device)
     warped = torch.empty_like(img)
-    prog.add("ft_resample2d_fwd", img.data_ptr(), flow.data_ptr(), warped.data_ptr(), B, 3, H, W, keep=(img, flow, warped))
     norm = torch.empty((B, 1, H, W), device=device)
+    for fl in (flow, smooth):
+        prog.add("ft_flow_warp_concat", x6.t.data_ptr(), fl.data_ptr(), ctypes.c_float(20.0), cat1.t.data_ptr(), B, H, W, x6.lpad,
+                 x6.wpitch, cat1.lpad, cat1.wpitch, f16, keep=(x6.t, fl, cat1.t))
+        prog.add("ft_resample2d_fwd", img.data_ptr(), fl.data_ptr(), warped.data_ptr(), B, 3, H, W, keep=(img, fl, warped))
     prog.add("ft_channelnorm_fwd", img.data_ptr(), norm.data_ptr(), B, 3, H, W, keep=(img, norm))
     torch.cuda.synchronize()
     prog.run_eager()
@@ -322,10 +327,14 @@ def flow_op_rooflines(device, B=16, H=384, W=512, iters=20):
         "ft_channelnorm_fwd": (px * 4 * (3 + 1), 0.0),          # (reads 3 channels, writes 1)
     }
     out = []
+    seen = {}
     for name, ms in times:
         nbytes, flops = algo[name]
         tbs = nbytes / (ms * 1e-3) / 1e12
-        row = {"kernel": name, "shape": f"[{B},256,{h8},{w8}] x2 -> 441 ch" if "corr" in name else f"[{B},*,{H},{W}]",
+        seen[name] = seen.get(name, 0) + 1
+        gather = name in ("ft_flow_warp_concat", "ft_resample2d_fwd")
+        row = {"kernel": name + ("_smooth_flow" if gather and seen[name] == 2 else ""),
+               "shape": f"[{B},256,{h8},{w8}] x2 -> 441 ch" if "corr" in name else f"[{B},*,{H},{W}]",
                "bound": "hbm", "us": round(ms * 1e3, 1), "algorithmic_bytes": nbytes, "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS,
                "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4)}
         if flops:

@@ -601,8 +601,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 // blocks.py:105-112 with stride on conv2, resnet.py:44-49): x has 64 * HEADC channels, the strip's t1 is kept at full input
 // resolution (2 TH + 1 rows), the taps of output pixel (r, c) sit at T1 row (2r + ky) W + 2c - 1 + kx (only the left border
 // needs the zero row: W is even), and the kernel ends behind conv2: t2 [N, H/2, W/2, P] leaves through the T2 tile.
-template <int MT1, int MT2, bool XH, int NS, int HEADC = 0>
-__global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const BnsParams p) {
+// NW = waves per workgroup (round 5).  4: a wave owns TWO output-channel tiles (one wave per SIMD).  8: a wave owns ONE tile and
+// two waves share a SIMD: every weight byte still reaches the CU once (the waves split the CHANNEL tiles, not the pixels), but
+// while one wave of a SIMD is held at its issue port by its weight loads (a buffer_load_b128 holds it ~40 cycles: a step of the
+// 4-wave form costs its MFMA time + ~335 cycles for its eight loads, tools/dev/ubench/l2_burst.hip) the other one multiplies.
+template <int MT1, int MT2, bool XH, int NS, int HEADC = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kernel(const BnsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 256;
   using G = BnsGeom<P>;
@@ -610,7 +614,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   static_assert(!(HEAD && XH), "the head form uses full-width strips");
   constexpr int NCT = G::NCT, NC1 = HEAD ? HEADC : G::NC1, KC = G::KC, WSTEP = G::WSTEP, ROWB = G::ROWB;
   constexpr int G2 = NC1, G3 = G2 + 9 * KC, GEND = HEAD ? G3 : G3 + 4 * KC;
-  constexpr int XROWS = MT1 * 32, LX = MT1;                  // one pixel group: 4 wave columns
+  static_assert(NW == 4 || NW == 8, "waves per workgroup");
+  constexpr int CTW = 8 / NW, NT = 64 * NW;                  // output-channel tiles per wave, threads
+  constexpr int XROWS = MT1 * 32, LX = (MT1 * 4 + NW - 1) / NW;   // x-chunk wave loads (8 rows each) per wave
+  static_assert(LX * NW * 8 * 128 <= G::XSTRIDE, "x-chunk buffer");
   constexpr int NOUT = MT2 * 32;
   constexpr int ZROW = 61440, TABS = 65536, STG = 81920, STGB = NOUT * ROWB;   // [76 K, 77 K): scratch of the L2 touch loads
   constexpr int LDS_BYTES = STG + 2 * STGB;
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   unsigned x_voff[LX];
 #pragma unroll
   for (int t = 0; t < LX; ++t) {
-    const int hp = (t * 4 + wave) * 8 + (lane >> 3);
+    const int hp = (t * NW + wave) * 8 + (lane >> 3);
     const int hr = hp / PW, hc = hp - hr * PW;
     const int iy = iy0 + hr, ix = XH ? x0 - 1 + hc : hc;
     unsigned v = kOOB;
@@ -674,19 +681,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     char* dst = smem + buf * G::XSTRIDE;
 #pragma unroll
     for (int t = 0; t < LX; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * 4 + wave) * 1024), 16, x_voff[t], c * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(dst + (t * NW + wave) * 1024), 16, x_voff[t], c * 128, 0, 0);
   };
   // the weight fragments of step g for this wave: (kk, tile 2*wcol + i) at g * WSTEP + (kk * NCT + 2*wcol + i) KiB
   static_assert(NS >= 3 && 12 % NS == 0, "ring phase of the unrolled phase-2 body (12 steps per kernel row)");
   constexpr int D = NS - 1;
-  uint4_t areg[NS][4][2];
+  uint4_t areg[NS][4][CTW];
   auto load_a = [&](auto slotc, int g) {        // past the end of the stream: out of range, zeros, never multiplied
     constexpr int SL = decltype(slotc)::value;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + 2 * wcol + i) * 1024, 0);
+      for (int i = 0; i < CTW; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + CTW * wcol + i) * 1024, 0);
   };
 
   auto load_a_half = [&](auto slotc, int g, auto halfc) {   // K16 slices {0, 1} or {2, 3} of the step
@@ -694,8 +701,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
     for (int kk = 2 * HF; kk < 2 * HF + 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + 2 * wcol + i) * 1024, 0);
+      for (int i = 0; i < CTW; ++i)
+        areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + CTW * wcol + i) * 1024, 0);
   };
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BNSD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -714,21 +721,21 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     const unsigned lo = loc * per, hi = lo + per < lines ? lo + per : lines;
     // (as LDS-DMA into a scratch corner: no destination register whose reuse the compiler would have to guard; issued
     // before the prologue's loads, so the hand-counted vmcnt waits below still see the order they assume)
-    for (unsigned l = lo + tid; l < hi; l += 256)
+    for (unsigned l = lo + tid; l < hi; l += NT)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + 77824 + wave * 256), 4, l << 7, 0, 0, 0);
   }
 #endif
   // prologue: all six tables (12 KiB, 3 x 256-byte pieces per wave ... 48 pieces), x chunks 0..2, weights of steps 0 and 1, zero row
 #pragma unroll
-  for (int t = 0; t < 12; ++t)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * 4 + wave) * 256), 4, (unsigned)lane * 4u, (t * 4 + wave) * 256, 0, 0);
+  for (int t = 0; t < 48 / NW; ++t)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * NW + wave) * 256), 4, (unsigned)lane * 4u, (t * NW + wave) * 256, 0, 0);
   issue_x(0, 0);
   issue_x(1, 1);
   issue_x(2, 2);
   bns_unroll<D>([&](auto sc) { load_a(sc, decltype(sc)::value); });
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
 
-  uint4_t res[4][2][MT2][2];
+  uint4_t res[4][CTW][MT2][2];
   int m_out[MT2], hp_out[MT2];          // output pixel of the lane in tile j, and its index in the halo patch
 #pragma unroll
   for (int j = 0; j < MT2; ++j) {
@@ -745,9 +752,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   }
 
   // ================= phase 1 ============================================================================================
-  float16_t acc1[2][MT1];
+  float16_t acc1[CTW][MT1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < CTW; ++i)
 #pragma unroll
     for (int j = 0; j < MT1; ++j)
 #pragma unroll
@@ -769,14 +776,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     auto mma1 = [&](auto setc, auto slotc, auto kkc) {
       constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < CTW; ++i)
 #pragma unroll
         for (int j = 0; j < MT1; ++j)
           acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]),
                                                               __builtin_bit_cast(half8_t, fx[S][j]), acc1[i][j], 0, 0, 0);
     };
     // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight steps (8 loads each) may fly
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 8 * D) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 4 * CTW * D) : "memory");
     BNS_BARRIER();
     ldx(c0{}, 0, 0);
     bns_unroll<NC1>([&](auto cc) {
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
       ldx(c1{}, buf, 1);
       mma1(c0{}, slot{}, std::integral_constant<int, 0>{});
       ldx(c0{}, buf, 2);
-      if constexpr (FT_BNS_PIN & 1) {
+      if constexpr ((FT_BNS_PIN & 1) && NW == 4) {
         // region: [x chunk c+2 DMA, slice-0 reads of this chunk, slice 3 of chunk c-1] (behind the last barrier) + the above
         __builtin_amdgcn_sched_group_barrier(0x020, LX, 0);
         bns_unroll<3>([&](auto) {
@@ -806,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
           __builtin_amdgcn_sched_group_barrier(0x100, (MT1 + 2) / 3, 0);
         });
       }
-      if (!HEAD && c % 4 == wcol) {  // this chunk holds the channels of this wave column for quarter c / 4
+      if (!HEAD && c % 4 == (CTW * wcol) / 2) {  // this chunk holds the channels of this wave column for quarter c / 4
         constexpr int q = c / 4;
         const char* xb = smem + buf * G::XSTRIDE;
 #pragma unroll
@@ -814,17 +821,17 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
           const int hp = hp_out[j];
           const char* rowp = xb + hp * 128;
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < CTW; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * i + 2 * lhi + h) ^ BNS_XKEY(hp)) << 4));
+              res[q][i][j][h] = *reinterpret_cast<const uint4_t*>(rowp + (((4 * ((CTW * wcol + i) & 1) + 2 * lhi + h) ^ BNS_XKEY(hp)) << 4));
         }
       }
       mma1(c1{}, slot{}, std::integral_constant<int, 1>{});
       load_a_half(std::integral_constant<int, (c + D) % NS>{}, c + D, c1{});
       ldx(c1{}, buf, 3);
       mma1(c0{}, slot{}, std::integral_constant<int, 2>{});
-      if constexpr (FT_BNS_PIN & 1) {
+      if constexpr ((FT_BNS_PIN & 1) && NW == 4) {
         bns_unroll<MT1>([&](auto) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -839,8 +846,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         // chunk c+1 are the weights of step c+1 (needed next anyway), x chunk c+2 and the weights of step c+2.
         // (with a prefetch distance of three or more steps the weights of step c+1 are OLDER than x chunk c+1: two weight
         // steps may stay in flight)
-        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + (D == 2 ? 8 : 16)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D == 2 ? 8 : 16) : "memory");
+        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + (D == 2 ? 4 * CTW : 8 * CTW)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D == 2 ? 4 * CTW : 8 * CTW) : "memory");
         BNS_BARRIER();
         if constexpr (c + 3 < NC1) issue_x(c + 3, buf);
         ldx(c0{}, (c + 1) % 3, 0);
@@ -854,8 +861,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   {
     const float* tb = reinterpret_cast<const float*>(smem + TABS);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+    for (int i = 0; i < CTW; ++i) {
+      const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
       float4_t sc[4], sh[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         }
         if (hp < npix_halo) {
           char* rowp = smem + hp * ROWB;
-          const int cb = (2 * wcol + i) * 4 + 2 * lhi;
+          const int cb = (CTW * wcol + i) * 4 + 2 * lhi;
 #pragma unroll
           for (int h = 0; h < 2; ++h)
             *reinterpret_cast<half8_t*>(rowp + (((cb + h) ^ (hp & 15)) << 4)) = h8[h];
@@ -889,10 +896,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   BNSD_TS(2);
 
   // ================= phases 2 + 3 =======================================================================================
-  float16_t acc[2][MT2];
+  float16_t acc[CTW][MT2];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CTW; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j)
 #pragma unroll
@@ -922,10 +929,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 #pragma unroll
     for (int j = 0; j < MT2; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (kk << 5)));
   };
-  auto mma2 = [&](auto setc, auto slotc, auto kkc, float16_t (&A)[2][MT2]) {
+  auto mma2 = [&](auto setc, auto slotc, auto kkc, float16_t (&A)[CTW][MT2]) {
     constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CTW; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j)
         A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, areg[SL][kk][i]),
@@ -934,7 +941,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   // one weight step g (ring slot SL = g % 3): slice 0 of the pixel operand already sits in register set 0; `rbn` = row
   // bases of the next step; `extra` = independent vector work that rides along (phase 3: a piece of the previous
   // quarter's epilogue), NX = how many of its VALU instructions each of the eight issue groups takes
-  auto dstep = [&](auto slotc, int g, const int (&rb)[MT2], bool has_next, const int (&rbn)[MT2], float16_t (&A)[2][MT2], auto nxc,
+  auto dstep = [&](auto slotc, int g, const int (&rb)[MT2], bool has_next, const int (&rbn)[MT2], float16_t (&A)[CTW][MT2], auto nxc,
                    auto&& extra) {
     constexpr int SL = decltype(slotc)::value, NX = decltype(nxc)::value;
     using slot = std::integral_constant<int, SL>;
@@ -951,7 +958,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     // Issue order of the step: one weight load and the pixel-operand reads after every MT2 MFMAs.  A buffer_load_b128 holds
     // the wave's issue port for ~40 cycles (tools/dev/ubench/l2_burst.hip: a step costs its compute time + 335 cycles for its
     // eight loads, whatever the prefetch depth); clustered as hipcc places them, the matrix pipe drains behind them.
-    if constexpr (FT_BNS_PIN & 1) {
+    if constexpr ((FT_BNS_PIN & 1) && NW == 4) {
       bns_unroll<8>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         __builtin_amdgcn_sched_group_barrier(0x008, MT2, 0);
@@ -993,8 +1000,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   {
     const float* tb = reinterpret_cast<const float*>(smem + TABS + G::TABB);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+    for (int i = 0; i < CTW; ++i) {
+      const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
       float4_t sc[4], sh[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -1009,7 +1016,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         for (int r = 0; r < 16; ++r)
           h8[r >> 3][r & 7] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
         char* rowp = smem + m * ROWB;
-        const int cb = (2 * wcol + i) * 4 + 2 * lhi;
+        const int cb = (CTW * wcol + i) * 4 + 2 * lhi;
 #pragma unroll
         for (int h = 0; h < 2; ++h) *reinterpret_cast<half8_t*>(rowp + (((cb + h) ^ (m & 15)) << 4)) = h8[h];
       }
@@ -1021,10 +1028,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
   BNSD_TS(4);
   if constexpr (HEAD) {
     // the head form ends here: the T2 tile (rows = output pixels, 16-byte chunk ^= row & 15) leaves as whole lines
-    constexpr int CPRH = ROWB / 16, NSTH = NOUT * CPRH / 256;
+    constexpr int CPRH = ROWB / 16, NSTH = NOUT * CPRH / NT;
 #pragma unroll
     for (int k = 0; k < NSTH; ++k) {
-      const int idx = tid + 256 * k, m = idx / CPRH, ch = idx % CPRH;
+      const int idx = tid + NT * k, m = idx / CPRH, ch = idx % CPRH;
       const int r = m / TWc, c = m - r * TWc;
       const unsigned vo = m < npix_out ? (unsigned)((((n * p.Ho + y0 + r) * p.Wo + c) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
       const uint4_t v = *reinterpret_cast<const uint4_t*>(smem + m * ROWB + ((ch ^ (m & 15)) << 4));
@@ -1035,12 +1042,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
 
   // ---- phase 3: four quarters of P output channels; the tile of a quarter leaves through one of two LDS staging tiles ----
   {
-    constexpr int CPR = ROWB / 16, NSTG = NOUT * CPR / 256;
+    constexpr int CPR = ROWB / 16, NSTG = NOUT * CPR / NT;
     unsigned s_voff[NSTG];
     int s_off[NSTG];
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
-      const int idx = tid + 256 * k, m = idx / CPR, ch = idx % CPR;
+      const int idx = tid + NT * k, m = idx / CPR, ch = idx % CPR;
       const int r = m / TWc, c = m - r * TWc;
       s_voff[k] = (m < npix_out && c < cols_out) ? (unsigned)((((n * p.H + y0 + r) * W + x0 + c) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
       s_off[k] = m * ROWB + ((ch ^ (m & 15)) << 4);
@@ -1049,11 +1056,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     row_bases(0, 0, 0, rb, false);
     ldb(c0{}, 0, rb);
     // epilogue of quarter q, tile (i, j): folded BN + residual + ReLU -> fp16 -> staging tile q & 1
-    auto epi_piece = [&](auto qc, int i, int j, float16_t (&A)[2][MT2]) {
+    auto epi_piece = [&](auto qc, int i, int j, float16_t (&A)[CTW][MT2]) {
       constexpr int q = decltype(qc)::value;
       char* stg = smem + STG + (q & 1) * STGB;
       const float* tb = reinterpret_cast<const float*>(smem + TABS + (2 + q) * G::TABB);
-      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
       float4_t sc[4], sh[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -1071,7 +1078,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
           o[e] = (half_t)__builtin_fmaxf(A[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
         }
 #if FT_BNS_STG
-        *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
+        *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((CTW * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
 #else
         // straight from the accumulator layout: the lane's 16 consecutive channels = two adjacent 16-byte stores
         const int orow = m / TWc, ocol = m - orow * TWc;
@@ -1092,9 +1099,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, s_voff[k] + (unsigned)(q * P * 2), 0, FT_YSTORE_BUF_AUX);
       }
     };
-    [[maybe_unused]] auto zero_set = [&](float16_t (&A)[2][MT2]) {
+    [[maybe_unused]] auto zero_set = [&](float16_t (&A)[CTW][MT2]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < CTW; ++i)
 #pragma unroll
         for (int j = 0; j < MT2; ++j)
 #pragma unroll
@@ -1106,12 +1113,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     // step, pinned between the MFMAs by dstep's issue groups.  The staging tiles alternate as before: tile (q-1) & 1 is
     // written during quarter q, read out behind quarter q's barrier; its previous readers (quarter q-3) are two barriers back.
     static_assert(2 * MT2 == KC, "one epilogue tile per weight step");
-    float16_t acc_b[2][MT2];
+    float16_t acc_b[CTW][MT2];
     zero_set(acc_b);
     bns_unroll<4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      float16_t (&A)[2][MT2] = (q & 1) ? acc_b : acc;
-      float16_t (&Aprev)[2][MT2] = (q & 1) ? acc : acc_b;
+      float16_t (&A)[CTW][MT2] = (q & 1) ? acc_b : acc;
+      float16_t (&Aprev)[CTW][MT2] = (q & 1) ? acc : acc_b;
       bns_unroll<KC>([&](auto kcc) {
         constexpr int kc = decltype(kcc)::value;
         constexpr int g = G3 + q * KC + kc;
@@ -1134,7 +1141,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
     });
     // quarter 3 has no successor to hide behind
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CTW; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j) epi_piece(std::integral_constant<int, 3>{}, i, j, acc_b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1152,7 +1159,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_direct_kernel(const 
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < CTW; ++i)
 #pragma unroll
         for (int j = 0; j < MT2; ++j) epi_piece(qc, i, j, acc);
       zero_acc();
@@ -1360,9 +1367,12 @@ static int bns_launch(const BnsParams& p, hipStream_t s) {
 #ifndef FT_BNS_XH_SLOTS
 #define FT_BNS_XH_SLOTS 3
 #endif
-template <int MT1, int MT2, bool XH, int HEADC = 0>
+#ifndef FT_BNS_WAVES_DEFAULT
+#define FT_BNS_WAVES_DEFAULT 4      // waves per workgroup of the direct kernels unless FT_BNS_WAVES says otherwise
+#endif
+template <int MT1, int MT2, bool XH, int HEADC = 0, int NW = 4>
 static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
-  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : FT_BNS_SLOTS, HEADC>;
+  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : FT_BNS_SLOTS, HEADC, NW>;
   constexpr int lds = 81920 + 2 * MT2 * 32 * 512;
   static bool attr_done[64] = {};          // the LDS opt-in is per device
   int dev = 0;
@@ -1371,7 +1381,7 @@ static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
     FT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
-  hipLaunchKernelGGL(k, dim3(p.total), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3(p.total), dim3(64 * NW), lds, s, p);
   FT_LAUNCH_CHECK("bottleneck_stream_direct_kernel");
   return FT_OK;
 }
@@ -1443,16 +1453,21 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   if (dbg & 64) p.ws_bytes = 0;     // dev: every weight load out of range (returns 0, no L2 access): the kernel's time without its weight stream
   if (dbg & 128) p.x_bytes = 0;     // dev: likewise the input
   hipStream_t s = as_stream(stream);
+  // FT_BNS_WAVES=4|8 (read per call: dev A/B and tests): waves per workgroup of the direct (256-plane) kernels.  Default: eight
+  // for the column-split form (R101 384x288 at 16 crops: 34.4 -> 33.3 us per block, R50 at 16 crops 30.0 -> 28.5), four for the
+  // full-width strips (batch 64: 46.1 vs 46.0 us — the eight-wave form gains in phases 1 and 3 what its doubled pixel-operand
+  // reads cost in phase 2; both forms sit on the CU's 64 B/clk weight path: 32 KiB of fragments per 16-MFMA step)
+  const bool waves8 = getenv("FT_BNS_WAVES") ? atoi(getenv("FT_BNS_WAVES")) == 8 : (FT_BNS_WAVES_DEFAULT == 8 || pl.variant == 3);
   switch (pl.variant) {
     case 0: return bns_launch<128, 4, 3>(p, s);
     case 5: return bns_launch<128, 3, 2>(p, s);
     case 1: return bns_launch<256, 4, 3>(p, s);
-    case 3: return bns_launch_direct<2, 1, true>(p, s);
-    case 4: return bns_launch_direct<4, 1, false, 8>(p, s);
+    case 3: return waves8 ? bns_launch_direct<2, 1, true, 0, 8>(p, s) : bns_launch_direct<2, 1, true>(p, s);
+    case 4: return waves8 ? bns_launch_direct<4, 1, false, 8, 8>(p, s) : bns_launch_direct<4, 1, false, 8>(p, s);
     default: {
       // 64-pixel strips at 256 planes: weights straight to registers (FT_BNS_DIRECT=0: through the LDS ring, dev A/B)
       static const bool no_direct = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;
-      return no_direct ? bns_launch<256, 3, 2>(p, s) : bns_launch_direct<3, 2, false>(p, s);
+      return no_direct ? bns_launch<256, 3, 2>(p, s) : (waves8 ? bns_launch_direct<3, 2, false, 0, 8>(p, s) : bns_launch_direct<3, 2, false>(p, s));
     }
   }
 }

@@ -249,6 +249,46 @@ def test_cluster_rejects_other_shapes(hip_lib):
         assert lib.ft_bottleneck_cluster_workspace_bytes(ctypes.byref(bad)) == 0
 
 
+@pytest.mark.parametrize("variant", [2, 3], ids=["full_width_strips", "column_split"])
+@pytest.mark.parametrize("case", S256, ids=[c[0] for c in S256])
+def test_stream_256_eight_wave_form_is_bit_identical(hip_lib, case, variant, monkeypatch):
+    """FT_BNS_WAVES=8 (round 5): the direct 256-plane kernels with eight waves per workgroup — a wave owns ONE output-channel
+    tile, two waves share a SIMD — do the same MFMAs in the same order per (channel tile, pixel tile) as the four-wave form:
+    identical bits, on every 256-plane shape and both strip forms; two runs of the eight-wave form agree."""
+    name, N, H, W, xcs, xoff, P = case
+    if variant == 2 and (H * W > 64 and W > 32):
+        pytest.skip("full-width strips need a row of <= 32 pixels at 256 planes")
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 37
+    C = 4 * P
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    want = F.relu(_bnf(F.conv2d(F.relu(_bnf(F.conv2d(F.relu(_bnf(F.conv2d(x, w1), bn1)), w2, padding=1), bn2)), w3), bn3) + x)
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    c3 = FusedConv(w3, bn=bn3, label="conv3", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    monkeypatch.setenv("FT_BNS_VARIANT", str(variant))
+    outs = {}
+    for waves in (4, 8):
+        monkeypatch.setenv("FT_BNS_WAVES", str(waves))
+        y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
+        prog = make_program()
+        record_bottleneck(prog, c1, c2, c3, xv, y, name)
+        run_program(prog)
+        outs[waves] = view_to_nchw(y)
+        y.t.fill_(5.0)
+        run_program(prog)
+        assert torch.equal(view_to_nchw(y), outs[waves]), f"{name} waves {waves}: two runs differ"
+        assert torch.all(y.t[..., :32] == 5.0)
+    scale = max(1.0, want.abs().max().item())
+    assert (outs[8] - want).abs().max().item() <= 2e-2 * scale
+    assert torch.equal(outs[4], outs[8]), f"{name}: eight-wave form differs from the four-wave form ({int((outs[4] != outs[8]).sum())} elements)"
+
+
 S128 = [c for c in STREAM_CASES if c[6] == 128] + [
     ("s128_r101_b16_48x36", 16, 48, 36, 512, 0, 128),    # configs[2] per-GPU shape: 160 strips of 5 rows -> 256 strips of 3 rows
     ("s128_recycle_small", 40, 48, 36, 512, 0, 128),     # 640 small strips: LDS reuse across workgroups
@@ -351,6 +391,19 @@ def test_stream_head_stride2_matches_oracle_and_the_two_launches(hip_lib, case):
     y.t.fill_(5.0)
     run_program(prog)
     assert torch.equal(view_to_nchw(y), got)
+    # the eight-wave form of the same kernel (FT_BNS_WAVES, read per call): identical bits
+    import os
+    keep = os.environ.get("FT_BNS_WAVES")
+    os.environ["FT_BNS_WAVES"] = "8" if keep != "8" else "4"
+    try:
+        y.t.fill_(5.0)
+        run_program(prog)
+        assert torch.equal(view_to_nchw(y), got), "the stride-2 head: eight- and four-wave forms differ"
+    finally:
+        if keep is None:
+            del os.environ["FT_BNS_WAVES"]
+        else:
+            os.environ["FT_BNS_WAVES"] = keep
 
 
 HEAD_CASES = [("r50_64x48", 2, 64, 48), ("r101_96x72", 1, 96, 72), ("ragged_13x20", 3, 13, 20), ("recycle", 24, 64, 48)]
