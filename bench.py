@@ -60,7 +60,7 @@ def build_flow(device, dtype, seed=1234, name="FlowNet2S"):
 def pmc_traffic(workload):
     """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE; tools/dev/prof_traffic.sh + pmc_traffic.py on this same command). None if not measured."""
-    for tag in ("r04", "r03", "r02", "r01"):       # the latest committed round
+    for tag in ("r05", "r04", "r03", "r02", "r01"):       # the latest committed round
         name = f"{tag}_{workload}_hbm_traffic_pmc.json"
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -415,6 +415,32 @@ def exact_argmax_record(model16, model32, x16, x32, device, steps, world):
         lagged.drain = drain
         el0d, rep0d, tot0d = measure(lagged, steps, 3, device)
         drain()
+        # ... and with the screen / gather / header copy recorded INSIDE the plan's graph (exact_in_plan): one replay + one event per
+        # step, the host looks at the header one step late; four plan replicas in rotation as the headline
+        model16.exact_in_plan = True
+        try:
+            eplans = [model16.plan_for(B, x16.shape[2], x16.shape[3], r) for r in range(4)]
+            for r, pl in enumerate(eplans):
+                pl.x_static.copy_(synth.pose_crops(100 + 1000 * r, B, x16.shape[2], x16.shape[3]))
+            st2 = {"i": 0, "prev": None}
+
+            def in_graph():
+                pl = eplans[st2["i"]]
+                st2["i"] = (st2["i"] + 1) % len(eplans)
+                model16.exact_submit_plan(pl)
+                if st2["prev"] is not None:
+                    model16.exact_finish_plan(st2["prev"])
+                st2["prev"] = pl
+
+            def drain2():
+                if st2["prev"] is not None:
+                    model16.exact_finish_plan(st2["prev"])
+                    st2["prev"] = None
+            in_graph.drain = drain2
+            el0g, rep0g, tot0g = measure(in_graph, steps, 3, device)
+            drain2()
+        finally:
+            model16.exact_in_plan = False
     finally:
         model16.exact_argmax_rel_bound = keep_bound
 
@@ -452,6 +478,8 @@ def exact_argmax_record(model16, model32, x16, x32, device, steps, world):
                               "repeats": rep0, "timed_region_s": round(tot0, 4)},
             "no_rerun_path_device_decision": {"value": round(B * world * steps / el0d, 2), "unit": "crops/s", "ms_per_step": round(1e3 * el0d / steps, 4),
                                               "repeats": rep0d, "timed_region_s": round(tot0d, 4)},
+            "no_rerun_path_in_graph": {"value": round(B * world * steps / el0g, 2), "unit": "crops/s", "ms_per_step": round(1e3 * el0g / steps, 4),
+                                       "repeats": rep0g, "timed_region_s": round(tot0g, 4)},
             "rerun_frac": round(rerun["n"] / max(rerun["calls"] * B, 1), 4),
             "argmax_identical_frac": same_b, "argmax_identical_frac_1024_crops": round(same / max(total, 1), 6),
             "rerun_frac_1024_crops": round(flagged / 1024.0, 4),
@@ -794,6 +822,7 @@ def summary_of(out):
          "fp16_mAP_OKS": g(out, "parity", "fp16", "mAP_at_OKS"), "fp32_argmax_identical": g(out, "parity", "fp32", "argmax_identical_frac"),
          "exact_argmax_crops_s": g(out, "fp16_exact_argmax", "value"), "exact_no_rerun_crops_s": g(out, "fp16_exact_argmax", "no_rerun_path", "value"),
          "exact_no_rerun_device_decision_crops_s": g(out, "fp16_exact_argmax", "no_rerun_path_device_decision", "value"),
+         "exact_no_rerun_in_graph_crops_s": g(out, "fp16_exact_argmax", "no_rerun_path_in_graph", "value"),
          "clip_frames_s": g(out, "clip", "frames_per_s"), "clips8_frames_s": g(out, "clip", "clips", "interleaved", "frames_per_s_total"),
          "cpu_crops_s": g(out, "cpu_baseline", "value"), "cpu_pairs_s": g(out, "flow", "cpu_baseline", "value"),
          "rccl_ranks_verified": g(out, "rccl", "ranks_verified")}

@@ -1001,8 +1001,7 @@ __global__ __launch_bounds__(256) void channelnorm_vec4_kernel(const float4_t* _
   const size_t b = i / HW4, pix = i - b * HW4;
   float4_t s = {0.f, 0.f, 0.f, 0.f};
   if (C == 3) {          // (the FlowNet2 shape: all three loads in flight before the first use)
-    const float4_t v0 = __builtin_nontemporal_load(in + (b * 3 + 0) * HW4 + pix), v1 = __builtin_nontemporal_load(in + (b * 3 + 1) * HW4 + pix),
-                   v2 = __builtin_nontemporal_load(in + (b * 3 + 2) * HW4 + pix);
+    const float4_t v0 = in[(b * 3 + 0) * HW4 + pix], v1 = in[(b * 3 + 1) * HW4 + pix], v2 = in[(b * 3 + 2) * HW4 + pix];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s[e] += v0[e] * v0[e];
@@ -1019,7 +1018,7 @@ __global__ __launch_bounds__(256) void channelnorm_vec4_kernel(const float4_t* _
   float4_t o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = sqrtf(s[e]);
-  __builtin_nontemporal_store(o, out + i);
+  out[i] = o;     // (plain: non-temporal loads / stores measured 34.7 us against 11.7)
 }
 
 // ---- fused inter-network stage: warp img1 by flow, brightness error, 12-channel concat ------------------

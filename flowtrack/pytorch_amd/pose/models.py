@@ -76,6 +76,8 @@ class DeconvResnet(HipModule):
     #: None: plans end at the heatmaps (the reference's forward).  True / False: plans also run max_preds on the heatmaps
     #: (with / without the adjust_coords nudge, lib/pose/utils/evaluation.py:11-35) and forward_keypoints() returns them
     keypoints_in_plan = None
+    #: record the exact-arg-max mode's screen + flagged-crop gather inside fp16 plans (needs keypoints_in_plan); see exact_submit_plan
+    exact_in_plan: bool = False
     #: dev: layer1 + layer2 as two half-batch lanes (parallel graph branches); FT_SPLIT_LANES=1
     split_lanes: int = int(os.environ.get("FT_SPLIT_LANES", "0") or 0)     # 1: lanes start together; 2: the second lane starts with its half of the stem
     #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
@@ -247,6 +249,22 @@ class DeconvResnet(HipModule):
             plan.kp_score, plan.kp_coords = plan.kp_rows[:, :, 2:], plan.kp_rows[:, :, :2]
             prog.add("ft_heatmap_keypoint_rows", heatmaps.data_ptr(), B, K, hh, hw, int(bool(self.keypoints_in_plan)),
                      plan.kp_idx.data_ptr(), plan.kp_rows.data_ptr(), keep=(plan.kp_idx, plan.kp_rows))
+            if self.exact_in_plan and dtype == torch.float16 and B <= 1024:
+                # the exact-arg-max mode's device side INSIDE the plan's graph (round 5): screen -> flag compaction + gather of the
+                # flagged crops' inputs -> header {count, indices} to pinned memory.  As graph nodes they cost their kernel time
+                # (~10 us); as five eager launches behind the replay they cost ~70 us of gaps per step.  exact_rel_bound is frozen
+                # into the plan (DeconvResnet.exact_submit_plan / exact_finish_plan).
+                import ctypes
+                ex = {"flags": torch.empty(B, dtype=torch.int32, device=device), "stats": torch.empty((B, 4), dtype=torch.float32, device=device),
+                      "stage": torch.empty((B, 3, H, W), dtype=torch.float32, device=device),
+                      "header": torch.zeros(1 + B, dtype=torch.int32, device=device), "header_host": torch.zeros(1 + B, dtype=torch.int32).pin_memory(),
+                      "rel_bound": float(self.exact_argmax_rel_bound), "event": None, "busy": False}
+                prog.add("ft_heatmap_argmax_screen", heatmaps.data_ptr(), B, K, hh, hw, ctypes.c_float(ex["rel_bound"]), ex["flags"].data_ptr(),
+                         ex["stats"].data_ptr(), keep=(ex["flags"], ex["stats"]))
+                prog.add("ft_gather_flagged_rows", ex["flags"].data_ptr(), B, x_static.data_ptr(), ctypes.c_longlong(3 * H * W * 4), ex["stage"].data_ptr(),
+                         ex["header"].data_ptr(), keep=(ex["stage"], ex["header"]))
+                prog.add("ft_memcpy_async", ex["header_host"].data_ptr(), ex["header"].data_ptr(), ctypes.c_size_t((1 + B) * 4), keep=(ex["header_host"],))
+                plan.exact = ex
         return plan
 
     def _record_block(self, prog, name: str, blk, cur, out, dtype, device) -> None:
@@ -347,7 +365,8 @@ class DeconvResnet(HipModule):
         with its own buffers — same packed weights, same tile picks — for callers that keep several batches of one shape
         in flight on different streams (tracking.PoseRunner per clip, tools/tracking/demo.run_clips)."""
         device, dtype = self._resolve()
-        key = (B, H, W, device, dtype, self.keypoints_in_plan) + ((replica,) if replica else ())
+        key = (B, H, W, device, dtype, self.keypoints_in_plan) + (("exact", float(self.exact_argmax_rel_bound)) if self.exact_in_plan else ()) + \
+            ((replica,) if replica else ())
         plan = self._plans.get(key)
         if plan is None:
             with torch.no_grad():
@@ -471,6 +490,69 @@ class DeconvResnet(HipModule):
         return h
 
     @torch.no_grad()
+    def exact_submit_plan(self, plan: "_PosePlan") -> "_PosePlan":
+        """exact_submit() for a caller that owns the plan (plan_for(..., replica) with `exact_in_plan` set, its x_static filled in
+        place): ONE graph replay — network, key-point rows, screen, gather, header copy — and an event.  The plan's buffers are the
+        step's state, so a plan must be finished (exact_finish_plan) before it is submitted again: callers that keep several steps
+        in flight rotate plan replicas."""
+        ex = getattr(plan, "exact", None)
+        if ex is None:
+            raise FlowtrackHipError("exact_submit_plan: the plan was built without exact_in_plan (fp16, keypoints_in_plan, B <= 1024)")
+        if ex["busy"]:
+            raise FlowtrackHipError("exact_submit_plan: this plan's previous step was not finished")
+        import ctypes
+        from .. import _lib
+        from ..hip_ops import check, current_stream_handle
+        lib = _lib.load()
+        if ex["event"] is None:
+            ev = ctypes.c_void_p()
+            check(lib.ft_event_create(ctypes.byref(ev)), "ft_event_create")
+            ex["event"] = ev
+        self.replay(plan)
+        check(lib.ft_event_record(ex["event"], current_stream_handle(plan.x_static.device)), "ft_event_record")
+        ex["busy"] = True
+        return plan
+
+    @torch.no_grad()
+    def exact_finish_plan(self, plan: "_PosePlan"):
+        """(plan.kp_rows with the flagged crops' rows replaced by the fp32 parity mode's, number of crops re-run)."""
+        from .. import _lib
+        from ..hip_ops import check
+        ex = plan.exact
+        if not ex["busy"]:
+            raise FlowtrackHipError("exact_finish_plan: nothing submitted")
+        check(_lib.load().ft_event_synchronize(ex["event"]), "ft_event_synchronize")
+        ex["busy"] = False
+        n = int(ex["header_host"][0])
+        if n:
+            B, _, H, W = plan.x_static.shape
+            self._rerun_flagged(ex["header_host"], ex["stage"], plan.kp_rows, n, B, H, W)
+        return plan.kp_rows, n
+
+    def _rerun_flagged(self, hdr, stage, rows, n, B, H, W):
+        """The n flagged crops (inputs staged in `stage`, indices in hdr[1:]) through the fp32 plan; their rows patched into `rows`."""
+        dev = rows.device
+        idx = hdr[1:1 + n].to(torch.int64).to(dev)
+        want, ex_flag = self.compute_dtype, self.exact_in_plan
+        self.compute_dtype, self.exact_in_plan = torch.float32, False
+        try:
+            lo = 0
+            while lo < n:
+                m = min(n - lo, B)
+                bucket = next(b for b in (8, 16, 32, 64, 128, 256, 1 << 30) if b >= m or b >= B)
+                bucket = min(bucket, max(B, 8))
+                xb = self.static_input(bucket, H, W)
+                take = min(m, bucket)
+                xb[:take].copy_(stage[lo:lo + take])
+                if take < bucket:
+                    xb[take:].zero_()
+                r32 = self.forward_keypoint_rows(xb)
+                rows.index_copy_(0, idx[lo:lo + take], r32[:take])
+                lo += take
+        finally:
+            self.compute_dtype, self.exact_in_plan = want, ex_flag
+
+    @torch.no_grad()
     def exact_finish(self, h: "_ExactHandle"):
         """Second half: (rows [B,K,3] with the parity mode's arg-max, number of crops re-run in fp32)."""
         if h.done:
@@ -486,25 +568,7 @@ class DeconvResnet(HipModule):
         n = int(hdr[0])
         h.done = True
         if n:
-            idx = hdr[1:1 + n].to(torch.int64).to(dev)
-            want = self.compute_dtype
-            self.compute_dtype = torch.float32
-            try:
-                lo = 0
-                while lo < n:
-                    m = min(n - lo, h.B)
-                    bucket = next(b for b in (8, 16, 32, 64, 128, 256, 1 << 30) if b >= m or b >= h.B)
-                    bucket = min(bucket, max(h.B, 8))
-                    xb = self.static_input(bucket, h.H, h.W)
-                    take = min(m, bucket)
-                    xb[:take].copy_(sl["stage"][lo:lo + take])
-                    if take < bucket:
-                        xb[take:].zero_()
-                    r32 = self.forward_keypoint_rows(xb)
-                    h.rows.index_copy_(0, idx[lo:lo + take], r32[:take])
-                    lo += take
-            finally:
-                self.compute_dtype = want
+            self._rerun_flagged(hdr, sl["stage"], h.rows, n, h.B, h.H, h.W)
         sl["busy"] = False
         return h.rows, n
 

@@ -448,6 +448,32 @@ def test_exact_argmax_submit_finish_equals_the_blocking_form(hip_lib):
                 m16.exact_finish(ha)
     finally:
         m16.exact_argmax_rel_bound = keep
+    # the same with the device side recorded INSIDE the plan's graph (exact_in_plan): plan replicas in rotation, finished one step late
+    m16.exact_in_plan = True
+    try:
+        for bound, lo, hi in ((0.0, 0, 0), (mid, 8, 56)):
+            m16.exact_argmax_rel_bound = bound
+            m16.exact_in_plan = False
+            want_a, na = m16.forward_keypoint_rows_exact(xa)
+            want_b, nb = m16.forward_keypoint_rows_exact(xb)
+            want_a, want_b = want_a.clone(), want_b.clone()
+            m16.exact_in_plan = True
+            pa, pb = m16.plan_for(64, 256, 192, 0), m16.plan_for(64, 256, 192, 1)
+            assert pa is not pb and pa.exact["rel_bound"] == bound
+            for rep in range(2):                         # second pass: the captured graph
+                pa.x_static.copy_(xa)
+                pb.x_static.copy_(xb)
+                m16.exact_submit_plan(pa)
+                m16.exact_submit_plan(pb)
+                with pytest.raises(Exception):
+                    m16.exact_submit_plan(pa)            # not finished yet
+                ra, ga = m16.exact_finish_plan(pa)
+                rb, gb = m16.exact_finish_plan(pb)
+                assert (ga, gb) == (na, nb), (bound, rep, ga, gb, na, nb)
+                assert torch.equal(ra, want_a) and torch.equal(rb, want_b), (bound, rep)
+    finally:
+        m16.exact_in_plan = False
+        m16.exact_argmax_rel_bound = keep
     # the gather alone: rows 3, 4, 17, 63 of 64 flagged
     import ctypes
     from flowtrack.pytorch_amd.hip_ops import current_stream_handle
