@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void heatmap_min_margin_kernel(const float* __
     float b = -INFINITY, s2 = -INFINITY;
     for (int i = threadIdx.x; i < HW; i += 256) {
       const float v = p[i];
-      if (v > b) { s2 = b; b = v; } else if (v > s2) s2 = v;
+      s2 = fmaxf(s2, fminf(b, v));          // (branch-free: see heatmap_argmax_screen_kernel)
+      b = fmaxf(b, v);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -229,22 +230,45 @@ __global__ __launch_bounds__(256) void heatmap_min_margin_kernel(const float* __
 //          or !(|top1| >= E)                    (max_preds zeroes the coordinates when score <= 0, evaluation.py:17-19: the mask can flip)
 //          or any non-finite statistic          (NaN compares false: written as negated >=)
 // stats[n] = (smallest margin, R, smallest |top1|, E).  K <= 256.
+// Round 5: a WAVE per map (the four waves of a crop's block walk its K maps in parallel, 16-byte loads when HW % 4 == 0, no
+// block barrier inside the walk; before: the whole block per map with two __syncthreads each: ~50 us for 64 crops x 17 maps on
+// 64 CUs, which is what the exact mode's "nothing flagged" path cost on top of the plain step).
 __global__ __launch_bounds__(256) void heatmap_argmax_screen_kernel(const float* __restrict__ hm, int K, int HW, float rel_bound,
                                                                     int32_t* __restrict__ flags, float* __restrict__ stats) {
   const int n = blockIdx.x;
-  __shared__ float s_b[4], s_s[4], s_m[4];
-  __shared__ float s_t1[256], s_t2[256];
-  float crop_max = -INFINITY, crop_min = INFINITY;
-  bool bad = false;
-  for (int k = 0; k < K; ++k) {
+  __shared__ float s_t1[256], s_t2[256], s_mn[256];
+  __shared__ int s_bad[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool nf = false;
+  for (int k = wave; k < K; k += 4) {
     const float* p = hm + ((size_t)n * K + k) * HW;
     float b = -INFINITY, s2 = -INFINITY, mn = INFINITY;
-    bool nf = false;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-      const float v = p[i];
+    auto take = [&](float v) {
+      // branch-free top-2 update: the if / else-if form (`if (v > b) { s2 = b; b = v; } else if (v > s2) s2 = v;`) was compiled
+      // into an indexed store to a two-element STACK array — a scratch load + store + vmcnt(0) per element, 10 us per map
       nf |= !(fabsf(v) <= 3.0e38f);
-      if (v > b) { s2 = b; b = v; } else if (v > s2) s2 = v;
+      s2 = fmaxf(s2, fminf(b, v));
+      b = fmaxf(b, v);
       mn = fminf(mn, v);
+    };
+    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      // eight 16-byte loads in flight per lane (one after the other the walk is load latency x loads: 73 us measured)
+      const float4_t* p4 = reinterpret_cast<const float4_t*>(p);
+      const int n4 = HW >> 2;
+      for (int i0 = 0; i0 < n4; i0 += 8 * 64) {
+        float4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 64 + lane;
+          v[u] = p4[i < n4 ? i : lane % n4];           // (tail: re-read a valid element, folded away below)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (i0 + u * 64 + lane < n4) { take(v[u][0]); take(v[u][1]); take(v[u][2]); take(v[u][3]); }
+        }
+      }
+    } else {
+      for (int i = lane; i < HW; i += 64) take(p[i]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -254,30 +278,18 @@ __global__ __launch_bounds__(256) void heatmap_argmax_screen_kernel(const float*
       b = nb;
       mn = fminf(mn, __shfl_xor(mn, off));
     }
-    bad |= __any(nf) != 0;
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();                  // (the previous map's partials have been read)
-    if ((threadIdx.x & 63) == 0) { s_b[wave] = b; s_s[wave] = s2; s_m[wave] = mn; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; ++w) {
-        const float nb = fmaxf(b, s_b[w]);
-        s2 = fmaxf(fminf(b, s_b[w]), fmaxf(s2, s_s[w]));
-        b = nb;
-        mn = fminf(mn, s_m[w]);
-      }
-      s_t1[k] = b;
-      s_t2[k] = s2;
-      crop_max = fmaxf(crop_max, b);
-      crop_min = fminf(crop_min, mn);
-    }
+    if (lane == 0) { s_t1[k] = b; s_t2[k] = s2; s_mn[k] = mn; }
   }
-  // every wave saw the same `bad` bits of ITS lanes only: fold the four waves through LDS
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = bad ? 1.f : 0.f;
+  const bool wbad = __any(nf) != 0;
+  if (lane == 0) s_bad[wave] = wbad ? 1 : 0;
   __syncthreads();
   if (threadIdx.x == 0) {
-    bool flag = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) > 0.f;
+    bool flag = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
+    float crop_max = -INFINITY, crop_min = INFINITY;
+    for (int k = 0; k < K; ++k) {
+      crop_max = fmaxf(crop_max, s_t1[k]);
+      crop_min = fminf(crop_min, s_mn[k]);
+    }
     const float R = crop_max - crop_min, E = rel_bound * R;
     float mmin = INFINITY, amin = INFINITY;
     for (int k = 0; k < K; ++k) {

@@ -13,13 +13,13 @@ for w in pose flow; do
   # kernel-level passes run the launch list in order (FT_NO_BRANCHES=1): inside parallel graph branches two kernels share
   # the GPU and each one's traced duration stretches, which is not what roofline.avg_launch_us (per-kernel, in order) means
   export FT_NO_BRANCHES=1
-  timeout 600 tools/dev/prof_trace.sh ${tag}_${w}_bench python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --fixed-warmup > /dev/null 2>&1
-  timeout 900 tools/dev/prof_traffic.sh ${tag}_${w} python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras --fixed-warmup
+  timeout 600 tools/dev/prof_trace.sh ${tag}_${w}_bench python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --fixed-warmup --rotate 1 > /dev/null 2>&1
+  timeout 900 tools/dev/prof_traffic.sh ${tag}_${w} python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras --fixed-warmup --rotate 1
   # forwards in that run: the first call runs the launch list twice eagerly (plain + after the tile picks), then 1
   # warm-up replay + 4 timed replays
   python tools/dev/pmc_traffic.py gpurun_out/traffic_${tag}_${w} 7 gpurun_out/${tag}_${w}_hbm_traffic_pmc.json
   # 4. MFMA-busy fraction per kernel (its own --pmc pass)
-  ( cd /tmp && export TMPDIR=/tmp && cd $R && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/mfma_${tag}_${w} -o pmc --output-format csv -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras --fixed-warmup > gpurun_out/mfma_${tag}_${w}.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && cd $R && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/mfma_${tag}_${w} -o pmc --output-format csv -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras --fixed-warmup --rotate 1 > gpurun_out/mfma_${tag}_${w}.log 2>&1 )
   python tools/dev/pmc_mfma.py gpurun_out/mfma_${tag}_${w} gpurun_out/${tag}_${w}_mfma_busy_pmc.json
   unset FT_NO_BRANCHES
 done
