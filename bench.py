@@ -316,7 +316,7 @@ def flow_op_rooflines(device, B=16, H=384, W=512, iters=20):
     torch.cuda.synchronize()
     prog.run_eager()
     prog.stream.synchronize()
-    times = prog.time_calls(iters=iters)
+    times = prog.time_calls(iters=iters, median=True)
     px = B * H * W
     algo = {
         # fp16 NHWC: two [B,256,48,64] feature maps in, 441 channels out (5.86 MB / pair)

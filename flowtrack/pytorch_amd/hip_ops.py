@@ -384,8 +384,9 @@ class Program:
             self.run_eager()
 
     @_on_plan_device
-    def time_calls(self, iters: int = 5, repeat_hot: bool = False):
-        """Per-call hipEvent timing on the program's stream (eager). Returns [(name, ms_avg)].
+    def time_calls(self, iters: int = 5, repeat_hot: bool = False, median: bool = False):
+        """Per-call hipEvent timing on the program's stream (eager). Returns [(name, ms_avg)] (median: the per-call MEDIAN over
+        the iterations instead of the mean — one stalled iteration of a 12-us kernel otherwise shows as 80 us).
         repeat_hot (dev): every call is launched TWICE in a row and the second launch is the one timed — its weights and
         inputs are as warm in L2 as they can be; against the plain numbers this shows what a layer pays for arriving cold."""
         self._ensure_workspace()
@@ -396,6 +397,7 @@ class Program:
             check(lib.ft_event_create(ctypes.byref(e)), "ft_event_create")
             evs.append(e)
         acc = [0.0] * len(self.calls)
+        samples = [[] for _ in self.calls]
         for _ in range(iters):
             with torch.cuda.stream(self.stream):
                 torch.cuda._sleep(4_000_000)   # device-side head start: the intervals below hold no host launch latency
@@ -428,8 +430,11 @@ class Program:
                 ms = ctypes.c_float()
                 check(lib.ft_event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
                 acc[i] += ms.value
+                samples[i].append(ms.value)
         for e in evs:
             lib.ft_event_destroy(e)
+        if median and not repeat_hot:
+            return [(self.calls[i][0], sorted(samples[i])[len(samples[i]) // 2]) for i in range(len(self.calls))]
         return [(self.calls[i][0], acc[i] / iters) for i in range(len(self.calls))]
 
     @_on_plan_device
