@@ -591,7 +591,12 @@ class FlowNet2S(FlowNetS, _FlowBase):
         return _FlowPlan(prog, x_static, out)
 
     def _fold_supported(self, B: int, H: int, W: int, dtype, pad: int = 3) -> bool:
-        """Whether conv1 on the padded view runs on the one kernel that takes a per-sample shift (fp16, large enough grids)."""
+        """Whether conv1 on the padded view runs on the one kernel that takes a per-sample shift (fp16, large enough grids).
+        NOTE: the fold therefore depends on the BATCH — one 384 x 512 pair (384 stem tiles) takes the two-launch path
+        (mean, then pack of the centred input), two or more pairs take the fold, which rounds the input to fp16 BEFORE the mean is
+        removed and enters mean / rgb_max as its fp16 value.  The flows of one pair at batch 1 and at batch >= 2 so differ at
+        fp16-rounding level (both within the fp16 mode's EPE bound, tests/test_flow_gpu.py); FT_MEAN_FOLD=0 pins the two-launch
+        path for every batch size."""
         if dtype != torch.float16 or W % 4:
             return False
         d = _lib.ConvDesc()
