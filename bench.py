@@ -662,6 +662,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("FT_DIST_BACKEND") == "gloo":           # dry run of the N > 1 code on fewer GPUs than ranks (parallel.init_from_env)
+        local_rank %= torch.cuda.device_count()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dtype = torch.float16 if args.dtype == "fp16" else torch.float32
