@@ -1045,6 +1045,12 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v
   reinterpret_cast<float4_t*>(p)[1] = b;
 }
 
+#ifndef FT_WARP_STORE_SC1
+#define FT_WARP_STORE_SC1 0
+#endif
+#ifndef FT_WARP_STORE_LINES
+#define FT_WARP_STORE_LINES 1     // fp16 output: whole-line stores after a lane exchange (-DFT_WARP_STORE_LINES=0: round 4's two strided pieces)
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void flow_warp_concat_kernel(const T* __restrict__ x6, const float* __restrict__ flow,
                                                                float div_flow, T* __restrict__ y, int H, int W, int xl,
@@ -1091,8 +1097,45 @@ __global__ __launch_bounds__(256) void flow_warp_concat_kernel(const T* __restri
       lo[0] = c[0]; lo[1] = c[1]; lo[2] = c[2]; lo[3] = c[3]; lo[4] = c[4]; lo[5] = c[5]; lo[6] = warp[0]; lo[7] = warp[1];
       hi[0] = warp[2]; hi[1] = dx / div_flow; hi[2] = dy / div_flow; hi[3] = sqrtf(nrm);
     }
-    st8<T>(y + i * 16, lo);
-    st8<T>(y + i * 16 + 8, hi);
+#if FT_WARP_STORE_LINES
+    if constexpr (std::is_same<T, half_t>::value) {
+      // A pixel's 32 output bytes leave as two 16-byte pieces; written straight from the pixel's lane a wave's store touches
+      // every other 16 bytes of 2 KB (half of 16 lines, twice).  Round 5: the lanes trade pieces first (ds_bpermute), so that
+      // store s writes ONE contiguous KiB = pixels 32 s .. 32 s + 31 whole (lane l: pixel 32 s + l / 2, piece l % 2).  Needs
+      // the wave's 64 pixels consecutive in memory: true here (thread = physical pixel, whole wave inside `total`, else fallback).
+      half8_t hl, hh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hl[e] = (half_t)lo[e]; hh[e] = (half_t)hi[e]; }
+      const uint4_t vl = __builtin_bit_cast(uint4_t, hl), vh = __builtin_bit_cast(uint4_t, hh);
+      const int lane = threadIdx.x & 63;
+      const size_t wave_first = i - lane;
+      if (wave_first + 64 <= total) {                      // wave-uniform
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const int src = (lane >> 1) + 32 * sidx;
+          uint4_t a, b;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = (unsigned)__shfl((int)vl[e], src);
+            b[e] = (unsigned)__shfl((int)vh[e], src);
+          }
+          const uint4_t v = (lane & 1) ? b : a;
+#if FT_WARP_STORE_SC1
+          store_out16(y + (wave_first + 32 * sidx) * 16 + lane * 8, v);
+#else
+          *reinterpret_cast<uint4_t*>(y + (wave_first + 32 * sidx) * 16 + lane * 8) = v;
+#endif
+        }
+      } else {
+        *reinterpret_cast<uint4_t*>(y + i * 16) = vl;
+        *reinterpret_cast<uint4_t*>(y + i * 16 + 8) = vh;
+      }
+    } else
+#endif
+    {
+      st8<T>(y + i * 16, lo);
+      st8<T>(y + i * 16 + 8, hi);
+    }
   }
 }
 
