@@ -412,3 +412,24 @@ def test_mean_fold_algebra_and_support_query(hip_lib):
     assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(16, 384, 512, shift_nstride=62))) == _lib.FT_ERR_UNSUPPORTED
     assert hip_lib.ft_conv_shift_nstride_supported(ctypes.byref(fold_desc(16, 384, 512, pool=1))) == _lib.FT_ERR_UNSUPPORTED
     assert int(hip_lib.ft_flow_pack_pair_sums_chunks(384)) == 96 and int(hip_lib.ft_flow_pack_pair_sums_chunks(50)) == 13
+
+
+def test_bench_line_summary_is_flat_and_last():
+    """bench.py's `summary` (round 5): a flat object of the sub-records' headline numbers, added as the LAST key of the line so that
+    the driver's stdout tail holds them; missing sub-records simply do not appear."""
+    import json
+    import bench
+    out = {"value": 56000.0, "roofline": {"frac": 0.245}, "same_batch_replay": {"value": 55900.0},
+           "flow": {"value": 19000.0, "roofline": {"frac": 0.25}, "cpu_baseline": {"value": 30.0},
+                    "roofline_ops": [{"kernel": "ft_channelnorm_fwd", "frac": 0.55}, {"kernel": "ft_resample2d_fwd_smooth_flow", "frac": 0.32}]},
+           "c3_per_gpu": {"value": 11300.0, "roofline": {"frac": 0.185}},
+           "parity": {"fp16": {"argmax_identical_frac": 0.99, "heatmap_max_abs_err": 0.0026, "mAP_at_OKS": 0.99}, "fp32": {"argmax_identical_frac": 1.0}},
+           "fp16_exact_argmax": {"value": 8500.0, "no_rerun_path": {"value": 52000.0}, "no_rerun_path_in_graph": {"value": 55000.0}},
+           "rccl": {"world": 8, "ranks_verified": 8}}
+    s = bench.summary_of(out)
+    assert s["pose_crops_s"] == 56000.0 and s["flow_frac"] == 0.25 and s["c3_frac"] == 0.185 and s["rccl_ranks_verified"] == 8
+    assert s["channelnorm_frac"] == 0.55 and s["resample2d_smooth_flow_frac"] == 0.32 and s["exact_no_rerun_in_graph_crops_s"] == 55000.0
+    assert "clip_frames_s" not in s and all(not isinstance(v, (dict, list)) for v in s.values())
+    out["summary"] = s
+    line = json.dumps(out, separators=(",", ":"))
+    assert line.rstrip("}").rsplit('"summary":', 1)[1].startswith("{") and len(line) < 4000
