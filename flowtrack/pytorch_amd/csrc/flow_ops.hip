@@ -839,7 +839,7 @@ constexpr int kRsMaxWindow = 6656;                         // window floats per 
 template <int C>
 __global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __restrict__ in1, const float* __restrict__ flow,
                                                                 float* __restrict__ out, int H, int W, int tiles_x, int tiles_y,
-                                                                unsigned in_bytes) {
+                                                                unsigned in_bytes, int wbudget) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) float rs_smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __r
   if (vec4) bx0 &= ~3;
   const int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
   const int pitch = ww <= 64 ? 64 : (ww <= 128 ? 128 : (ww <= 256 ? 256 : ((ww + 255) & ~255)));   // floats per LDS row: a power of two up to 256
-  const bool fits = (((long long)pitch * wh + 255) & ~255LL) <= kRsMaxWindow;
+  const bool fits = (((long long)pitch * wh + 255) & ~255LL) <= wbudget;
   if (fits) {
     // the window of every plane through LDS-DMA, straight into LDS (no VGPR round trip, every piece in flight at once: the tile's
     // latency is ONE memory round trip, not one per row).  A wave instruction moves 1 KiB = 256 consecutive LDS floats = 256 / pitch
@@ -1363,12 +1363,21 @@ extern "C" int ft_resample2d_fwd(const float* in1, const float* flow, float* out
     const long long nblk = (long long)B * tiles_x * tiles_y;
     if (nblk <= 0x7fffffffLL) {
       const dim3 grid((unsigned)nblk);
-      const size_t lds = (size_t)C * kRsMaxWindow * sizeof(float);
+      // window budget per plane (floats): the LDS a workgroup reserves = C x budget x 4 bytes decides how many workgroups share a CU
+      // (26 KiB per plane: two; 9 KiB: five); tiles whose window exceeds it take the pair gathers.  FT_RESAMPLE_WBUDGET (dev A/B)
+      // Round 5, same box, configs[3] shapes (noise = per-pixel N(0, 4 px) flows, smooth = a 12 x 16 grid of N(0, 6 px) vectors upsampled):
+      //   budget 6656 (26 KiB per plane, 2 workgroups per CU): noise 45.5 us, smooth 39.7 us
+      //   budget 3328 (13 KiB, 4 per CU):                      noise 56.4 us (every tile falls back), smooth 32.3 us
+      //   budget 2304 / 1536:                                   noise 55.8 / 55.1, smooth 35.6 / 37.0
+      // Flow fields that reach this operator are network outputs (smooth): 3328 is the default.
+      static const int wb_env = getenv("FT_RESAMPLE_WBUDGET") ? atoi(getenv("FT_RESAMPLE_WBUDGET")) : 0;
+      const int wbudget = wb_env >= 256 && wb_env <= kRsMaxWindow ? (wb_env & ~255) : 3328;
+      const size_t lds = (size_t)C * wbudget * sizeof(float);
 #define FT_RS_LAUNCH(CC)                                                                                                   \
   {                                                                                                                        \
     auto kw = resample2d_window_kernel<CC>;                                                                                \
     if (lds > 64 * 1024) FT_RAISE_LDS(kw, 112 * 1024);                                                                     \
-    hipLaunchKernelGGL(kw, grid, dim3(256), lds, as_stream(stream), in1, flow, out, H, W, tiles_x, tiles_y, (unsigned)in_bytes); \
+    hipLaunchKernelGGL(kw, grid, dim3(256), lds, as_stream(stream), in1, flow, out, H, W, tiles_x, tiles_y, (unsigned)in_bytes, wbudget); \
   }
       switch (C) {
         case 1: FT_RS_LAUNCH(1) break;
