@@ -508,3 +508,62 @@ def test_fused_bottleneck_rejects_other_blocks(hip_lib):
     assert hip_lib.ft_bottleneck_supported(ctypes.byref(d)) == 2
     d.dtype = _lib.FT_F16
     assert hip_lib.ft_bottleneck_supported(ctypes.byref(d)) == 0
+
+
+# bottleneck_rstat_kernel (register-stationary strips, csrc/bottleneck_rstat.hip): (name, N, H, W, x channel stride, x channel offset, rows per strip)
+RSTAT_CASES = [
+    ("rs_r50_b4_16rows", 4, 64, 48, 256, 0, 16),       # the benchmarked strip shape: 16 rows x 48 = 12 steps, halo rows on both sides
+    ("rs_r50_b2_whole", 2, 64, 48, 256, 0, 64),        # one strip per image: both halo rows outside the image
+    ("rs_ragged_13x20", 3, 13, 20, 256, 0, 5),         # 5 + 5 + 3 rows, 100 pixels per strip: last step ragged
+    ("rs_tiny_5x3", 1, 5, 3, 256, 0, 5),               # 15 pixels: one step, every lane on an x border somewhere
+    ("rs_view_offset", 1, 16, 16, 320, 32, 7),         # input is a channel slice of a wider buffer
+    ("rs_wide_62", 2, 9, 62, 256, 0, 4),               # the widest supported row (T1 ring span 254 of 256)
+    ("rs_width_33", 2, 20, 33, 256, 0, 0),             # odd width, the library's own strip height
+    ("rs_recycle_b40", 40, 64, 48, 256, 0, 8),         # 320 workgroups: a second round on 256 CUs (LDS reuse across workgroups)
+]
+
+
+@pytest.mark.parametrize("case", RSTAT_CASES, ids=[c[0] for c in RSTAT_CASES])
+def test_register_stationary_strip_form_is_bit_identical_to_the_patch_form(hip_lib, case, monkeypatch):
+    """FT_BNK_RSTAT = 2 runs bottleneck_rstat_kernel wherever the shape fits (FT_BNR_SR = rows per strip), 0 the patch kernel:
+    same operand layouts, same K order, same epilogue expressions -> the same bits; and both within tolerance of the oracle."""
+    name, N, H, W, xcs, xoff, sr = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 29
+    P, C = 64, 256
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+    t2 = F.relu(_bnf(F.conv2d(t1, w2, padding=1), bn2))
+    want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + x)
+    mk = dict(dtype=dtype, device=dev, act="relu")
+    c1 = FusedConv(w1, bn=bn1, label="conv1", **mk)
+    c2 = FusedConv(w2, pad=1, bn=bn2, label="conv2", **mk)
+    c3 = FusedConv(w3, bn=bn3, label="conv3", **mk)
+    xv = nchw_to_view(x, dtype, dev, cstride=xcs, coff=xoff)
+    if xoff:
+        xv.t[..., :xoff] = 7.0
+    outs = {}
+    for mode in (2, 0):
+        monkeypatch.setenv("FT_BNK_RSTAT", str(mode))
+        if sr:
+            monkeypatch.setenv("FT_BNR_SR", str(sr))
+        y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
+        prog = make_program()
+        record_bottleneck(prog, c1, c2, c3, xv, y, name)
+        assert prog.calls[0][0] == "ft_bottleneck_fwd"
+        run_program(prog)
+        got = view_to_nchw(y)
+        assert torch.all(y.t[..., :32] == 3.0), "channels outside the output slice were written"
+        for _ in range(3):                       # same bits on every run (poisoned output first)
+            y.t.fill_(5.0)
+            run_program(prog)
+            assert torch.equal(view_to_nchw(y), got), f"{name} mode {mode}: two runs differ"
+        outs[mode] = got
+    scale = max(1.0, want.abs().max().item())
+    err = (outs[2] - want).abs().max().item()
+    assert err <= 2e-2 * scale, f"{name}: strip form vs oracle max abs err {err:.3e} (scale {scale:.2f})"
+    nbad = (outs[2] != outs[0]).sum().item()
+    assert nbad == 0, f"{name}: strip form differs from the patch form in {nbad} of {outs[0].numel()} values (max {(outs[2] - outs[0]).abs().max().item():.3e})"
