@@ -94,6 +94,9 @@ _PROTOTYPES = {
     "ft_bottleneck_supported": (c_int, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_flops": (c_double, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_rstat_supported": (c_int, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_rstat_weight_bytes": (ctypes.c_longlong, []),
+    "ft_bottleneck_rstat_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_stream_supported": (c_int, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_stream_weight_bytes": (ctypes.c_longlong, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_stream_pack": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(HERE, "libflowtrack_hip.so")
 STAMP_PATH = os.path.join(HERE, ".libflowtrack_hip.stamp")
 
 SOURCES = ["conv_igemm.hip", "conv_igemm8.hip", "bottleneck.hip", "bottleneck_rstat.hip", "bottleneck_stream.hip", "bottleneck_cluster.hip", "conv_direct.hip", "conv_wstat.hip", "aux_ops.hip", "flow_ops.hip", "crop_ops.hip", "runtime.hip"]
-HEADERS = [os.path.join(CSRC, "ft_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_wstat.h"), os.path.join(CSRC, "bottleneck_rstat.h"), os.path.join(INCLUDE, "flowtrack_hip.h")]
+HEADERS = [os.path.join(CSRC, "ft_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_wstat.h"), os.path.join(INCLUDE, "flowtrack_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -29,7 +29,6 @@
 
 #include <type_traits>
 
-#include "bottleneck_rstat.h"
 #include "ft_common.h"
 
 // cache-policy bits of the block input's LDS-DMA loads (read once per workgroup + its halo neighbours): 0 = default, 2 = nt (A/B
@@ -557,10 +556,6 @@ extern "C" int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x, con
   const int st = supported(d);
   if (st != FT_OK) return st;
   if (!x || !w1 || !w2 || (!w3 && !d->head_only) || !scale_shift || !y) return FT_ERR_INVALID_ARG;
-  {   // identity blocks on maps up to 62 wide with enough pixels per CU: the register-stationary strip form (bottleneck_rstat.hip)
-    BnrPlan pl;
-    if (bnr_plan(d, &pl) == FT_OK) return bnr_launch(d, pl, x, w1, w2, w3, scale_shift, y, as_stream(stream));
-  }
   BnkParams p{};
   p.x = static_cast<const char*>(x);
   p.y = static_cast<char*>(y);

@@ -3,29 +3,38 @@
 // (reference: Bottleneck.forward, lib/pose/models/blocks.py:105-120; layer1.1 / layer1.2 of resnet.py:29-36).  gfx950 only.
 //
 // Why a second form beside bottleneck_fused_kernel (bottleneck.hip).  That kernel owns a 128-pixel patch per workgroup: every
-// patch pulls its 136 KB of weights through L2 -> LDS again, computes conv1 on a 1.5x halo, has its x loads in flight only
-// during one of its three phases and reads 1.5 KB of LDS per MFMA; with no memory traffic at all it still takes 41 us per
-// block at batch 64 (FT_BNK_DBG ablations), against an HBM floor of ~34 us (100 MB in, 100 MB out).  Here:
+// patch pulls its 136 KB of weights through L2 -> LDS again (58 LDS-DMA pieces per wave and patch), computes conv1 on a 1.5x halo
+// and has its x loads in flight only during one of its three phases; with no memory traffic at all it still takes 41 us per block at
+// batch 64 (FT_BNK_DBG ablations) against an HBM floor of ~34 us (100 MB in, 100 MB out).  What bounds BOTH forms without memory
+// is instruction ISSUE: a SIMD issues one instruction per ~4 cycles whatever the number of waves (measured here with per-section
+// s_memtime sums against the ISA's instruction counts: 8 cycles per instruction per wave at two waves per SIMD) and of the ~1300
+// instructions per 64 pixels and SIMD only 68 are MFMAs.  So this form is built around the instruction count:
 //   * ONE 8-wave workgroup per CU owns a STRIP of SR full-width rows of one image (batch 64, 64 x 48 maps: 16 rows, 256 strips)
 //     and walks it in steps of 64 consecutive pixels (row-major, flat: a 3x3 tap is a shift by dy * W + dx in a flat ring);
 //     conv1's halo is the row above / below the strip, computed once (1.12x at 16 rows), nothing is recomputed between steps.
-//   * The 139 KB of weights are loaded ONCE per workgroup and stay in registers as MFMA A operands: the waves are two GROUPS,
-//     G0 (waves 0-3) holds W1 and W3 (its wave (nt, pt): channel tile nt of conv1 / channel tiles 4 nt .. 4 nt + 3 of conv3,
-//     pixel tile pt), G1 (waves 4-7) holds W2 (channel tile nt, pixel tile pt: 36 fragments = 144 registers).  One wave of
-//     each group per SIMD: while G0 runs its epilogues (80 results per lane and step) G1's 36 MFMAs own the matrix pipe.
+//   * The weights are loaded ONCE per workgroup and stay in registers as MFMA A operands: the waves are two GROUPS, G0 (waves 0-3)
+//     holds W1 and W3 (its wave (nt, pt): channel tile nt of conv1 / channel tiles 4 nt .. 4 nt + 3 of conv3, pixel tile pt), G1
+//     (waves 4-7) holds W2 (channel tile nt, pixel tile pt).  One wave of each group per SIMD.
+//   * The epilogues are (almost) gone: the BatchNorm SCALE is folded into the fp16 weights (from the fp32 master weights: one
+//     rounding, as before), the SHIFT enters through one extra MFMA k-step (A = [hi(shift) lo(shift) 0 ...], B = [1 1 0 ...]: exact to
+//     22 bits) that also replaces the accumulator's zero fill, and the RESIDUAL is two more k-steps against an identity fragment
+//     (x * 1.0 accumulates exactly).  What is left per result pair is v_cvt_pk_f16_f32 + v_pk_max_f16 (relu(fp16(v)) == fp16(relu(v))).
+//     No scale / shift table, no fp16 -> fp32 conversions, no per-value VALU multiply.
 //   * Software pipeline, ONE s_barrier per step.  Iteration i:  G0: conv3(step i - 1) from T2 + residual -> y; then the
 //     residual fetch of step i; then conv1(step i + 2) from the x ring -> T1 ring.   G1: LDS-DMA of x(step i + 3) into the
 //     ring (+ an L2 touch of step i + 6: the demand load one iteration ahead then hits L2), conv2(step i) from T1 -> T2.
 //   * x ring: two 32-KiB step buffers (64 pixels x 512 B, 16-byte chunks XOR-ed with pixel & 15 on the SOURCE side of the
-//     DMA: conflict-free ds_read_b128 fragments).  T1: a 256-pixel flat ring of 128-byte rows (live span 2 W + 130 pixels:
-//     W <= 62).  T2: two 64-pixel tiles.  The residual does not wait in LDS for three steps: each G0 wave DMAs its own
-//     32-pixel x 128-channel piece of x again (an L2 hit) into a wave-private 8-KiB tile, adds it in the accumulator layout,
-//     writes y in place and stores the tile as whole 16-byte pieces (256 contiguous bytes per pixel).
+//     DMA: conflict-free ds_read_b128 fragments).  T1: a 256-pixel flat ring, T2: two 64-pixel tiles, both with 144-byte rows
+//     (128 + 16: sixteen consecutive rows land on sixteen distinct 16-byte bank slots, and a fragment's k-step is an instruction
+//     offset instead of an XOR).  T1's live span is 2 W + 130 pixels: W <= 62.  The residual does not wait in LDS for three steps:
+//     each G0 wave DMAs its own 32-pixel x 128-channel piece of x again (an L2 hit) into a wave-private 8-KiB tile, multiplies it
+//     in as B fragments, writes y in place and stores the tile as whole 16-byte pieces (256 contiguous bytes per pixel).
 //   * Every in-loop LDS access is inline asm with hand-placed lgkmcnt waits (hipcc puts `s_waitcnt vmcnt(0)` in front of
 //     compiler-visible LDS accesses while an LDS-DMA is in flight: conv_wstat.hip).
-// Same operand layouts, same K order, same epilogue expressions as bottleneck_fused_kernel: the results are bit-identical.
-#include "bottleneck_rstat.h"
-
+// Weight buffer (ft_bottleneck_rstat_fwd's `wpack`, built by the caller once per weight set; fp16):
+//   [64][272]  conv1: w1[co][ci] * scale1[co], then 16 columns {hi(shift1[co]), lo(shift1[co]), 0 x 14}
+//   [64][592]  conv2: w2[co][(ky * 3 + kx) * 64 + ci] * scale2[co], then the 16 shift columns
+//   [256][80]  conv3: w3[co][ci] * scale3[co], then the 16 shift columns         (hi = fp16(shift), lo = fp16(shift - hi))
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -34,12 +43,18 @@ namespace ft {
 namespace {
 
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+struct BnrPlan {
+  int SR;   // rows per strip
+  int S;    // strips per image
+};
 
 struct BnrParams {
   const char* x;
   char* y;
-  const char *w1, *w2, *w3;
-  const float* tab;  // [s1 64 | b1 64 | s2 64 | b2 64 | s3 256 | b3 256]
+  const char* wp;
   int N, H, W;
   int SR, S;         // rows per strip, strips per image
   int x_cstride, x_coff, y_cstride, y_coff;
@@ -48,15 +63,19 @@ struct BnrParams {
   int dbg;           // FT_BNR_DBG (dev): 1 no x / residual loads, 4 no stores, 8 no L2 touch, 32 per-wave cycle counts
 };
 
+constexpr int kK1 = 272, kK2 = 592, kK3 = 80;                       // packed row lengths (halves)
+constexpr int kW1Bytes = 64 * kK1 * 2, kW2Bytes = 64 * kK2 * 2, kW3Bytes = 256 * kK3 * 2;
 constexpr int kXB = 32768;        // one step of x: 64 pixels x 512 B
+constexpr int kRow = 144;         // T1 / T2 row pitch
 constexpr int kOffX = 0;          // two step buffers
 constexpr int kOffStg = 65536;    // four wave-private 8-KiB residual / output tiles (32 pixels x 256 B)
-constexpr int kOffT1 = 98304;     // 256-slot flat ring x 128 B
-constexpr int kOffT2 = 131072;    // two 64-pixel x 128-B tiles
-constexpr int kOffTab = 147456;   // 3 KiB folded-BN table
-constexpr int kOffZero = 150528;  // 64 B of zeros (x-border taps)
-constexpr int kOffScr = 150592;   // 1 KiB scratch of the L2 touch loads
-constexpr int kLds = 151616;
+constexpr int kOffT1 = 98304;     // 256-slot flat ring x 144 B
+constexpr int kOffT2 = kOffT1 + 256 * kRow;    // two 64-pixel tiles x 144 B
+constexpr int kT2B = 64 * kRow;
+constexpr int kOffZero = kOffT2 + 2 * kT2B;    // 128 B of zeros (x-border taps: all four k-steps of a tap at 32-byte offsets)
+constexpr int kOffScr = kOffZero + 128;        // 1 KiB scratch of the L2 touch loads
+constexpr int kLds = kOffScr + 1024;
+static_assert(kLds <= 163840, "LDS");
 
 #define BNR_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -64,46 +83,37 @@ __device__ __forceinline__ void rd128(uint4_t& v, unsigned a) { asm volatile("ds
 template <int OFF>
 __device__ __forceinline__ void rd128o(uint4_t& v, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); }
 template <int OFF>
-__device__ __forceinline__ void rd128fo(float4_t& v, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); }
-__device__ __forceinline__ void rd64(uint2_t& v, unsigned a) { asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a)); }
+__device__ __forceinline__ void wr64o(unsigned a, uint2_t v) { asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
 __device__ __forceinline__ void wr64(unsigned a, uint2_t v) { asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory"); }
 // counted LDS waits that carry the registers they release (no MFMA / VALU use can move above them)
+template <int N>
+__device__ __forceinline__ void wait2(uint4_t (&f)[2]) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N)); }
 template <int N>
 __device__ __forceinline__ void wait4(uint4_t (&f)[4]) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N)); }
 template <int N>
 __device__ __forceinline__ void wait8(uint4_t (&f)[8]) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N));
 }
-__device__ __forceinline__ void wait_tab(float4_t (&sc)[4], float4_t (&sh)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]));
+__device__ __forceinline__ float16_t mfma(const uint4_t& a, const uint4_t& b, const float16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ void wait_res(float4_t (&sc)[4], float4_t (&sh)[4], uint2_t (&rs)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(rs[0]), "+v"(rs[1]),
-                 "+v"(rs[2]), "+v"(rs[3]));
-}
-
-typedef float float2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-// relu(fp16(v)) == fp16(relu(v)) (rounding is monotonic and keeps the sign); packed: v_cvt_pk_f16_f32 + v_pk_max_f16.  A negative
-// value that rounds to -0 comes out as a zero of either sign: equal as a number.
-__device__ __forceinline__ half2_t relu2(float2_t v) {
-  const half2_t h = __builtin_convertvector(v, half2_t);
-  return __builtin_elementwise_max(h, half2_t{(half_t)0.f, (half_t)0.f});
-}
-// accumulator registers 4 g .. 4 g + 3 -> relu(acc * scale + shift) as four fp16 (two v_pk_fma_f32)
-__device__ __forceinline__ uint2_t epi4(const float16_t& acc, const float4_t& sc, const float4_t& sh, int g) {
+// accumulator registers 4 g .. 4 g + 3 -> relu as four fp16.  relu(fp16(v)) == fp16(relu(v)) (rounding is monotonic and keeps the
+// sign); a negative value that rounds to -0 comes out as a zero of either sign: equal as a number.
+__device__ __forceinline__ uint2_t relu4(const float16_t& acc, int g) {
   half4_t hv;
 #pragma unroll
   for (int e2 = 0; e2 < 2; ++e2) {
     const float2_t a = {acc[g * 4 + e2 * 2], acc[g * 4 + e2 * 2 + 1]};
-    const float2_t k = {sc[e2 * 2], sc[e2 * 2 + 1]}, b = {sh[e2 * 2], sh[e2 * 2 + 1]};
-    const half2_t o = relu2(__builtin_elementwise_fma(a, k, b));
-    hv[e2 * 2] = o[0];
-    hv[e2 * 2 + 1] = o[1];
+    const half2_t h = __builtin_elementwise_max(__builtin_convertvector(a, half2_t), half2_t{(half_t)0.f, (half_t)0.f});
+    hv[e2 * 2] = h[0];
+    hv[e2 * 2 + 1] = h[1];
   }
   return __builtin_bit_cast(uint2_t, hv);
 }
+
+// wt[] slots.  G0: 0..15 W1 k-steps, 16 its shift step; 17 + 5 mt + kk: W3 channel tile mt, k-step kk (kk = 4: shift step);
+// 37, 38 the identity halves.  G1: 0..35 W2 k-steps (4 per tap), 36 its shift step.
+constexpr int kNW = 39;
 
 __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -135,54 +145,60 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
 
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, 64 * 256 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, 64 * 576 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, 256 * 64 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.wp), 0, kW1Bytes + kW2Bytes + kW3Bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
   // ---- this wave's weights, MFMA A fragments (lane (m = l31, lhi): 8 halves k = 16 s + 8 lhi .. of row m) ----------------
-  // G0: wt[0..15] = W1 rows nt * 32 + m, k-steps 0..15; wt[16 + 4 mt + kk] = W3 rows (4 nt + mt) * 32 + m, k-step kk.
-  // G1: wt[4 tap + kk] = W2 rows nt * 32 + m, k = tap * 64 + 16 kk ...
-  uint4_t wt[36];
+  uint4_t wt[kNW];
   if (grp == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) wt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w1, (unsigned)(((nt * 32 + l31) * 256 + k * 16 + lhi * 8) * 2), 0, 0);
+    for (int k = 0; k < 17; ++k) wt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(((nt * 32 + l31) * kK1 + k * 16 + lhi * 8) * 2), 0, 0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      wt[16 + k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w3, (unsigned)((((nt * 4 + (k >> 2)) * 32 + l31) * 64 + (k & 3) * 16 + lhi * 8) * 2), 0, 0);
+    for (int k = 0; k < 20; ++k)
+      wt[17 + k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(kW1Bytes + kW2Bytes + (((nt * 4 + k / 5) * 32 + l31) * kK3 + (k % 5) * 16 + lhi * 8) * 2), 0, 0);
+    // identity halves: row m, k-step s holds 1.0 at k = m - 16 s
 #pragma unroll
-    for (int k = 32; k < 36; ++k) wt[k] = uint4_t{0u, 0u, 0u, 0u};
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int e = l31 - s2 * 16 - lhi * 8;                  // position 0..7 inside this lane's 8 halves, if any
+      uint4_t id = {0u, 0u, 0u, 0u};
+      const unsigned one = (e & 1) ? 0x3C000000u : 0x00003C00u;
+      if (e >= 0 && e < 8) {
+        id.x = (e >> 1) == 0 ? one : 0u;
+        id.y = (e >> 1) == 1 ? one : 0u;
+        id.z = (e >> 1) == 2 ? one : 0u;
+        id.w = (e >> 1) == 3 ? one : 0u;
+      }
+      wt[37 + s2] = id;
+    }
   } else {
 #pragma unroll
-    for (int k = 0; k < 36; ++k)
-      wt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w2, (unsigned)(((nt * 32 + l31) * 576 + (k >> 2) * 64 + (k & 3) * 16 + lhi * 8) * 2), 0, 0);
+    for (int k = 0; k < 37; ++k) wt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(kW1Bytes + ((nt * 32 + l31) * kK2 + k * 16 + lhi * 8) * 2), 0, 0);
+    wt[37] = wt[38] = uint4_t{0u, 0u, 0u, 0u};
   }
-  // folded-BN table and the zero row (plain accesses: no LDS-DMA is in flight yet)
-  if (tid < 192) *reinterpret_cast<float4_t*>(smem + kOffTab + tid * 16) = *reinterpret_cast<const float4_t*>(p.tab + tid * 4);
-  if (tid >= 192 && tid < 196) *reinterpret_cast<uint4_t*>(smem + kOffZero + (tid - 192) * 16) = uint4_t{0u, 0u, 0u, 0u};
+  // B fragment of the shift step: k = 0 and 1 are 1.0 for every pixel
+  uint4_t ones = {lhi == 0 ? 0x3C003C00u : 0u, 0u, 0u, 0u};
+  if (tid < 8) *reinterpret_cast<uint4_t*>(smem + kOffZero + tid * 16) = uint4_t{0u, 0u, 0u, 0u};      // (no LDS-DMA is in flight yet)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   // ... and the compiler has to know the weights are there (it cannot see the wait above and would guard their first in-loop
   // use with a vmcnt(0) of its own: the whole x stream)
 #pragma unroll
-  for (int k = 0; k < 36; ++k) asm volatile("" : "+v"(wt[k]));
+  for (int k = 0; k < kNW; ++k) asm volatile("" : "+v"(wt[k]));
   BNR_BARRIER();
 
   // ---- per-lane constants -----------------------------------------------------------------------------------------------
   // Few bases, everything else derived from them by ONE VALU operation or an instruction offset at the point of use; each
-  // iteration passes the bases through an empty asm so that hipcc does not hoist the ~120 derived addresses out of the loop
-  // (it did, and spilled them: 167 scratch registers in the first version).
+  // iteration passes the bases through an empty asm so that hipcc does not hoist the derived addresses out of the loop (it
+  // did, and spilled them: 167 scratch registers in the first version).  The two groups need different constants: ONE set of
+  // registers, named per group below.
   int ptile = pt * 32 + l31;                                    // this lane's pixel inside a step (B-fragment row)
-  unsigned tab_a = lds0 + kOffTab + lhi * 16 + nt * 128;        // folded-BN table, conv1 / conv2: float index X + g * 8 + lhi * 4 = base + offset
-  // The two groups need different constants: ONE set of registers, named per group below (both sets live = 23 spilled registers)
-  unsigned lc0, lc1, lc2, lc3, lc4, lc5, lc6, lc7, lc8;
+  unsigned lc0, lc1, lc2, lc3, lc4, lc5, lc6, lc7;
   const int xpitch = p.x_cstride * 2, ypitch = p.y_cstride * 2;
   if (grp == 0) {
     // conv1: B fragment of k-step s from the x step buffer: pixel row ptile (512 B), chunk (2 s + lhi) ^ (pixel & 15)
     lc0 = (unsigned)(ptile * 512 + ((lhi ^ (l31 & 15)) << 4));                      // xrd_off, ^ (s << 5)
-    // 128-byte rows (T2 tile / T1 slot r): chunk c of row r sits at (c ^ ((r >> 1) & 7)) << 4
-    lc1 = (unsigned)(ptile * 128 + ((lhi ^ ((ptile >> 1) & 7)) << 4));              // t2rd_off, ^ (kk << 5)
+    lc1 = (unsigned)(ptile * kRow + lhi * 16);                                      // t2rd_off: T2 row ptile, + 32 kk
     // staging tile (wave-private, 32 pixels x 256 B): chunk c of pixel r at (c ^ (r & 15)) << 4
-    lc2 = (lds0 + kOffStg + gw * 8192 + l31 * 256 + lhi * 8) ^ (unsigned)((l31 & 15) << 4);   // stg_acc, ^ (chunk << 4)
+    lc2 = (lds0 + kOffStg + gw * 8192 + l31 * 256) ^ (unsigned)((l31 & 15) << 4);   // stg_px, ^ (chunk << 4)
     lc3 = lds0 + kOffStg + gw * 8192 + lane * 16;                                   // stg_row, + t * 1024: pixel 4 t + lane / 16
     // piece t of the tile: pixel 4 t + rp, 16-byte position lane & 15 = chunk (lane & 15) ^ (pixel & 15): byte offset from the tile's
     // first pixel = 4 t * pitch + rp * pitch + (c16 ^ ((4 t & 15) << 4))
@@ -190,19 +206,20 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
     lc5 = (unsigned)((lane >> 4) * xpitch);                                         // rx
     lc6 = (unsigned)((lane >> 4) * ypitch);                                         // ry
     lc7 = (unsigned)(((lane & 15) ^ (lane >> 4)) << 4);                             // c16
-    lc8 = lds0 + kOffTab + lhi * 16 + nt * 512;                                     // tab_c: conv3, channels nt * 128 ..
   } else {
-    lc0 = (unsigned)(ptile * 128 + lhi * 8) ^ (unsigned)((((ptile >> 1) & 7)) << 4) ^ (unsigned)(nt << 6);   // t2wr_off, ^ (g << 4)
+    lc0 = (unsigned)(ptile * kRow + nt * 64 + lhi * 8);                             // t2wr_off: T2 row ptile, channels nt * 32 + 4 lhi, + 16 g
     // x DMA lane: piece t * 4 + gw = pixels 2 piece, 2 piece + 1; lane (lhi, l31) = 16-byte position l31 of pixel pp = 8 t + xpp, source
     // chunk l31 ^ (pp & 15): byte offset from the step's first pixel = 8 t * pitch + xpp * pitch + (xc16 ^ ((t & 1) << 7))
     lc1 = (unsigned)(2 * gw + lhi);                                                 // xpp
     lc2 = (unsigned)((2 * gw + lhi) * xpitch);                                      // xpx
     lc3 = (unsigned)((l31 ^ lhi ^ (2 * gw)) << 4);                                  // xc16
     lc4 = (unsigned)(ptile % W);                                                    // col: the lane's column (x border of the 3x3 taps)
-    lc5 = lc6 = lc7 = lc8 = 0u;
+    lc5 = lc2 + lc3;                                                                // xl0: lane offset of even pieces
+    lc6 = lc2 + (lc3 ^ 128u);                                                       // xl1: ... of odd pieces
+    lc7 = 0u;
   }
-  unsigned &xrd_off = lc0, &t2rd_off = lc1, &stg_acc = lc2, &stg_row = lc3, &rp = lc4, &rx = lc5, &ry = lc6, &c16 = lc7, &tab_c = lc8;
-  unsigned &t2wr_off = lc0, &xpp = lc1, &xpx = lc2, &xc16 = lc3, &col = lc4;
+  unsigned &xrd_off = lc0, &t2rd_off = lc1, &stg_px = lc2, &stg_row = lc3, &rp = lc4, &rx = lc5, &ry = lc6, &c16 = lc7;
+  unsigned &t2wr_off = lc0, &xpp = lc1, &col = lc4, &xl0 = lc5, &xl1 = lc6;   // (lc2 = xpp * pitch, lc3 = the lane's source chunk * 16)
   const unsigned dcol = (unsigned)(64 % W);
   const unsigned zaddr = lds0 + kOffZero;
 
@@ -211,58 +228,49 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
   unsigned long long tph[4] = {0, 0, 0, 0}, tprev = 0, tc0 = 0;
 #define BNR_TS(k) do { if (p.dbg & 32) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tprev; tprev = t_; } } while (0)
   if (p.dbg & 32) tc0 = tprev = __builtin_amdgcn_s_memtime();
+  const float16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   for (int i = jlo - 3; i <= NS; ++i) {
-    asm volatile("" : "+v"(ptile), "+v"(tab_a), "+v"(lc0), "+v"(lc1), "+v"(lc2), "+v"(lc3), "+v"(lc4), "+v"(lc5), "+v"(lc6), "+v"(lc7), "+v"(lc8));
+    asm volatile("" : "+v"(ptile), "+v"(lc0), "+v"(lc1), "+v"(lc2), "+v"(lc3), "+v"(lc4), "+v"(lc5), "+v"(lc6), "+v"(lc7), "+v"(ones));
     if (grp == 0) {
       // ================= G0: conv3 of step i - 1 ========================================================================
       const int ic = i - 1;
       if (ic >= 0 && ic < NS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's residual piece of step ic has landed
-        const unsigned t2b = lds0 + kOffT2 + (ic & 1) * 8192;
-        uint4_t fb[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) rd128(fb[kk], t2b + (t2rd_off ^ (unsigned)(kk << 5)));
-        wait4<0>(fb);
-        // channel tile mt + 1 is multiplied while tile mt's epilogue runs on the vector ALU
-        float16_t acc[2];
-        auto mul = [&](auto mc) {
+        const unsigned t2b = lds0 + kOffT2 + (ic & 1) * kT2B + t2rd_off;
+        uint4_t fb[4], xr[2][2];
+        static_for<4>([&](auto kc) { rd128o<decltype(kc)::value * 32>(fb[decltype(kc)::value], t2b); });
+        // residual B fragments of channel tile mt: channels 32 mt + 16 s + 8 lhi .. = chunk 4 mt + 2 s + lhi of the lane's pixel
+        auto rd_res = [&](auto mc, uint4_t (&f)[2]) {
           constexpr int mt = decltype(mc)::value;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt & 1][r] = 0.f;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            acc[mt & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wt[16 + mt * 4 + kk]), __builtin_bit_cast(half8_t, fb[kk]),
-                                                                 acc[mt & 1], 0, 0, 0);
+          for (int s2 = 0; s2 < 2; ++s2) rd128(f[s2], stg_px ^ (unsigned)((mt * 4 + s2 * 2 + lhi) << 4));
         };
-        mul(std::integral_constant<int, 0>{});
+        rd_res(std::integral_constant<int, 0>{}, xr[0]);
+        rd_res(std::integral_constant<int, 1>{}, xr[1]);
+        wait4<4>(fb);
+        float16_t acc[2];
+        // shift step (replaces the zero fill), four k-steps of t2, two identity steps of x.  `behind` = LDS operations issued after
+        // this tile's residual reads
+        auto mul = [&](auto mc, auto bc) {
+          constexpr int mt = decltype(mc)::value, behind = decltype(bc)::value;
+          float16_t a = mfma(wt[17 + mt * 5 + 4], ones, zero16);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) a = mfma(wt[17 + mt * 5 + kk], fb[kk], a);
+          wait2<behind>(xr[mt & 1]);
+          a = mfma(wt[37], xr[mt & 1][0], a);
+          a = mfma(wt[38], xr[mt & 1][1], a);
+          acc[mt & 1] = a;
+        };
+        mul(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
         static_for<4>([&](auto mc) {
           constexpr int mt = decltype(mc)::value;
-          float4_t sc[4], sh[4];
-          uint2_t rs[4];
-          static_for<4>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            rd128fo<1024 + mt * 128 + g * 32>(sc[g], tab_c);
-            rd128fo<2048 + mt * 128 + g * 32>(sh[g], tab_c);
-            rd64(rs[g], stg_acc ^ (unsigned)((mt * 4 + g) << 4));
-          });
-          if constexpr (mt + 1 < 4) mul(std::integral_constant<int, mt + 1>{});
-          wait_res(sc, sh, rs);
+          // tile mt + 1 goes to the matrix pipe before tile mt's results are touched; tile mt + 2's residual reads follow
+          if constexpr (mt == 0) mul(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+          if constexpr (mt == 1 || mt == 2) mul(std::integral_constant<int, mt + 1>{}, std::integral_constant<int, 4>{});
+          if constexpr (mt + 2 < 4) rd_res(std::integral_constant<int, mt + 2>{}, xr[mt & 1]);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const half4_t res = __builtin_bit_cast(half4_t, rs[g]);
-            half4_t hv;
-#pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-              const float2_t a = {acc[mt & 1][g * 4 + e2 * 2], acc[mt & 1][g * 4 + e2 * 2 + 1]};
-              const float2_t k = {sc[g][e2 * 2], sc[g][e2 * 2 + 1]}, b = {sh[g][e2 * 2], sh[g][e2 * 2 + 1]};
-              const half2_t r2 = {res[e2 * 2], res[e2 * 2 + 1]};
-              const half2_t o = relu2(__builtin_elementwise_fma(a, k, b) + __builtin_convertvector(r2, float2_t));
-              hv[e2 * 2] = o[0];
-              hv[e2 * 2 + 1] = o[1];
-            }
-            wr64(stg_acc ^ (unsigned)((mt * 4 + g) << 4), __builtin_bit_cast(uint2_t, hv));
-          }
+          for (int g = 0; g < 4; ++g) wr64((stg_px + lhi * 8) ^ (unsigned)((mt * 4 + g) << 4), relu4(acc[mt & 1], g));
         });
         // the finished 32 x 128-channel tile leaves as whole 16-byte pieces (LDS operations of one wave execute in order)
         uint4_t rv[8];
@@ -271,10 +279,17 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
         const int qb = ic * 64 + pt * 32;
         const unsigned yb = (unsigned)(((imgbase + r0W + qb) * p.y_cstride + p.y_coff + nt * 128) * 2);
         const int lim = (p.dbg & 4) ? 0 : npx - qb;                // pixels of the tile that exist
+        // (16-byte buffer stores keep the literal 0 as scalar offset: conv_igemm8.hip's hazard note)
+        if (lim >= 32) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-          __builtin_amdgcn_raw_buffer_store_b128(rv[t], rsrc_y, t * 4 + (int)rp < lim ? yb + (unsigned)(t * 4 * ypitch) + ry + (c16 ^ (unsigned)((t & 3) << 6)) : kOOB,
-                                                 0, FT_YSTORE_BUF_AUX);
+          for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_buffer_store_b128(rv[t], rsrc_y, (yb + (unsigned)(t * 4 * ypitch)) + ry + (c16 ^ (unsigned)((t & 3) << 6)), 0, FT_YSTORE_BUF_AUX);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_buffer_store_b128(rv[t], rsrc_y, t * 4 + (int)rp < lim ? (yb + (unsigned)(t * 4 * ypitch)) + ry + (c16 ^ (unsigned)((t & 3) << 6)) : kOOB,
+                                                   0, FT_YSTORE_BUF_AUX);
+        }
       }
       BNR_TS(0);
       // ================= G0: residual piece of step i (x again, an L2 hit) into the wave's tile ===============================
@@ -282,50 +297,50 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
         const int qb = i * 64 + pt * 32;
         const unsigned xb = (unsigned)(((imgbase + r0W + qb) * p.x_cstride + p.x_coff + nt * 128) * 2);
         const int lim = (p.dbg & 1) ? 0 : npx - qb;
+        const int ldsb = kOffStg + gw * 8192;
+        if (lim >= 32) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + kOffStg + gw * 8192 + t * 1024), 16,
-                                                   t * 4 + (int)rp < lim ? xb + (unsigned)(t * 4 * xpitch) + rx + (c16 ^ (unsigned)((t & 3) << 6)) : kOOB, 0, 0, 0);
+          for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + ldsb + t * 1024), 16, rx + (c16 ^ (unsigned)((t & 3) << 6)),
+                                                     xb + (unsigned)(t * 4 * xpitch), 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + ldsb + t * 1024), 16,
+                                                     t * 4 + (int)rp < lim ? rx + (c16 ^ (unsigned)((t & 3) << 6)) : kOOB, xb + (unsigned)(t * 4 * xpitch), 0, 0);
+        }
       }
       BNR_TS(1);
       // ================= G0: conv1 of step i + 2 -> T1 ring =================================================================
       const int j = i + 2;
       if (j >= jlo && j <= jhi) {
         const unsigned xbuf = lds0 + kOffX + (j & 1) * kXB;
-        uint4_t f0[8], f1[8];
+        uint4_t fr[3][4];                      // four k-steps per group, two groups (256 MFMA cycles) of read-ahead
+        auto rd_grp = [&](auto gc, uint4_t (&f)[4]) {
+          constexpr int g4 = decltype(gc)::value;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rd128(f0[k], xbuf + (xrd_off ^ (unsigned)(k << 5)));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rd128(f1[k], xbuf + (xrd_off ^ (unsigned)((8 + k) << 5)));
-        float16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        wait8<8>(f0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wt[k]), __builtin_bit_cast(half8_t, f0[k]), acc, 0, 0, 0);
-        float4_t sc[4], sh[4];
+          for (int k = 0; k < 4; ++k) rd128(f[k], xbuf + (xrd_off ^ (unsigned)((g4 * 4 + k) << 5)));
+        };
+        rd_grp(std::integral_constant<int, 0>{}, fr[0]);
+        rd_grp(std::integral_constant<int, 1>{}, fr[1]);
+        float16_t acc = mfma(wt[16], ones, zero16);
         static_for<4>([&](auto gc) {
-          constexpr int g = decltype(gc)::value;
-          rd128fo<g * 32>(sc[g], tab_a);
-          rd128fo<256 + g * 32>(sh[g], tab_a);
-        });
-        wait8<8>(f1);
+          constexpr int g4 = decltype(gc)::value;
+          if constexpr (g4 + 2 < 4) rd_grp(std::integral_constant<int, g4 + 2>{}, fr[(g4 + 2) % 3]);
+          wait4<(3 - g4 < 2 ? 3 - g4 : 2) * 4>(fr[g4 % 3]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wt[8 + k]), __builtin_bit_cast(half8_t, f1[k]), acc, 0, 0, 0);
-        wait_tab(sc, sh);
+          for (int k = 0; k < 4; ++k) acc = mfma(wt[g4 * 4 + k], fr[g4 % 3][k], acc);
+        });
         const int q = j * 64 + ptile;
         const bool inside = (unsigned)(r0W + q) < (unsigned)HW;     // out-of-image rows are conv2's zero padding, not relu(bn1(0))
-        const int slot = q & 255;
-        const unsigned t1w = (lds0 + kOffT1 + (unsigned)(slot * 128 + lhi * 8)) ^ (unsigned)(((slot >> 1) & 7) << 4) ^ (unsigned)(nt << 6);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2_t hb = epi4(acc, sc[g], sh[g], g);
+        const unsigned t1w = lds0 + kOffT1 + (unsigned)((q & 255) * kRow + nt * 64 + lhi * 8);
+        static_for<4>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          uint2_t hb = relu4(acc, g);
           hb.x = inside ? hb.x : 0u;
           hb.y = inside ? hb.y : 0u;
-          wr64(t1w ^ (unsigned)(g << 4), hb);
-        }
+          wr64o<g * 16>(t1w, hb);
+        });
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       BNR_TS(2);
@@ -340,15 +355,25 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
         hi = hi < npx + W - jx * 64 ? hi : npx + W - jx * 64;
         if (p.dbg & 1) hi = lo - 1;
         const unsigned span = (unsigned)(hi - lo);                 // (hi < lo: nothing)
+        // the uniform part of the address rides in the instruction's scalar offset (not range-checked: an unwanted lane's vector
+        // offset alone is out of range), the lane part is one of two constants: no vector ALU work per piece on whole steps
         const unsigned xb = (unsigned)(((imgbase + fb0) * p.x_cstride + p.x_coff) * 2);
+        const int ldsb = kOffX + (jx & 1) * kXB + gw * 1024;
+        if (lo <= 0 && hi >= 63) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + kOffX + (jx & 1) * kXB + (t * 4 + gw) * 1024), 16,
-                                                   (hi >= lo && (unsigned)(t * 8 + (int)xpp - lo) <= span) ? xb + (unsigned)(t * 8 * xpitch) + xpx + (xc16 ^ (unsigned)((t & 1) << 7)) : kOOB,
-                                                   0, 0, 0);
+          for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + ldsb + t * 4096), 16, (t & 1) ? xl1 : xl0, xb + (unsigned)(t * 8 * xpitch), 0, 0);
+        } else {
+          // (ragged steps: the step's first pixel may lie before the image, i.e. a NEGATIVE base: everything in the 32-bit vector offset)
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr)(smem + ldsb + t * 4096), 16,
+                                                     (hi >= lo && (unsigned)(t * 8 + (int)xpp - lo) <= span) ? xb + (unsigned)(t * 8 * xpitch) + ((t & 1) ? xl1 : xl0) : kOOB,
+                                                     0, 0, 0);
+        }
       }
       const int jt = i + 6;
-      if (jt <= jhi && !(p.dbg & 8)) {
+      if (jt <= jhi && (p.dbg & 8)) {        // (off: measured 65 us with the touch, 54 without)
         const int idx = gw * 64 + lane;                            // line idx & 3 of pixel idx >> 2
         const int q = jt * 64 + (idx >> 2);
         const int f = r0W + q;
@@ -360,42 +385,27 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
       // ================= G1: conv2 of step i from the T1 ring -> T2 =========================================================
       if (i >= 0 && i < NS) {
         const int q = i * 64 + ptile;
-        const unsigned t1b = lds0 + kOffT1;
+        const unsigned t1b = lds0 + kOffT1 + lhi * 16;
         uint4_t fr[3][4];                      // fragments of taps t, t + 1, t + 2: two taps (256 MFMA cycles) of read-ahead
         auto rd_tap = [&](auto tc, uint4_t (&f)[4]) {
           constexpr int tap = decltype(tc)::value, dy = tap / 3 - 1, dx = tap % 3 - 1;
-          const int slot = (q + dy * W + dx) & 255;
-          const unsigned rel = (unsigned)(slot * 128 + ((lhi ^ ((slot >> 1) & 7)) << 4));
-          bool edge = false;
-          if constexpr (dx == -1) edge = col == 0u;
-          if constexpr (dx == 1) edge = col == (unsigned)(W - 1);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) rd128(f[kk], edge ? zaddr : t1b + (rel ^ (unsigned)(kk << 5)));
+          unsigned a = t1b + (unsigned)(((q + dy * W + dx) & 255) * kRow);
+          if constexpr (dx == -1) a = col == 0u ? zaddr : a;           // (the 128 zero bytes serve all four k-steps)
+          if constexpr (dx == 1) a = col == (unsigned)(W - 1) ? zaddr : a;
+          static_for<4>([&](auto kc) { rd128o<decltype(kc)::value * 32>(f[decltype(kc)::value], a); });
         };
-        float16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         rd_tap(std::integral_constant<int, 0>{}, fr[0]);
         rd_tap(std::integral_constant<int, 1>{}, fr[1]);
+        float16_t acc = mfma(wt[36], ones, zero16);
         static_for<9>([&](auto tc) {
           constexpr int tap = decltype(tc)::value;
           if constexpr (tap + 2 < 9) rd_tap(std::integral_constant<int, tap + 2>{}, fr[(tap + 2) % 3]);
           wait4<(8 - tap < 2 ? 8 - tap : 2) * 4>(fr[tap % 3]);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wt[tap * 4 + kk]), __builtin_bit_cast(half8_t, fr[tap % 3][kk]),
-                                                         acc, 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) acc = mfma(wt[tap * 4 + kk], fr[tap % 3][kk], acc);
         });
-        float4_t sc[4], sh[4];
-        static_for<4>([&](auto gc) {
-          constexpr int g = decltype(gc)::value;
-          rd128fo<512 + g * 32>(sc[g], tab_a);
-          rd128fo<768 + g * 32>(sh[g], tab_a);
-        });
-        wait_tab(sc, sh);
-        const unsigned t2w = lds0 + kOffT2 + (i & 1) * 8192 + t2wr_off;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) wr64(t2w ^ (unsigned)(g << 4), epi4(acc, sc[g], sh[g], g));
+        const unsigned t2w = lds0 + kOffT2 + (i & 1) * kT2B + t2wr_off;
+        static_for<4>([&](auto gc) { wr64o<decltype(gc)::value * 16>(t2w, relu4(acc, decltype(gc)::value)); });
         col += dcol;
         col = col >= (unsigned)W ? col - (unsigned)W : col;
       }
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
     BNR_TS(3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (p.dbg & 32) {      // dev: lifetime and x-wait cycles of every wave (the output is garbage then)
+  if (p.dbg & 32) {      // dev: lifetime and per-section cycles of every wave (the output is garbage then)
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + (blockIdx.x * 8 + wave) * 8;
@@ -419,17 +429,18 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
 #endif
 }
 
-}  // namespace
-
-int bnr_plan(const ft_bottleneck_desc* d, BnrPlan* out) {
+static int bnr_plan(const ft_bottleneck_desc* d, BnrPlan* out) {
   if (!d || !out) return FT_ERR_INVALID_ARG;
   // FT_BNK_RSTAT (read per call: dev / tests): 0 = off, 1 = where the cost rule below takes it (default), 2 = wherever the shape fits;
   // FT_BNR_SR = rows per strip
   const int mode = getenv("FT_BNK_RSTAT") ? atoi(getenv("FT_BNK_RSTAT")) : 1;
   if (mode <= 0) return FT_ERR_UNSUPPORTED;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0) return FT_ERR_INVALID_ARG;
   if (d->dtype != FT_F16 || d->C != 256 || d->P != 64 || d->stride > 1 || d->head_only || d->projection) return FT_ERR_UNSUPPORTED;
-  if (d->W < 3 || d->W > 62 || d->H < 1 || d->N < 1) return FT_ERR_UNSUPPORTED;       // T1 ring: 2 W + 130 <= 256 pixels
-  if ((long long)d->N * d->H * d->W * d->y_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
+  if (d->W < 3 || d->W > 62) return FT_ERR_UNSUPPORTED;       // T1 ring: 2 W + 130 <= 256 pixels
+  if (d->x_coff < 0 || d->y_coff < 0 || d->x_coff % 8 || d->y_coff % 8 || d->x_cstride % 8 || d->y_cstride % 8) return FT_ERR_UNSUPPORTED;
+  if (d->x_cstride < d->x_coff + d->C || d->y_cstride < d->y_coff + d->C) return FT_ERR_INVALID_ARG;
+  if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= (1LL << 31) || (long long)d->N * d->H * d->W * d->y_cstride * 2 >= (1LL << 31)) return FT_ERR_UNSUPPORTED;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     static int cached[64] = {};
@@ -455,15 +466,26 @@ int bnr_plan(const ft_bottleneck_desc* d, BnrPlan* out) {
   return FT_OK;
 }
 
-int bnr_launch(const ft_bottleneck_desc* d, const BnrPlan& pl, const void* x, const void* w1, const void* w2, const void* w3,
-               const float* scale_shift, void* y, hipStream_t stream) {
+}  // namespace
+}  // namespace ft
+
+extern "C" int ft_bottleneck_rstat_supported(const ft_bottleneck_desc* d) {
+  ft::BnrPlan pl;
+  return ft::bnr_plan(d, &pl);
+}
+
+extern "C" long long ft_bottleneck_rstat_weight_bytes(void) { return ft::kW1Bytes + ft::kW2Bytes + ft::kW3Bytes; }
+
+extern "C" int ft_bottleneck_rstat_fwd(const ft_bottleneck_desc* d, const void* x, const void* wpack, void* y, ft_stream_t stream) {
+  using namespace ft;
+  BnrPlan pl;
+  const int st = bnr_plan(d, &pl);
+  if (st != FT_OK) return st;
+  if (!x || !wpack || !y) return FT_ERR_INVALID_ARG;
   BnrParams p{};
   p.x = static_cast<const char*>(x);
   p.y = static_cast<char*>(y);
-  p.w1 = static_cast<const char*>(w1);
-  p.w2 = static_cast<const char*>(w2);
-  p.w3 = static_cast<const char*>(w3);
-  p.tab = scale_shift;
+  p.wp = static_cast<const char*>(wpack);
   p.N = d->N; p.H = d->H; p.W = d->W;
   p.SR = pl.SR; p.S = pl.S;
   p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
@@ -473,9 +495,7 @@ int bnr_launch(const ft_bottleneck_desc* d, const BnrPlan& pl, const void* x, co
   static const int dbg = getenv("FT_BNR_DBG") ? atoi(getenv("FT_BNR_DBG")) : 0;
   p.dbg = dbg;
   FT_RAISE_LDS(bottleneck_rstat_kernel, kLds);
-  hipLaunchKernelGGL(bottleneck_rstat_kernel, dim3(p.total), dim3(512), kLds, stream, p);
+  hipLaunchKernelGGL(bottleneck_rstat_kernel, dim3(p.total), dim3(512), kLds, as_stream(stream), p);
   FT_LAUNCH_CHECK("bottleneck_rstat_kernel");
   return FT_OK;
 }
-
-}  // namespace ft

@@ -94,7 +94,7 @@ def new_act(N: int, H: int, W: int, C: int, dtype, device, cstride: Optional[int
 # --------------------------------------------------------------------------------------------
 def is_conv_call(name: str) -> bool:
     """Launches whose work is convolution MACs (the roofline's kernels): ft_conv2d_fwd[_ws] and ft_bottleneck_fwd."""
-    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_stream_fwd", "ft_bottleneck_cluster_fwd", "ft_conv_direct_fwd")
+    return name.startswith("ft_conv2d_fwd") or name in ("ft_bottleneck_fwd", "ft_bottleneck_rstat_fwd", "ft_bottleneck_stream_fwd", "ft_bottleneck_cluster_fwd", "ft_conv_direct_fwd")
 
 
 def _on_plan_device(fn):
@@ -1189,6 +1189,33 @@ def _bottleneck_stream_operands(c1: "FusedConv", d, x: ActView, planes: int, p1,
     return cached
 
 
+def _bottleneck_rstat_weights(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", device) -> torch.Tensor:
+    """Weight buffer of ft_bottleneck_rstat_fwd (layout: include/flowtrack_hip.h), built once per weight set from the fp32 weights:
+    each conv's BatchNorm scale folded into its fp16 weights (ONE rounding, like the plain fp16 weights), the shift as a
+    (hi, lo) fp16 pair in 16 extra K columns."""
+    cached = c1._packed.get(("bnr_weights",))
+    if cached is not None:
+        return cached
+    parts = []
+    for conv in (c1, c2, c3):
+        scale, shift = fold_scale_shift(conv.cout, conv.cout, conv._bias, conv._bn, torch.device("cpu"))
+        w = conv._weight.permute(0, 2, 3, 1).reshape(conv.cout, -1).float()          # [co][(ky * 3 + kx) * cin + ci]
+        if scale is not None:
+            w = w * scale[:, None]
+        sh = shift if shift is not None else torch.zeros(conv.cout)
+        extra = torch.zeros((conv.cout, 16), dtype=torch.float16)
+        hi = sh.half()
+        extra[:, 0] = hi
+        extra[:, 1] = (sh - hi.float()).half()
+        parts.append(torch.cat([w.half(), extra], dim=1).reshape(-1))
+    buf = torch.cat(parts).contiguous().to(device)
+    if buf.numel() * 2 != int(_lib.load().ft_bottleneck_rstat_weight_bytes()):
+        raise FlowtrackHipError(f"ft_bottleneck_rstat weight buffer: {buf.numel() * 2} bytes built, library expects "
+                                f"{int(_lib.load().ft_bottleneck_rstat_weight_bytes())}")
+    c1._packed[("bnr_weights",)] = buf
+    return buf
+
+
 def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
                       label: str, cluster: bool = False) -> None:
     """conv1 + bn1 + relu -> conv2 + bn2 + relu -> conv3 + bn3 + residual(x) + relu as ONE launch (ft_bottleneck_fwd);
@@ -1228,6 +1255,11 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
     flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
     prog.flops += flops
     prog.fused_records.append((label, len(prog.calls), flops))
+    if lib.ft_bottleneck_rstat_supported(ctypes.byref(d)) == 0:
+        # maps up to 62 wide with enough pixels per CU: the register-stationary strip form (csrc/bottleneck_rstat.hip)
+        wpack = _bottleneck_rstat_weights(c1, c2, c3, x.t.device)
+        prog.add("ft_bottleneck_rstat_fwd", ctypes.byref(d), x.t.data_ptr(), wpack.data_ptr(), y.t.data_ptr(), keep=(d, x.t, y.t, wpack))
+        return
     table = torch.cat([t.flatten()[:n] for t, n in ((s1, planes), (b1, planes), (s2, planes), (b2, planes), (s3, x.C), (b3, x.C))]).contiguous()
     prog.add("ft_bottleneck_fwd", ctypes.byref(d), x.t.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), table.data_ptr(),
              y.t.data_ptr(), keep=(d, x.t, y.t, w1, w2, w3, table))

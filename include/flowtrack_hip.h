@@ -267,6 +267,18 @@ int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,
 /* algorithmic FLOPs of the three convs (2*MACs, no halo recompute) */
 double ft_bottleneck_flops(const ft_bottleneck_desc* d);
 
+/* Register-stationary strip form of the same identity block (csrc/bottleneck_rstat.hip; fp16, C = 256, P = 64, stride 1,
+ * 3 <= W <= 62): one persistent 8-wave workgroup per strip of full-width rows keeps all weights in registers.  The folded
+ * BatchNorms travel INSIDE the weight buffer, which the caller builds once per weight set (fp16, from the fp32 weights):
+ *   [64][272]  w1[co][ci] * scale1[co], then 16 columns {hi(shift1[co]), lo(shift1[co]), 0 x 14}
+ *   [64][592]  w2[co][(ky*3+kx)*64 + ci] * scale2[co], then the 16 shift columns
+ *   [256][80]  w3[co][ci] * scale3[co], then the 16 shift columns          (hi = fp16(shift), lo = fp16(shift - hi))
+ * (the shift is added by one extra MFMA k-step against a vector of ones, the residual by two k-steps against an identity).
+ * _supported also applies the cost rule (at least eight 64-pixel steps per strip) unless FT_BNK_RSTAT=2; FT_BNK_RSTAT=0 -> unsupported. */
+int ft_bottleneck_rstat_supported(const ft_bottleneck_desc* d);
+long long ft_bottleneck_rstat_weight_bytes(void);
+int ft_bottleneck_rstat_fwd(const ft_bottleneck_desc* d, const void* x, const void* wpack, void* y, ft_stream_t stream);
+
 /* Streamed-weights form of the same fusion for the 128- and 256-plane stages (fp16, C = 4P, P = 128 or 256, stride 1,
  * head_only = 0; ResNet layer2.1+ / layer3.1+): a workgroup owns a full-width strip of output rows of one image, keeps
  * t1 / t2 in LDS and streams the block's weights once through an LDS ring (csrc/bottleneck_stream.hip).

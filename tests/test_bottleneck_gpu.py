@@ -524,9 +524,11 @@ RSTAT_CASES = [
 
 
 @pytest.mark.parametrize("case", RSTAT_CASES, ids=[c[0] for c in RSTAT_CASES])
-def test_register_stationary_strip_form_is_bit_identical_to_the_patch_form(hip_lib, case, monkeypatch):
-    """FT_BNK_RSTAT = 2 runs bottleneck_rstat_kernel wherever the shape fits (FT_BNR_SR = rows per strip), 0 the patch kernel:
-    same operand layouts, same K order, same epilogue expressions -> the same bits; and both within tolerance of the oracle."""
+def test_register_stationary_strip_form_matches_oracle_and_the_patch_form(hip_lib, case, monkeypatch):
+    """FT_BNK_RSTAT = 2 runs bottleneck_rstat_kernel wherever the shape fits (FT_BNR_SR = rows per strip), 0 the patch kernel.
+    The strip form folds each BatchNorm scale into its fp16 weights (one rounding of w * scale instead of one of w) and adds the
+    shift and the residual inside the matrix product: the same mathematics with differently placed roundings, so it is held to the
+    oracle's tolerance and to fp16-rounding distance from the patch form, not to its bits."""
     name, N, H, W, xcs, xoff, sr = case
     dev, dtype, seed = torch.device("cuda:0"), torch.float16, 29
     P, C = 64, 256
@@ -553,7 +555,7 @@ def test_register_stationary_strip_form_is_bit_identical_to_the_patch_form(hip_l
         y = ActView(torch.full((N, H, W, C + 32), 3.0, dtype=dtype, device=dev), C, 32)
         prog = make_program()
         record_bottleneck(prog, c1, c2, c3, xv, y, name)
-        assert prog.calls[0][0] == "ft_bottleneck_fwd"
+        assert prog.calls[0][0] == ("ft_bottleneck_rstat_fwd" if mode else "ft_bottleneck_fwd")
         run_program(prog)
         got = view_to_nchw(y)
         assert torch.all(y.t[..., :32] == 3.0), "channels outside the output slice were written"
@@ -563,7 +565,9 @@ def test_register_stationary_strip_form_is_bit_identical_to_the_patch_form(hip_l
             assert torch.equal(view_to_nchw(y), got), f"{name} mode {mode}: two runs differ"
         outs[mode] = got
     scale = max(1.0, want.abs().max().item())
-    err = (outs[2] - want).abs().max().item()
-    assert err <= 2e-2 * scale, f"{name}: strip form vs oracle max abs err {err:.3e} (scale {scale:.2f})"
-    nbad = (outs[2] != outs[0]).sum().item()
-    assert nbad == 0, f"{name}: strip form differs from the patch form in {nbad} of {outs[0].numel()} values (max {(outs[2] - outs[0]).abs().max().item():.3e})"
+    err = {m: (outs[m] - want).abs().max().item() for m in outs}
+    assert err[2] <= 2e-2 * scale, f"{name}: strip form vs oracle max abs err {err[2]:.3e} (scale {scale:.2f})"
+    assert err[2] <= 1.5 * err[0] + 1e-3 * scale, f"{name}: strip form {err[2]:.3e} vs patch form {err[0]:.3e} from the oracle"
+    diff = (outs[2] - outs[0]).abs()
+    assert diff.max().item() <= 1e-2 * scale, f"{name}: strip form vs patch form max abs diff {diff.max().item():.3e}"
+    assert diff.mean().item() <= 5e-4 * scale, f"{name}: strip form vs patch form mean abs diff {diff.mean().item():.3e}"

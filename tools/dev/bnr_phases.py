@@ -24,7 +24,10 @@ for _ in range(3):
     prog.run_eager(); prog.stream.synchronize()
 nwg = B * 4 if not os.environ.get("FT_BNR_SR") else B * ((H + int(os.environ["FT_BNR_SR"]) - 1) // int(os.environ["FT_BNR_SR"]))
 t = y.t.view(torch.int64).reshape(-1)[: nwg * 64].reshape(nwg, 8, 8).cpu().double()
-print(f"{nwg} workgroups; kernel span {(t[:, :, 5] + t[:, :, 0]).max() - t[:, :, 5].min():.0f} cycles; start spread {t[:, :, 5].max() - t[:, :, 5].min():.0f}")
+ti = y.t.view(torch.int64).reshape(-1)[: nwg * 64].reshape(nwg, 8, 8).cpu()
+st, life = ti[:, :, 5], ti[:, :, 0]
+print(f"{nwg} workgroups; first start -> last end {((st + life).max() - st.min()).item()} cycles; start spread {(st.max() - st.min()).item()}; "
+      f"end spread {((st + life).max() - (st + life).min()).item()}")
 for g, names in ((0, ["conv3 + tile out", "residual issue", "conv1", "barrier"]), (1, ["x issue", "conv2", "wait x", "barrier"])):
     w = t[:, g * 4:(g + 1) * 4, :]
     print(f" G{g}: lifetime mean {w[:, :, 0].mean():.0f}")
