@@ -311,7 +311,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       for (int g = 0; g < 4; ++g) {
         half4_t h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (half_t)__builtin_fmaxf(acc1[j][g * 4 + e] * sc[g][e] + sh[g][e], 0.f);
+        for (int e = 0; e < 4; e += 2) {
+          const half2_t o = bn_relu_pk(acc1[j][g * 4 + e], acc1[j][g * 4 + e + 1], sc[g][e], sc[g][e + 1], sh[g][e], sh[g][e + 1]);
+          h[e] = o[0];
+          h[e + 1] = o[1];
+        }
         uint2 hb = __builtin_bit_cast(uint2, h);
         hb.x = inside ? hb.x : 0u;       // out-of-image halo pixels are conv2's zero padding, not relu(bn1(0))
         hb.y = inside ? hb.y : 0u;
@@ -390,7 +394,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       for (int g = 0; g < 4; ++g) {
         half4_t h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (half_t)__builtin_fmaxf(acc2[j][g * 4 + e] * sc[g][e] + sh[g][e], 0.f);
+        for (int e = 0; e < 4; e += 2) {
+          const half2_t o = bn_relu_pk(acc2[j][g * 4 + e], acc2[j][g * 4 + e + 1], sc[g][e], sc[g][e + 1], sh[g][e], sh[g][e + 1]);
+          h[e] = o[0];
+          h[e + 1] = o[1];
+        }
         *reinterpret_cast<half4_t*>(rowp + (((wc2 * 4 + g) << 4) ^ msw)) = h;
       }
     }
@@ -485,8 +493,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       for (int g = 0; g < 4; ++g) {
         half4_t h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          h[e] = (half_t)__builtin_fmaxf(acc3[j][g * 4 + e] * sc[g][e] + sh[g][e] + (PROJ ? 0.f : (float)res[PROJ ? 0 : q][j][g][e]), 0.f);
+        for (int e = 0; e < 4; e += 2) {
+          half2_t o;
+          if constexpr (PROJ) o = bn_relu_pk(acc3[j][g * 4 + e], acc3[j][g * 4 + e + 1], sc[g][e], sc[g][e + 1], sh[g][e], sh[g][e + 1]);
+          else o = bn_res_relu_pk(acc3[j][g * 4 + e], acc3[j][g * 4 + e + 1], sc[g][e], sc[g][e + 1], sh[g][e], sh[g][e + 1],
+                                  res[PROJ ? 0 : q][j][g][e], res[PROJ ? 0 : q][j][g][e + 1]);
+          h[e] = o[0];
+          h[e + 1] = o[1];
+        }
         *reinterpret_cast<half4_t*>(rowp + (((wc2 * 4 + g) << 4) ^ msw)) = h;
       }
     }

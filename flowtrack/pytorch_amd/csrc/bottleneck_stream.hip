@@ -72,6 +72,11 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 #define FT_BNS_OVL 0    // dev A/B: phase 3 of the direct kernel hides a quarter's epilogue inside the next quarter's weight steps
 #endif
 #ifndef FT_BNS_L2_TOUCH
+// the ring kernel's phase-3 epilogue in packed form (ft_common.h: bn_res_relu_acc8): 0 = scalar (the packed form needs aligned register
+// pairs and pushed <128,4,3> from 506 registers / no spill to 512 / 48 spilled)
+#ifndef FT_BNS_PK_RES
+#define FT_BNS_PK_RES 0
+#endif
 #define FT_BNS_L2_TOUCH 1   // the direct kernel's first round of workgroups pulls the weight stream into its XCD's L2 (one touch per line)
 #endif
 #ifndef FT_BNS_PIN
@@ -323,10 +328,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
         const int iy = y0 - 1 + hr;
         const bool inside = (unsigned)iy < (unsigned)p.H;     // out-of-image halo rows are conv2's zero padding
         half8_t h8[2];
+        bn_relu_acc16(acc1[i][j], sc, sh, h8);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = __builtin_fmaxf(acc1[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
-          h8[r >> 3][r & 7] = inside ? (half_t)v : (half_t)0.f;
+        for (int h = 0; h < 2; ++h) {
+          uint4_t u = __builtin_bit_cast(uint4_t, h8[h]);
+          u.x = inside ? u.x : 0u; u.y = inside ? u.y : 0u; u.z = inside ? u.z : 0u; u.w = inside ? u.w : 0u;
+          h8[h] = __builtin_bit_cast(half8_t, u);
         }
         if (hp < npix_halo) {
           char* rowp = smem + hp * ROWB;
@@ -464,9 +471,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
       for (int j = 0; j < MT2; ++j) {
         const int m = m_out[j];
         half8_t h8[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          h8[r >> 3][r & 7] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
+        bn_relu_acc16(acc[i][j], sc, sh, h8);
         char* rowp = smem + m * ROWB;
         const int cb = (2 * wcol + i) * 4 + 2 * lhi;
 #pragma unroll
@@ -536,12 +541,16 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
+#if FT_BNS_PK_RES
+            const half8_t o = bn_res_relu_acc8(acc[i][j], h, sc, sh, rs);
+#else
             half8_t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const int r = h * 8 + e;
               o[e] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
             }
+#endif
             if constexpr (STAGED) {
               const int m = m_out[j];
               *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
@@ -876,10 +885,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         const int iy = iy0 + hr, ix = XH ? x0 - 1 + (hp - hr * PW) : 0;
         const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
         half8_t h8[2];
+        bn_relu_acc16(acc1[i][j], sc, sh, h8);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = __builtin_fmaxf(acc1[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
-          h8[r >> 3][r & 7] = inside ? (half_t)v : (half_t)0.f;
+        for (int h = 0; h < 2; ++h) {
+          uint4_t u = __builtin_bit_cast(uint4_t, h8[h]);
+          u.x = inside ? u.x : 0u; u.y = inside ? u.y : 0u; u.z = inside ? u.z : 0u; u.w = inside ? u.w : 0u;
+          h8[h] = __builtin_bit_cast(half8_t, u);
         }
         if (hp < npix_halo) {
           char* rowp = smem + hp * ROWB;
@@ -1012,9 +1023,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
       for (int j = 0; j < MT2; ++j) {
         const int m = m_out[j];
         half8_t h8[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          h8[r >> 3][r & 7] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], 0.f);
+        bn_relu_acc16(acc[i][j], sc, sh, h8);
         char* rowp = smem + m * ROWB;
         const int cb = (CTW * wcol + i) * 4 + 2 * lhi;
 #pragma unroll
@@ -1071,12 +1080,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
-        half8_t o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int r = h * 8 + e;
-          o[e] = (half_t)__builtin_fmaxf(A[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
-        }
+        const half8_t o = bn_res_relu_acc8(A[i][j], h, sc, sh, rs);
 #if FT_BNS_STG
         *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((CTW * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
 #else

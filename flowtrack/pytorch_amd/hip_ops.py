@@ -1216,10 +1216,20 @@ def _bottleneck_rstat_weights(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv",
     return buf
 
 
+def bottleneck_strips_supported(x: ActView, y: ActView, planes: int) -> bool:
+    """True when ft_bottleneck_rstat_fwd (register-stationary strips, csrc/bottleneck_rstat.hip) covers this identity block."""
+    if x.t.dtype != torch.float16 or x.rowpacked:
+        return False
+    d = _bottleneck_desc(x, y, planes)
+    return _lib.load().ft_bottleneck_rstat_supported(ctypes.byref(d)) == 0
+
+
 def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
-                      label: str, cluster: bool = False) -> None:
+                      label: str, cluster: bool = False, form: str = "auto") -> None:
     """conv1 + bn1 + relu -> conv2 + bn2 + relu -> conv3 + bn3 + residual(x) + relu as ONE launch (ft_bottleneck_fwd);
-    the packed weights / folded BN are those the three FusedConv layers would use on channel-aligned views."""
+    the packed weights / folded BN are those the three FusedConv layers would use on channel-aligned views.
+    `form` (64-plane blocks): "patch" = ft_bottleneck_fwd, "strips" = ft_bottleneck_rstat_fwd, "auto" = strips where the library's
+    cost rule takes them."""
     lib = _lib.load()
     if y.t.data_ptr() == x.t.data_ptr():
         raise FlowtrackHipError(f"{label}: the fused bottleneck cannot run in place")
@@ -1255,7 +1265,9 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
     flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
     prog.flops += flops
     prog.fused_records.append((label, len(prog.calls), flops))
-    if lib.ft_bottleneck_rstat_supported(ctypes.byref(d)) == 0:
+    if form == "strips":
+        check(lib.ft_bottleneck_rstat_supported(ctypes.byref(d)), "ft_bottleneck_rstat_supported")
+    if form != "patch" and lib.ft_bottleneck_rstat_supported(ctypes.byref(d)) == 0:
         # maps up to 62 wide with enough pixels per CU: the register-stationary strip form (csrc/bottleneck_rstat.hip)
         wpack = _bottleneck_rstat_weights(c1, c2, c3, x.t.device)
         prog.add("ft_bottleneck_rstat_fwd", ctypes.byref(d), x.t.data_ptr(), wpack.data_ptr(), y.t.data_ptr(), keep=(d, x.t, y.t, wpack))

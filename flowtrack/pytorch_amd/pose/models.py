@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ..engine import HipModule
 from ..hip_ops import (ActView, FlowtrackHipError, FusedConv, FusedShortcutConv, Program, bottleneck_fusable,
-                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_cluster_supported, bottleneck_head_stream_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head, record_bottleneck_head_stream,
+                       bottleneck_entry_fusable, bottleneck_head_fusable, bottleneck_cluster_supported, bottleneck_strips_supported, bottleneck_head_stream_fusable, bottleneck_prefers_fused, new_act, new_rowpacked_act, record_bottleneck, record_bottleneck_entry, record_bottleneck_head, record_bottleneck_head_stream,
                        record_maxpool, record_pack_input)
 from ..params import ActMarker, BatchNormParams, ConvParams, ConvTransposeParams
 
@@ -286,7 +286,7 @@ class DeconvResnet(HipModule):
             t2 = new_act(B, Ho, Wo, planes, dtype, device)
 
             def fused_form():
-                record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused")
+                record_bottleneck(prog, c1, c2, c3, cur, out, name + ".fused", form="patch")
 
             def conv_form():
                 c1.record(prog, cur, t1)
@@ -299,6 +299,10 @@ class DeconvResnet(HipModule):
                 # round 5: the same block shared by a cluster of four workgroups per image (t1 / t2 exchanged inside the
                 # launch): a third recorded form, kept where the first-call benchmark measures it faster
                 forms = forms + (("cluster", lambda: record_bottleneck(prog, c1, c2, c3, cur, out, name + ".cluster", cluster=True)),)
+            if planes == 64 and bottleneck_strips_supported(cur, out, planes):
+                # round 5: the 64-plane block on register-stationary strips (csrc/bottleneck_rstat.hip): 54 against 57.5 us alone,
+                # equal inside the network: a recorded form, kept where the first-call benchmark measures it faster
+                forms = forms + (("strips", lambda: record_bottleneck(prog, c1, c2, c3, cur, out, name + ".strips", form="strips")),)
             prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
             for form_name, form in forms:
                 prog.option(form_name)

@@ -3,7 +3,7 @@
 R=$(cd $(dirname $0)/../.. && pwd); P=$R/flowtrack/pytorch_amd; name=$1; shift
 mkdir -p $P/build_$name
 pids=()
-for s in conv_igemm conv_igemm8 bottleneck bottleneck_stream bottleneck_cluster conv_direct conv_wstat aux_ops flow_ops crop_ops runtime; do
+for s in conv_igemm conv_igemm8 bottleneck bottleneck_rstat bottleneck_stream bottleneck_cluster conv_direct conv_wstat aux_ops flow_ops crop_ops runtime; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I$R/include -I$P/csrc "$@" -c $P/csrc/$s.hip -o $P/build_$name/$s.o &
   pids+=($!)
 done
