@@ -1799,15 +1799,15 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvParams p, in
   constexpr int VEC = Elem<T>::VEC;
   constexpr int NV = PIX * NCO;  // partial sums per lane
   static_assert(NV == 8, "the reduction below folds exactly 8 values over the 64 lanes");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nvec = p.kh * p.kw * p.cin_groups;   // 16-byte vectors along K per output pixel
-  for (int i = tid; i < NCO * nvec; i += 256) {
-    const int co = i / nvec, v = i - co * nvec;
-    reinterpret_cast<uint4_t*>(smem)[i] = reinterpret_cast<const uint4_t*>(p.w + (size_t)co * p.Kpad * sizeof(T))[v];
-  }
-  __syncthreads();
-  const uint4_t* sw = reinterpret_cast<const uint4_t*>(smem);
+  // Round 5: no weight staging and no branches around the loads.  A wave makes ONE pass over its PIX pixels (ppb = 16 for every
+  // layer below 32 k pixels), so copying the weight set into LDS first bought nothing but a barrier; and the input loads sat
+  // each in its own divergent region behind a full wait (18 K steps x 4 dependent L2 round trips: 20 us for 28 MFLOP at
+  // FlowNet's predict_flow6).  Now: weights straight from L2 (every wave reads the same lines), inputs as buffer loads whose
+  // offset is out of range where the tap leaves the image, two K vectors per lane in flight = 12 independent loads per wait.
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;
   const int m_begin = blockIdx.x * ppb;
   const int m_end = m_begin + ppb < p.M ? m_begin + ppb : p.M;
   const int tap0 = lane / p.cin_groups;
@@ -1830,24 +1830,33 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvParams p, in
 #pragma unroll
     for (int c = 0; c < NV; ++c) acc[c] = 0.f;
     int tap = tap0, cg = cg0;
-    for (int v = lane; v < nvec; v += 64) {
-      const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      uint4_t wv[NCO];
+    constexpr int U = 2;
+    for (int v = lane; v < nvec; v += 64 * U) {
+      uint4_t wv[U][NCO], xv[U][PIX];
 #pragma unroll
-      for (int c = 0; c < NCO; ++c) wv[c] = sw[c * nvec + v];
+      for (int u = 0; u < U; ++u) {
+        const int vv = v + 64 * u;
+        const bool live = vv < nvec;
+        const int vc = live ? vv : 0;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
 #pragma unroll
-      for (int i = 0; i < PIX; ++i) {
-        const int iy = py_[i] * p.sy - p.pad + ky, ix = px_[i] * p.sy - p.pad_x + kx;
-        uint4_t xv = {0u, 0u, 0u, 0u};
-        if (m + i < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-          const size_t off = ((size_t)(pn[i] * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff + cg * VEC;
-          xv = *reinterpret_cast<const uint4_t*>(p.x + off * sizeof(T));
+        for (int c = 0; c < NCO; ++c) wv[u][c] = reinterpret_cast<const uint4_t*>(p.w + (size_t)c * p.Kpad * sizeof(T))[vc];
+#pragma unroll
+        for (int i = 0; i < PIX; ++i) {
+          const int iy = py_[i] * p.sy - p.pad + ky, ix = px_[i] * p.sy - p.pad_x + kx;
+          const bool ok = live && m + i < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+          const unsigned off = (unsigned)((((pn[i] * p.Hi + iy) * p.Wi + ix) * p.x_cstride + p.x_coff + cg * VEC) * (int)sizeof(T));
+          xv[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : kOOB, 0, 0);
         }
-#pragma unroll
-        for (int c = 0; c < NCO; ++c) acc[i * NCO + c] = dot8(xv, wv[c], acc[i * NCO + c], (T*)nullptr);
+        cg += 64;
+        while (cg >= p.cin_groups) { cg -= p.cin_groups; ++tap; }
       }
-      cg += 64;
-      while (cg >= p.cin_groups) { cg -= p.cin_groups; ++tap; }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < PIX; ++i)
+#pragma unroll
+          for (int c = 0; c < NCO; ++c) acc[i * NCO + c] = dot8(xv[u][i], wv[u][c], acc[i * NCO + c], (T*)nullptr);
     }
     // transpose-reduce: 8 values x 64 lanes -> value j summed over all lanes, held by lanes with (lane>>3)==j
     float r4[4], r2[2], r1;
@@ -3082,19 +3091,17 @@ static int conv2d_fwd_impl(const ft_conv_desc* d, const void* x, const void* w_p
   }
   if (!d->transposed && d->Cout <= 4) {
     const int nco = d->Cout <= 2 ? 2 : 4;
-    const size_t lds = (size_t)nco * g.ntaps * g.cin_groups * 16;
-    if (lds <= 160 * 1024) {
-      // pixels per workgroup: enough workgroups to fill the chip, enough pixels to amortise the weight staging
+    if (x_bytes < (1ull << 31) && g.cout_pad >= nco) {
+      p.x_bytes = (unsigned)x_bytes;
+      // pixels per workgroup: enough workgroups to fill the chip; a wave takes PIX = 8 / nco pixels per pass
       int ppb = ceil_div(p.M, 2048);
       ppb = ppb < 16 ? 16 : (ppb > 128 ? 128 : ppb);
       ppb = round_up(ppb, 16);
       dim3 grid(ceil_div(p.M, ppb));
-#define FT_FEWOUT(T, N, P)                                                                                    \
-  do {                                                                                                       \
-    auto k = conv_fewout_kernel<T, N, P>;                                                                    \
-    if (lds > 64 * 1024)                                                                                     \
-      FT_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p, ppb);                                                  \
+#define FT_FEWOUT(T, N, P)                                          \
+  do {                                                              \
+    auto k = conv_fewout_kernel<T, N, P>;                           \
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, s, p, ppb);           \
   } while (0)
       if (d->dtype == FT_F16) { if (nco == 2) FT_FEWOUT(half_t, 2, 4); else FT_FEWOUT(half_t, 4, 2); }
       else { if (nco == 2) FT_FEWOUT(float, 2, 4); else FT_FEWOUT(float, 4, 2); }
