@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import types
 
 import numpy as np
 import pytest
@@ -266,6 +267,64 @@ def test_bottleneck_desc_matches_header_and_argument_checks(hip_lib):
     assert hip_lib.ft_bottleneck_flops(ctypes.byref(desc())) == 2.0 * macs
     # NULL operands are an argument error, not a crash (no launch happens)
     assert hip_lib.ft_bottleneck_fwd(ctypes.byref(desc()), None, None, None, None, None, None, None) == invalid
+
+
+def test_bottleneck_rstat_plan_and_weight_buffer(hip_lib, monkeypatch):
+    """ft_bottleneck_rstat_* without a GPU: which shapes the strip form takes (cost rule, FT_BNK_RSTAT switch, map width), and the
+    weight buffer hip_ops builds for it: BatchNorm scale folded into the fp16 weights, the shift as a (hi, lo) fp16 pair in 16
+    extra K columns, in the layout include/flowtrack_hip.h states."""
+    import torch
+    from flowtrack.pytorch_amd import hip_ops, synth
+    from flowtrack.pytorch_amd._lib import BottleneckDesc
+
+    def desc(**kw):
+        d = BottleneckDesc()
+        base = dict(dtype=0, N=64, H=64, W=48, C=256, P=64, x_cstride=256, x_coff=0, y_cstride=256, y_coff=0, head_only=0)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        return d
+    ok, unsupported, invalid = 0, 2, 1
+    monkeypatch.delenv("FT_BNK_RSTAT", raising=False)
+    monkeypatch.delenv("FT_BNR_SR", raising=False)
+    sup = lambda **kw: hip_lib.ft_bottleneck_rstat_supported(ctypes.byref(desc(**kw)))
+    assert sup() == ok                                  # 64 images x 4 strips of 16 rows = one strip per CU
+    assert sup(N=2) == unsupported                      # one-row strips: the patch kernel's case
+    assert sup(W=72, H=96) == unsupported               # T1 ring: W <= 62
+    assert sup(P=128, C=512, x_cstride=512, y_cstride=512) == unsupported
+    assert sup(head_only=1) == unsupported and sup(projection=1) == unsupported and sup(dtype=1) == unsupported
+    assert sup(x_coff=4) == unsupported and sup(y_cstride=128) == invalid and sup(N=0) == invalid
+    monkeypatch.setenv("FT_BNK_RSTAT", "2")
+    assert sup(N=2) == ok and sup(W=72, H=96) == unsupported
+    monkeypatch.setenv("FT_BNK_RSTAT", "0")
+    assert sup() == unsupported
+    monkeypatch.setenv("FT_BNK_RSTAT", "2")
+    assert hip_lib.ft_bottleneck_rstat_fwd(ctypes.byref(desc()), None, None, None, None) == invalid      # NULL operands: no launch
+
+    bn = lambda name, c: {"weight": synth.uniform(3, name + "g", (c,), 0.5, 1.5), "bias": synth.normal(3, name + "b", (c,), 0.1),
+                          "running_mean": synth.normal(3, name + "m", (c,), 0.1), "running_var": synth.uniform(3, name + "v", (c,), 0.5, 1.5),
+                          "eps": 1e-5}
+    w1, w2, w3 = synth.normal(3, "w1", (64, 256, 1, 1), 0.08), synth.normal(3, "w2", (64, 64, 3, 3), 0.06), synth.normal(3, "w3", (256, 64, 1, 1), 0.17)
+    b1, b2, b3 = bn("1", 64), bn("2", 64), bn("3", 256)
+    # (FusedConv itself needs a GPU; the packer reads these fields of it)
+    layer = lambda w, b: types.SimpleNamespace(cout=w.shape[0], _weight=w.float(), _bias=None, _bn=b, _packed={})
+    c1, c2, c3 = layer(w1, b1), layer(w2, b2), layer(w3, b3)
+    buf = hip_ops._bottleneck_rstat_weights(c1, c2, c3, torch.device("cpu"))
+    assert buf.dtype == torch.float16 and buf.numel() * 2 == hip_lib.ft_bottleneck_rstat_weight_bytes() == 2 * (64 * 272 + 64 * 592 + 256 * 80)
+    assert hip_ops._bottleneck_rstat_weights(c1, c2, c3, torch.device("cpu")) is buf        # built once per weight set
+    pos = 0
+    for w, b, k in ((w1, b1, 256), (w2, b2, 576), (w3, b3, 64)):
+        co = w.shape[0]
+        blk = buf[pos:pos + co * (k + 16)].reshape(co, k + 16).float()
+        pos += co * (k + 16)
+        scale = b["weight"].double() / torch.sqrt(b["running_var"].double() + 1e-5)
+        shift = b["bias"].double() - b["running_mean"].double() * scale
+        want = (w.permute(0, 2, 3, 1).reshape(co, k).double() * scale[:, None]).float()       # k = (ky * 3 + kx) * cin + ci
+        # w * scale rounded ONCE to fp16 (the packer multiplies in fp32: a product on a rounding boundary may fall either way)
+        assert ((blk[:, :k] - want).abs() <= want.abs() * 2.0 ** -10 + 1e-7).all(), "w * scale, rounded once"
+        assert (blk[:, :k] == want.half().float()).float().mean().item() > 0.999
+        assert (blk[:, k] + blk[:, k + 1] - shift.float()).abs().max().item() <= 2e-7 * max(1.0, shift.abs().max().item()), "hi + lo = shift"
+        assert torch.all(blk[:, k + 2:] == 0)
 
 
 def test_flip_test_pairs_follow_the_dataset():
