@@ -22,7 +22,8 @@
 //     No scale / shift table, no fp16 -> fp32 conversions, no per-value VALU multiply.
 //   * Software pipeline, ONE s_barrier per step.  Iteration i:  G0: conv3(step i - 1) from T2 + residual -> y; then the
 //     residual fetch of step i; then conv1(step i + 2) from the x ring -> T1 ring.   G1: LDS-DMA of x(step i + 3) into the
-//     ring (+ an L2 touch of step i + 6: the demand load one iteration ahead then hits L2), conv2(step i) from T1 -> T2.
+//     ring, conv2(step i) from T1 -> T2.  (An L2 touch of step i + 6 — one dword per line, so that the demand load hits L2 —
+//     is in the code behind FT_BNR_DBG & 8: 65 us with it, 54 without.)
 //   * x ring: two 32-KiB step buffers (64 pixels x 512 B, 16-byte chunks XOR-ed with pixel & 15 on the SOURCE side of the
 //     DMA: conflict-free ds_read_b128 fragments).  T1: a 256-pixel flat ring, T2: two 64-pixel tiles, both with 144-byte rows
 //     (128 + 16: sixteen consecutive rows land on sixteen distinct 16-byte bank slots, and a fragment's k-step is an instruction
@@ -31,6 +32,13 @@
 //     in as B fragments, writes y in place and stores the tile as whole 16-byte pieces (256 contiguous bytes per pixel).
 //   * Every in-loop LDS access is inline asm with hand-placed lgkmcnt waits (hipcc puts `s_waitcnt vmcnt(0)` in front of
 //     compiler-visible LDS accesses while an LDS-DMA is in flight: conv_wstat.hip).
+// Measured (batch 64, 64 x 48; tools/dev/bnk_bench.py, bnr_phases.py): 53.6 us against the patch kernel's 57.5 us on the same box
+// (first version with the scale / shift table and the residual on the vector ALU: 71 us); inside the R50 network 54.3 / 57.0 against
+// 55.6 / 54.8 us, so hip_ops records it as an ALTERNATIVE form of the block that the first-call benchmark has to prefer by 3 %.
+// With every load and store off it takes 41 us: G0 needs 5.9 k cycles per step, G1 3.9 k (it waits at the barrier for 30 % of its
+// life); ~900 instructions per step and SIMD, 82 of them MFMAs.  Tried on top and not kept: wave priority for G0 (no change); one
+// predicated instruction stream per group with every MFMA followed by its share of the rest (sched_barrier pins): the groups balance
+// at 4.3 k cycles per step but the pipeline's fill and drain iterations then cost full steps: 62 us.
 // Weight buffer (ft_bottleneck_rstat_fwd's `wpack`, built by the caller once per weight set; fp16):
 //   [64][272]  conv1: w1[co][ci] * scale1[co], then 16 columns {hi(shift1[co]), lo(shift1[co]), 0 x 14}
 //   [64][592]  conv2: w2[co][(ky * 3 + kx) * 64 + ci] * scale2[co], then the 16 shift columns
