@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_rstat_kernel(const BnrParam
                                                      0, 0, 0);
         }
       }
-      const int jt = i + 6;
+      const int jt = i + ((p.dbg >> 8) & 7 ? ((p.dbg >> 8) & 7) : 6);     // (dev: FT_BNR_DBG bits 8..10 = the touch's lead over the step the loop is in)
       if (jt <= jhi && (p.dbg & 8)) {        // (off: measured 65 us with the touch, 54 without)
         const int idx = gw * 64 + lane;                            // line idx & 3 of pixel idx >> 2
         const int q = jt * 64 + (idx >> 2);

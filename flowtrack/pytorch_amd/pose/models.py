@@ -299,10 +299,13 @@ class DeconvResnet(HipModule):
                 # round 5: the same block shared by a cluster of four workgroups per image (t1 / t2 exchanged inside the
                 # launch): a third recorded form, kept where the first-call benchmark measures it faster
                 forms = forms + (("cluster", lambda: record_bottleneck(prog, c1, c2, c3, cur, out, name + ".cluster", cluster=True)),)
-            if planes == 64 and bottleneck_strips_supported(cur, out, planes):
-                # round 5: the 64-plane block on register-stationary strips (csrc/bottleneck_rstat.hip): 54 against 57.5 us alone,
-                # equal inside the network: a recorded form, kept where the first-call benchmark measures it faster
-                forms = forms + (("strips", lambda: record_bottleneck(prog, c1, c2, c3, cur, out, name + ".strips", form="strips")),)
+            if self.strip_kernels and planes == 64 and bottleneck_strips_supported(cur, out, planes):
+                # round 5: the 64-plane block on register-stationary strips (csrc/bottleneck_rstat.hip): 54 against 57.5 us alone
+                # and with warm caches, 59-63 against ~55 us behind a cold L2 (its prologue waits for 139 KB of weights before the
+                # first x load): recorded only with FT_STRIP_KERNELS=1 — the first-call benchmark times a group's later options
+                # behind warmer caches than its first, a bias larger than this form's margin
+                strips = (("strips", lambda: record_bottleneck(prog, c1, c2, c3, cur, out, name + ".strips", form="strips")),)
+                forms = strips + forms if os.environ.get("FT_STRIP_KERNELS") == "2" else forms + strips      # (2: the first choice, dev)
             prog.begin_choice(f"bottleneck|{B},{cur.H},{cur.W},{cur.C},{planes},{cur.cstride},{out.cstride}")
             for form_name, form in forms:
                 prog.option(form_name)
@@ -363,6 +366,7 @@ class DeconvResnet(HipModule):
     #: form's 48 (each of its two in-launch hand-offs costs 4-5 us: profiles/README.md, round 5), and its workgroups wait for
     #: each other inside the launch (bounded spins: nothing deadlocks, but a timed-out hand-off gives a wrong block).
     cluster_kernels: bool = os.environ.get("FT_CLUSTER_KERNELS", "0") == "1"
+    strip_kernels: bool = os.environ.get("FT_STRIP_KERNELS", "0") in ("1", "2")      # the 64-plane block's register-stationary form as an option
 
     def plan_for(self, B: int, H: int, W: int, replica: int = 0) -> _PosePlan:
         """The plan (launch list + activation buffers + graph) of one input shape.  `replica` > 0 gives an independent copy
