@@ -69,6 +69,11 @@ __device__ __forceinline__ int cd_key(int row) { return CPR < 16 ? ((row >> FT_C
 #ifndef FT_CD_WSLOTS
 #define FT_CD_WSLOTS 3
 #endif
+#ifndef FT_CD_L2_TOUCH
+#define FT_CD_L2_TOUCH 0   // conv_direct_kernel: every wave touches its weight stream once at kernel start (cold L2 inside a network).
+                           // Measured in the R50 network (net_bench.py, NB_HOT=1, two runs each): the K-concat exits 27 -> 31-35 us, the step
+                           // 1.147 -> 1.169 ms: up to 36 LDS-DMA issues per wave in front of the first x load cost more than the misses they hide
+#endif
 template <int KSPLIT>
 struct CdGeom {
   static constexpr int MT = 3, BP = 96;                       // pixel tiles per wave, pixels per workgroup
@@ -125,6 +130,17 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
+#if FT_CD_L2_TOUCH
+  // Inside a network this layer's weights are not in the XCD's L2 when the kernel starts, and the register ring keeps only
+  // WS - 1 chunks (16 KiB per wave) in flight: a cold stream is paced by the miss latency.  Every wave therefore asks for all
+  // lines of ITS stream once, up front (one dword per 128-byte line, LDS-DMA into a scratch corner: the oldest vector-memory
+  // operations of the wave, every counted wait below covers them).  FT_CD_DBG & 512 switches it off.
+  if (!(p.dbg & 512)) {
+    for (int c = (NCH > 0 ? FT_CD_WSLOTS : 3) - 1; c < nchunk; ++c)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + G::LDS_BYTES + wave * 256), 4, (unsigned)lane * 128u,
+                                               ((cb * nchunk + c) * 4 + wave) * 8192, 0, 0);
+  }
+#endif
   // ---- loaders ---------------------------------------------------------------------------------------------------------
   // ring row = pixel, ROWB bytes; a 1-KiB wave load covers 1024 / ROWB rows; XOR swizzle on the SOURCE 16-byte position
   constexpr int CPR = ROWB / 16;                  // 16-byte positions per row: 8 or 32
@@ -1593,7 +1609,8 @@ static int cd_plan(const ft_conv_desc* d, CdPlan* out) {
 template <int KSPLIT, bool HAS_RES, int NCH, bool TAPS = false>
 static int cd_launch(const CdParams& p, hipStream_t s) {
   auto k = conv_direct_kernel<KSPLIT, HAS_RES, NCH, TAPS>;
-  constexpr int lds = CdGeom<KSPLIT>::LDS_BYTES;
+  constexpr int lds = CdGeom<KSPLIT>::LDS_BYTES + (FT_CD_L2_TOUCH ? 1024 : 0);     // (+ the L2 touch's scratch)
+  static_assert(lds <= 163840, "LDS map");
   static bool attr_done[64] = {};
   int dev = 0;
   FT_HIP_CHECK(hipGetDevice(&dev));
