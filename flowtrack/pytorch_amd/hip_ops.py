@@ -262,21 +262,38 @@ class Program:
                         g["ev"].append(e)
                         marks[i] = e
                     g["ms"] = [float("inf")] * (len(g["marks"]) - 1)
+                # One pass per OPTION INDEX (round 5): pass j runs only option j of every group under test (groups with fewer
+                # options: their first, untimed), so each option is timed behind the cache state its real predecessors leave.
+                # Timing all options of a group back to back in one pass let the later ones find the group's input and the
+                # previous option's output warm in L2 / MALL: worth 4-10 us per launch here (net_bench.py, NB_HOT=1), more than
+                # the 3 % an option has to win by.  FT_CHOICE_SINGLE_PASS=1 restores the one-pass timing.
+                single = os.environ.get("FT_CHOICE_SINGLE_PASS", "0") == "1"
+                owner = {}
+                for g in todo:
+                    m = g["marks"]
+                    for j in range(len(m) - 1):
+                        for i in range(m[j] + 1, m[j + 1]):
+                            owner[i] = (j, len(m) - 1)
+                npass = 1 if single else max(len(g["ms"]) for g in todo)
                 for _ in range(reps):
-                    with torch.cuda.stream(self.stream):
-                        torch.cuda._sleep(4_000_000)
-                    for i, (name, args) in enumerate(self.calls):
-                        if name.startswith("__"):
-                            if i in marks:
-                                check(lib.ft_event_record(marks[i], sh))
-                            continue
-                        check(getattr(lib, name)(*args, sh), name)
-                    check(lib.ft_stream_synchronize(sh), "ft_stream_synchronize")
-                    for g in todo:
-                        for j in range(len(g["ms"])):
-                            ms = ctypes.c_float()
-                            check(lib.ft_event_elapsed_ms(g["ev"][j], g["ev"][j + 1], ctypes.byref(ms)))
-                            g["ms"][j] = min(g["ms"][j], ms.value)
+                    for jpass in range(npass):
+                        with torch.cuda.stream(self.stream):
+                            torch.cuda._sleep(4_000_000)
+                        for i, (name, args) in enumerate(self.calls):
+                            if name.startswith("__"):
+                                if i in marks:
+                                    check(lib.ft_event_record(marks[i], sh))
+                                continue
+                            o = owner.get(i)
+                            if o is not None and not single and o[0] != (jpass if jpass < o[1] else 0):
+                                continue
+                            check(getattr(lib, name)(*args, sh), name)
+                        check(lib.ft_stream_synchronize(sh), "ft_stream_synchronize")
+                        for g in todo:
+                            for j in (range(len(g["ms"])) if single else ([jpass] if jpass < len(g["ms"]) else [])):
+                                ms = ctypes.c_float()
+                                check(lib.ft_event_elapsed_ms(g["ev"][j], g["ev"][j + 1], ctypes.byref(ms)))
+                                g["ms"][j] = min(g["ms"][j], ms.value)
                 total, names = {}, {}
                 for g in todo:
                     names[g["key"]] = g["names"]
