@@ -34,7 +34,8 @@
 //     compiler-visible LDS accesses while an LDS-DMA is in flight: conv_wstat.hip).
 // Measured (batch 64, 64 x 48; tools/dev/bnk_bench.py, bnr_phases.py): 53.6 us against the patch kernel's 57.5 us on the same box
 // (first version with the scale / shift table and the residual on the vector ALU: 71 us); inside the R50 network 54.3 / 57.0 against
-// 55.6 / 54.8 us, so hip_ops records it as an ALTERNATIVE form of the block that the first-call benchmark has to prefer by 3 %.
+// 55.6 / 54.8 us on one box, 60.8 / 60.8 against 59.5 / 57.9 on another (behind the cold L2 a network leaves this form loses 7-9 us,
+// the patch form 4-6), so the Python host records it as an ALTERNATIVE form of the block only with FT_STRIP_KERNELS=1.
 // With every load and store off it takes 41 us: G0 needs 5.9 k cycles per step, G1 3.9 k (it waits at the barrier for 30 % of its
 // life); ~900 instructions per step and SIMD, 82 of them MFMAs.  Tried on top and not kept: wave priority for G0 (no change); one
 // predicated instruction stream per group with every MFMA followed by its share of the rest (sched_barrier pins): the groups balance
