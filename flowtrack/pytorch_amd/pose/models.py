@@ -79,6 +79,7 @@ class DeconvResnet(HipModule):
     #: record the exact-arg-max mode's screen + flagged-crop gather inside fp16 plans (needs keypoints_in_plan); see exact_submit_plan
     exact_in_plan: bool = False
     #: dev: layer1 + layer2 as two half-batch lanes (parallel graph branches); FT_SPLIT_LANES=1
+    split_lanes4: bool = os.environ.get("FT_SPLIT_LANES4", "0") == "1"       # dev: layer4 as two half-batch lanes
     split_lanes: int = int(os.environ.get("FT_SPLIT_LANES", "0") or 0)     # 1: lanes start together; 2: the second lane starts with its half of the stem
     #: run the 1x1 heatmap conv as the fused tail of the last deconv (fp16 mode); FT_FUSE_HEATMAP=0 keeps it a launch
     fuse_heatmap: bool = os.environ.get("FT_FUSE_HEATMAP", "1") != "0"
@@ -209,6 +210,33 @@ class DeconvResnet(HipModule):
                 cur = chain[-1][2]
                 continue
             if split and li == 2:
+                continue
+            if self.split_lanes4 and li == 4 and dtype == torch.float16 and B % 2 == 0 and B >= 32:
+                # FT_SPLIT_LANES4=1 (dev): layer4 as two half-batch lanes.  Its nine launches are small (15-30 us each, of which ~6 us
+                # are the launch's ramp with the chip mostly idle: cd_phases.py shows 10-us workgroup lifetimes in 16-us kernels); two
+                # lanes fill each other's ramps, and halving the pixels halves the workgroups, not the weight bytes per workgroup.
+                # MEASURED (two interleaved bench runs): 56.37 / 55.82 -> 53.75 / 53.79 k crops/s: off.
+                chain = []
+                hh, ww = cur.H, cur.W
+                for bi, blk in enumerate(layer):
+                    hh, ww = hh // blk.stride, ww // blk.stride
+                    chain.append((f"layer4.{bi}", blk, new_act(B, hh, ww, blk.conv1.cout * 4, dtype, device)))
+                prog.fork()
+                for half, (lo, hi) in enumerate(((0, B // 2), (B // 2, B))):
+                    c = cur.batch_slice(lo, hi)
+
+                    def lane(c=c, lo=lo, hi=hi):
+                        for name, blk, out_full in chain:
+                            o = out_full.batch_slice(lo, hi)
+                            self._record_block(prog, name, blk, c, o, dtype, device)
+                            c = o
+                    if half == 1:
+                        with prog.side():
+                            lane()
+                    else:
+                        lane()
+                prog.join()
+                cur = chain[-1][2]
                 continue
             for bi, blk in enumerate(layer):
                 name = f"layer{li}.{bi}"
