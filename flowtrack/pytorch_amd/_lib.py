@@ -46,7 +46,7 @@ class BottleneckDesc(ctypes.Structure):
 
     _fields_ = [("dtype", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("P", c_int),
                 ("x_cstride", c_int), ("x_coff", c_int), ("y_cstride", c_int), ("y_coff", c_int), ("head_only", c_int), ("projection", c_int),
-                ("stride", c_int)]
+                ("stride", c_int), ("folded", c_int)]
 
 
 class ConvGeometry(ctypes.Structure):
@@ -98,6 +98,7 @@ _PROTOTYPES = {
     "ft_bottleneck_rstat_weight_bytes": (ctypes.c_longlong, []),
     "ft_bottleneck_rstat_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_stream_supported": (c_int, [POINTER(BottleneckDesc)]),
+    "ft_bottleneck_stream_folds": (c_int, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_stream_weight_bytes": (ctypes.c_longlong, [POINTER(BottleneckDesc)]),
     "ft_bottleneck_stream_pack": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ft_bottleneck_stream_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -141,7 +142,9 @@ _PROTOTYPES = {
                                        c_void_p, c_void_p, c_void_p]),
 }
 
-EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+# declared only under FT_EXPERIMENTAL in the header: measured alternatives the default plans do not record (tests / tools/dev reach them)
+EXPERIMENTAL_SYMBOLS = ("ft_bottleneck_rstat_supported", "ft_bottleneck_rstat_weight_bytes", "ft_bottleneck_rstat_fwd", "ft_bottleneck_cluster_supported", "ft_bottleneck_cluster_workspace_bytes", "ft_bottleneck_cluster_status_offset", "ft_bottleneck_cluster_fwd")
+EXPORTED_SYMBOLS = tuple(n for n in _PROTOTYPES if n not in EXPERIMENTAL_SYMBOLS)
 
 _lib = None
 

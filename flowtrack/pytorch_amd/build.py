@@ -21,6 +21,7 @@ STAMP_PATH = os.path.join(HERE, ".libflowtrack_hip.stamp")
 
 SOURCES = ["conv_igemm.hip", "conv_igemm8.hip", "bottleneck.hip", "bottleneck_rstat.hip", "bottleneck_stream.hip", "bottleneck_cluster.hip", "conv_direct.hip", "conv_wstat.hip", "aux_ops.hip", "flow_ops.hip", "crop_ops.hip", "runtime.hip"]
 HEADERS = [os.path.join(CSRC, "ft_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_wstat.h"), os.path.join(INCLUDE, "flowtrack_hip.h")]
+EXPORTS = os.path.join(CSRC, "exports.map")   # version script: only ft_* leaves the library
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -34,7 +35,7 @@ def _hipcc() -> str:
 
 def _fingerprint() -> str:
     h = hashlib.sha256()
-    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [EXPORTS]:
         with open(path, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS + [ARCH]).encode())
@@ -83,7 +84,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}")
         with open(stamp, "w") as f:
             f.write(want)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}", *objs, "-o", LIB_PATH]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -71,13 +71,17 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 #ifndef FT_BNS_OVL
 #define FT_BNS_OVL 0    // dev A/B: phase 3 of the direct kernel hides a quarter's epilogue inside the next quarter's weight steps
 #endif
-#ifndef FT_BNS_L2_TOUCH
-// the ring kernel's phase-3 epilogue in packed form (ft_common.h: bn_res_relu_acc8): 0 = scalar (the packed form needs aligned register
-// pairs and pushed <128,4,3> from 506 registers / no spill to 512 / 48 spilled)
+// the ring kernel's phase-3 epilogue (table form) in packed form (ft_common.h: bn_res_relu_acc8): 0 = scalar (the packed form needs
+// aligned register pairs and pushed <128,4,3> from 506 registers / no spill to 512 / 48 spilled)
 #ifndef FT_BNS_PK_RES
 #define FT_BNS_PK_RES 0
 #endif
+#ifndef FT_BNS_L2_TOUCH
 #define FT_BNS_L2_TOUCH 1   // the direct kernel's first round of workgroups pulls the weight stream into its XCD's L2 (one touch per line)
+#endif
+#ifndef FT_BNSD_ABL
+#define FT_BNSD_ABL 0   // dev ablations of the direct kernel (TIMING ONLY, results are wrong): 1 = no chunk barriers in phase 1, 2 = no residual
+                        // pick-up, 16 / 32 = the weight loads of phase 1 / phases 2 + 3 are not issued at all (FT_BNS_DBG=64 still issues them)
 #endif
 #ifndef FT_BNS_PIN
 #define FT_BNS_PIN 3    // dev A/B: bit 0 = pinned issue order in phase 1 of the direct kernel, bit 1 = in its weight steps (dstep)
@@ -113,7 +117,9 @@ struct BnsGeom {
   static_assert(ZROW % ROWB == 0 && ZROW + ROWB <= WBASE && WBASE + 3 * WSTEP == LDS_BYTES, "LDS map");
 };
 
-template <int P, int MT1, int MT2>
+// FOLD: the folded operands (see bottleneck_stream_direct_kernel): scales in the weights, shifts as (hi, lo) pairs in p.tab, shift and
+// residual added by MFMA, every epilogue = fp16(relu(acc)); no table ever travels through LDS.
+template <int P, int MT1, int MT2, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = BnsGeom<P>;
@@ -152,8 +158,42 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 6 * G::TABB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, FOLD ? (2 * P + G::C) * 4 : 6 * G::TABB, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
+
+  // folded form: shift pairs of this wave's MFMA rows per (epilogue, tile) and the residual's 0/1 matrix (see the direct kernel)
+  [[maybe_unused]] unsigned shp[6][2];
+  [[maybe_unused]] uint4_t permA[2];
+  [[maybe_unused]] const uint4_t onesB = uint4_t{0x3C003C00u, 0u, 0u, 0u};
+  if constexpr (FOLD) {
+    const int sg = bns_sigma(l31);
+    const unsigned so = lhi == 0 ? 4u * (unsigned)sg : kOOB;
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        shp[e][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, so, 4 * (e * P + (2 * wcol + i) * 32), 0);
+    const bool on = lhi == (sg >> 4);
+    const int ph = (sg >> 3) & 1, pe = sg & 7;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      unsigned w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (on && ph == hh && (pe >> 1) == k) ? (0x3C00u << (16 * (pe & 1))) : 0u;
+      permA[hh] = uint4_t{w[0], w[1], w[2], w[3]};
+    }
+    asm volatile("" ::: "memory");     // older than every hand-counted load below
+  }
+  [[maybe_unused]] auto add_shift = [&](int e, auto& A, auto mtc) {      // A[i][j] += shift of epilogue e (one MFMA per tile)
+    constexpr int MT = decltype(mtc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint4_t sa = uint4_t{shp[e][i], 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, sa), __builtin_bit_cast(half8_t, onesB), A[i][j], 0, 0, 0);
+    }
+  };
 
 #if FT_BNS_L2_TOUCH
   // the first round of workgroups on an XCD pulls the block's weight stream into that XCD's L2, each its own 1/n-th, one
@@ -200,6 +240,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
                                                g * WSTEP + (t * 4 + wave) * 1024, 0, 0);
   };
   auto issue_tab = [&](int e) {       // {scale[P], shift[P]} of epilogue e; one buffer: issued once epilogue e-1 is behind a barrier
+    if constexpr (FOLD) return;
 #pragma unroll
     for (int t = 0; t < G::LT; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + G::TAB + (t * 4 + wave) * 256), 4, (unsigned)lane * 4u,
@@ -311,15 +352,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNS_BARRIER();
   {
-    const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+    if constexpr (FOLD) add_shift(0, acc1, std::integral_constant<int, MT1>{});
+    [[maybe_unused]] const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
-      float4_t sc[4], sh[4];
+      [[maybe_unused]] const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      [[maybe_unused]] float4_t sc[4], sh[4];
+      if constexpr (!FOLD) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
       }
 #pragma unroll
       for (int j = 0; j < MT1; ++j) {
@@ -328,7 +372,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
         const int iy = y0 - 1 + hr;
         const bool inside = (unsigned)iy < (unsigned)p.H;     // out-of-image halo rows are conv2's zero padding
         half8_t h8[2];
-        bn_relu_acc16(acc1[i][j], sc, sh, h8);
+        if constexpr (FOLD) relu_acc16(acc1[i][j], h8);
+        else bn_relu_acc16(acc1[i][j], sc, sh, h8);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           uint4_t u = __builtin_bit_cast(uint4_t, h8[h]);
@@ -457,21 +502,25 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNS_BARRIER();
   {
-    const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+    if constexpr (FOLD) add_shift(1, acc, std::integral_constant<int, MT2>{});
+    [[maybe_unused]] const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ch = (2 * wcol + i) * 32 + 16 * lhi;
-      float4_t sc[4], sh[4];
+      [[maybe_unused]] const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+      [[maybe_unused]] float4_t sc[4], sh[4];
+      if constexpr (!FOLD) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
       }
 #pragma unroll
       for (int j = 0; j < MT2; ++j) {
         const int m = m_out[j];
         half8_t h8[2];
-        bn_relu_acc16(acc[i][j], sc, sh, h8);
+        if constexpr (FOLD) relu_acc16(acc[i][j], h8);
+        else bn_relu_acc16(acc[i][j], sc, sh, h8);
         char* rowp = smem + m * ROWB;
         const int cb = (2 * wcol + i) * 4 + 2 * lhi;
 #pragma unroll
@@ -526,31 +575,54 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
       }
       constexpr int glast = G::G3 + q * KC + KC - 1;
       char* stg = smem + (P == 128 ? G::STG : G::WBASE + (glast % 3) * WSTEP);
-      const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+      [[maybe_unused]] const float* tb = reinterpret_cast<const float*>(smem + G::TAB);
+      if constexpr (FOLD) {
+        // shift3 of the quarter and the residual join the accumulators as three MFMAs per tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4_t sa = uint4_t{shp[2 + q][i], 0u, 0u, 0u};
+#pragma unroll
+          for (int j = 0; j < MT2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, sa), __builtin_bit_cast(half8_t, onesB), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, permA[h]), __builtin_bit_cast(half8_t, res[q][i][j][h]),
+                                                                 acc[i][j], 0, 0, 0);
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ch = (2 * wcol + i) * 32 + 16 * lhi;
-        float4_t sc[4], sh[4];
+        [[maybe_unused]] const int ch = (2 * wcol + i) * 32 + 16 * lhi;
+        [[maybe_unused]] float4_t sc[4], sh[4];
+        if constexpr (!FOLD) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+          for (int g4 = 0; g4 < 4; ++g4) {
+            sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+            sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+          }
         }
 #pragma unroll
         for (int j = 0; j < MT2; ++j) {
+          [[maybe_unused]] half8_t o8[2];
+          if constexpr (FOLD) relu_acc16(acc[i][j], o8);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
-#if FT_BNS_PK_RES
-            const half8_t o = bn_res_relu_acc8(acc[i][j], h, sc, sh, rs);
-#else
             half8_t o;
+            if constexpr (FOLD) {
+              o = o8[h];
+            } else {
+              const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
+#if FT_BNS_PK_RES
+              o = bn_res_relu_acc8(acc[i][j], h, sc, sh, rs);
+#else
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int r = h * 8 + e;
-              o[e] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
-            }
+              for (int e = 0; e < 8; ++e) {
+                const int r = h * 8 + e;
+                o[e] = (half_t)__builtin_fmaxf(acc[i][j][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3] + (float)rs[e], 0.f);
+              }
 #endif
+            }
             if constexpr (STAGED) {
               const int m = m_out[j];
               *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((2 * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
@@ -614,7 +686,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
 // two waves share a SIMD: every weight byte still reaches the CU once (the waves split the CHANNEL tiles, not the pixels), but
 // while one wave of a SIMD is held at its issue port by its weight loads (a buffer_load_b128 holds it ~40 cycles: a step of the
 // 4-wave form costs its MFMA time + ~335 cycles for its eight loads, tools/dev/ubench/l2_burst.hip) the other one multiplies.
-template <int MT1, int MT2, bool XH, int NS, int HEADC = 0, int NW = 4>
+// FOLD (round 6) = the folded operands: the BatchNorm scales are in the fp16 weights (one rounding, like the plain weights),
+// p.tab holds the shifts as (hi, lo) fp16 pairs, uint32 [P + P + C].  A shift enters its accumulator as ONE extra MFMA per tile (A row
+// = {hi, lo, 0 ..}, B = ones at k = 0, 1), the identity residual as TWO (A = the 0/1 matrix that maps the registers the residual was
+// picked up in — 16 consecutive channels per lane — onto the tile's MFMA rows), and every epilogue shrinks to fp16(relu(acc)):
+// per quarter of phase 3 ~190 vector instructions + 32 table reads become 12 MFMAs + 64 (ft_common.h: relu_acc16).
+template <int MT1, int MT2, bool XH, int NS, int HEADC = 0, int NW = 4, bool FOLD = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kernel(const BnsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 256;
@@ -671,7 +748,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.ws), 0, p.ws_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, 6 * G::TABB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tab), 0, FOLD ? (2 * P + G::C) * 4 : 6 * G::TABB, 0x00020000);
   constexpr unsigned kOOB = 0x80000000u;
 
   unsigned x_voff[LX];
@@ -701,8 +778,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < CTW; ++i)
+      for (int i = 0; i < CTW; ++i) {
+#if FT_BNSD_ABL & 32
+        if (g >= NC1) { uint4_t z{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(z)); areg[SL][kk][i] = z; continue; }
+#endif
         areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + CTW * wcol + i) * 1024, 0);
+      }
   };
 
   auto load_a_half = [&](auto slotc, int g, auto halfc) {   // K16 slices {0, 1} or {2, 3} of the step
@@ -710,8 +791,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 #pragma unroll
     for (int kk = 2 * HF; kk < 2 * HF + 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < CTW; ++i)
+      for (int i = 0; i < CTW; ++i) {
+#if FT_BNSD_ABL & 16
+        { uint4_t z{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(z)); areg[SL][kk][i] = z; continue; }
+#endif
         areg[SL][kk][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, g * WSTEP + (kk * NCT + CTW * wcol + i) * 1024, 0);
+      }
   };
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BNSD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -735,9 +820,46 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   }
 #endif
   // prologue: all six tables (12 KiB, 3 x 256-byte pieces per wave ... 48 pieces), x chunks 0..2, weights of steps 0 and 1, zero row
+  // folded form: no tables in LDS; the shift pair of MFMA row l31 of every (epilogue, channel tile) of this wave sits in a register
+  // (lanes 32..63 hold k = 8..15 of the shift slice: zeros, fetched out of range), and the two residual slices' 0/1 matrix is built here:
+  // accumulator register k of lane (pixel, half) is channel 16 half + k (bns_sigma), the residual registers hold channels
+  // 16 half + 8 h + e as element e of slice h, which the MFMA reads as k = 8 half + e: row r takes slice (sigma(r) >> 3) & 1, k = 8 (sigma(r) >> 4) + (sigma(r) & 7)
+  [[maybe_unused]] unsigned shp[6][CTW];
+  [[maybe_unused]] uint4_t permA[2];
+  [[maybe_unused]] const uint4_t onesB = uint4_t{0x3C003C00u, 0u, 0u, 0u};
+  if constexpr (FOLD) {
+    const int sg = bns_sigma(l31);
+    const unsigned so = lhi == 0 ? 4u * (unsigned)sg : kOOB;
 #pragma unroll
-  for (int t = 0; t < 48 / NW; ++t)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * NW + wave) * 256), 4, (unsigned)lane * 4u, (t * NW + wave) * 256, 0, 0);
+    for (int e = 0; e < 6; ++e)
+#pragma unroll
+      for (int i = 0; i < CTW; ++i)
+        shp[e][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, so, 4 * (e * P + (CTW * wcol + i) * 32), 0);
+    const bool on = lhi == (sg >> 4);
+    const int ph = (sg >> 3) & 1, pe = sg & 7;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      unsigned w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (on && ph == hh && (pe >> 1) == k) ? (0x3C00u << (16 * (pe & 1))) : 0u;
+      permA[hh] = uint4_t{w[0], w[1], w[2], w[3]};
+    }
+    asm volatile("" ::: "memory");     // older than every hand-counted load below
+  } else {
+#pragma unroll
+    for (int t = 0; t < 48 / NW; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * NW + wave) * 256), 4, (unsigned)lane * 4u, (t * NW + wave) * 256, 0, 0);
+  }
+  [[maybe_unused]] auto add_shift = [&](int e, auto& A, auto mtc) {      // A[i][j] += shift of epilogue e (one MFMA per tile)
+    constexpr int MT = decltype(mtc)::value;
+#pragma unroll
+    for (int i = 0; i < CTW; ++i) {
+      const uint4_t sa = uint4_t{shp[e][i], 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, sa), __builtin_bit_cast(half8_t, onesB), A[i][j], 0, 0, 0);
+    }
+  };
   issue_x(0, 0);
   issue_x(1, 1);
   issue_x(2, 2);
@@ -780,7 +902,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
       constexpr int S = decltype(setc)::value;
       const char* xb = smem + buf * G::XSTRIDE;
 #pragma unroll
-      for (int j = 0; j < MT1; ++j) fx[S][j] = *reinterpret_cast<const uint4_t*>(xb + (b1_off[j] ^ (kk << 5)));
+      for (int j = 0; j < MT1; ++j) {
+#if FT_BNSD_ABL & 8
+        { uint4_t z{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(z)); fx[S][j] = z; continue; }
+#endif
+        fx[S][j] = *reinterpret_cast<const uint4_t*>(xb + (b1_off[j] ^ (kk << 5)));
+      }
     };
     auto mma1 = [&](auto setc, auto slotc, auto kkc) {
       constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
@@ -794,6 +921,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
     // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight steps (8 loads each) may fly
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 4 * CTW * D) : "memory");
     BNS_BARRIER();
+    BNSD_TS(7);             // start-up: x chunk 0 of every wave has landed
     ldx(c0{}, 0, 0);
     bns_unroll<NC1>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
@@ -822,7 +950,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
           __builtin_amdgcn_sched_group_barrier(0x100, (MT1 + 2) / 3, 0);
         });
       }
-      if (!HEAD && c % 4 == (CTW * wcol) / 2) {  // this chunk holds the channels of this wave column for quarter c / 4
+      if (!HEAD && !(FT_BNSD_ABL & 2) && c % 4 == (CTW * wcol) / 2) {  // this chunk holds the channels of this wave column for quarter c / 4
         constexpr int q = c / 4;
         const char* xb = smem + buf * G::XSTRIDE;
 #pragma unroll
@@ -855,10 +983,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         // chunk c+1 are the weights of step c+1 (needed next anyway), x chunk c+2 and the weights of step c+2.
         // (with a prefetch distance of three or more steps the weights of step c+1 are OLDER than x chunk c+1: two weight
         // steps may stay in flight)
+#if FT_BNSD_ABL & 4
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif !(FT_BNSD_ABL & 16)
         if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX + (D == 2 ? 4 * CTW : 8 * CTW)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D == 2 ? 4 * CTW : 8 * CTW) : "memory");
+#else
+        if constexpr (c + 2 < NC1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#if !(FT_BNSD_ABL & 1)
         BNS_BARRIER();
-        if constexpr (c + 3 < NC1) issue_x(c + 3, buf);
+#endif
+        if constexpr (c + 3 < NC1 && !(FT_BNSD_ABL & 4)) issue_x(c + 3, buf);
         ldx(c0{}, (c + 1) % 3, 0);
       }
       mma1(c1{}, slot{}, std::integral_constant<int, 3>{});
@@ -868,15 +1005,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNS_BARRIER();          // every wave is past its last x-chunk read: the x buffers become T1
   {
-    const float* tb = reinterpret_cast<const float*>(smem + TABS);
+    if constexpr (FOLD) add_shift(0, acc1, std::integral_constant<int, MT1>{});
+    [[maybe_unused]] const float* tb = reinterpret_cast<const float*>(smem + TABS);
 #pragma unroll
     for (int i = 0; i < CTW; ++i) {
-      const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
-      float4_t sc[4], sh[4];
+      [[maybe_unused]] const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
+      [[maybe_unused]] float4_t sc[4], sh[4];
+      if constexpr (!FOLD) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
       }
 #pragma unroll
       for (int j = 0; j < MT1; ++j) {
@@ -885,7 +1025,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         const int iy = iy0 + hr, ix = XH ? x0 - 1 + (hp - hr * PW) : 0;
         const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
         half8_t h8[2];
-        bn_relu_acc16(acc1[i][j], sc, sh, h8);
+        if constexpr (FOLD) relu_acc16(acc1[i][j], h8);
+        else bn_relu_acc16(acc1[i][j], sc, sh, h8);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           uint4_t u = __builtin_bit_cast(uint4_t, h8[h]);
@@ -938,7 +1079,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   auto ldb = [&](auto setc, int kk, const int (&rb)[MT2]) {
     constexpr int S = decltype(setc)::value;
 #pragma unroll
-    for (int j = 0; j < MT2; ++j) fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (kk << 5)));
+    for (int j = 0; j < MT2; ++j) {
+#if FT_BNSD_ABL & 64
+      { uint4_t z{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(z)); fb[S][j] = z; continue; }
+#endif
+      fb[S][j] = *reinterpret_cast<const uint4_t*>(smem + (rb[j] ^ (kk << 5)));
+    }
   };
   auto mma2 = [&](auto setc, auto slotc, auto kkc, float16_t (&A)[CTW][MT2]) {
     constexpr int S = decltype(setc)::value, SL = decltype(slotc)::value, kk = decltype(kkc)::value;
@@ -977,7 +1123,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         __builtin_amdgcn_sched_group_barrier(0x100, (i & 1) ? (MT2 + 1) / 2 : MT2 / 2, 0);
         if constexpr (NX > 0) {
           __builtin_amdgcn_sched_group_barrier(0x002, NX, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the folded-BN table reads of the piece
+          __builtin_amdgcn_sched_group_barrier(0x100, FOLD ? 0 : 1, 0);      // the folded-BN table reads of the piece
           __builtin_amdgcn_sched_group_barrier(0x200, (i & 3) == 3 ? 1 : 0, 0);
         }
       });
@@ -1009,21 +1155,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BNS_BARRIER();          // every wave is past its last T1 read: T2 overwrites T1
   {
-    const float* tb = reinterpret_cast<const float*>(smem + TABS + G::TABB);
+    if constexpr (FOLD) add_shift(1, acc, std::integral_constant<int, MT2>{});
+    [[maybe_unused]] const float* tb = reinterpret_cast<const float*>(smem + TABS + G::TABB);
 #pragma unroll
     for (int i = 0; i < CTW; ++i) {
-      const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
-      float4_t sc[4], sh[4];
+      [[maybe_unused]] const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
+      [[maybe_unused]] float4_t sc[4], sh[4];
+      if constexpr (!FOLD) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
       }
 #pragma unroll
       for (int j = 0; j < MT2; ++j) {
         const int m = m_out[j];
         half8_t h8[2];
-        bn_relu_acc16(acc[i][j], sc, sh, h8);
+        if constexpr (FOLD) relu_acc16(acc[i][j], h8);
+        else bn_relu_acc16(acc[i][j], sc, sh, h8);
         char* rowp = smem + m * ROWB;
         const int cb = (CTW * wcol + i) * 4 + 2 * lhi;
 #pragma unroll
@@ -1068,19 +1218,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
     auto epi_piece = [&](auto qc, int i, int j, float16_t (&A)[CTW][MT2]) {
       constexpr int q = decltype(qc)::value;
       char* stg = smem + STG + (q & 1) * STGB;
-      const float* tb = reinterpret_cast<const float*>(smem + TABS + (2 + q) * G::TABB);
-      const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
-      float4_t sc[4], sh[4];
+      [[maybe_unused]] const float* tb = reinterpret_cast<const float*>(smem + TABS + (2 + q) * G::TABB);
+      [[maybe_unused]] const int ch = (CTW * wcol + i) * 32 + 16 * lhi;
+      [[maybe_unused]] float4_t sc[4], sh[4];
+      [[maybe_unused]] half8_t o8[2];
+      if constexpr (FOLD) {
+        relu_acc16(A[i][j], o8);
+      } else {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
-        sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *reinterpret_cast<const float4_t*>(tb + ch + g4 * 4);
+          sh[g4] = *reinterpret_cast<const float4_t*>(tb + P + ch + g4 * 4);
+        }
       }
       const int m = m_out[j];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const half8_t rs = __builtin_bit_cast(half8_t, res[q][i][j][h]);
-        const half8_t o = bn_res_relu_acc8(A[i][j], h, sc, sh, rs);
+        half8_t o;
+        if constexpr (FOLD) o = o8[h];
+        else o = bn_res_relu_acc8(A[i][j], h, sc, sh, __builtin_bit_cast(half8_t, res[q][i][j][h]));
 #if FT_BNS_STG
         *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((CTW * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
 #else
@@ -1090,6 +1246,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo + (unsigned)(q * P * 2), 0, FT_BNS_DIRECT_AUX);
 #endif
       }
+    };
+    // folded form: shift3 of the quarter and the residual join tile (i, j)'s accumulator as three MFMAs
+    [[maybe_unused]] auto fold_tail = [&](auto qc, int i, int j, float16_t (&A)[CTW][MT2]) {
+      constexpr int q = decltype(qc)::value;
+      const uint4_t sa = uint4_t{shp[2 + q][i], 0u, 0u, 0u};
+      A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, sa), __builtin_bit_cast(half8_t, onesB), A[i][j], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, permA[h]), __builtin_bit_cast(half8_t, res[q][i][j][h]), A[i][j], 0, 0, 0);
     };
     auto readout = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
@@ -1111,12 +1276,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 #pragma unroll
           for (int r = 0; r < 16; ++r) A[i][j][r] = 0.f;
     };
-#if FT_BNS_OVL
+    constexpr bool OVL = FT_BNS_OVL && CTW * MT2 == KC;     // one epilogue tile per weight step
+    if constexpr (OVL) {
     // Overlapped form: two accumulator sets alternate between the quarters; the epilogue of quarter q-1 (VALU + LDS writes,
     // ~3.4 k cycles when it ran alone behind its quarter) rides inside the weight steps of quarter q, one (i, j) tile per
     // step, pinned between the MFMAs by dstep's issue groups.  The staging tiles alternate as before: tile (q-1) & 1 is
     // written during quarter q, read out behind quarter q's barrier; its previous readers (quarter q-3) are two barriers back.
-    static_assert(2 * MT2 == KC, "one epilogue tile per weight step");
     float16_t acc_b[CTW][MT2];
     zero_set(acc_b);
     bns_unroll<4>([&](auto qc) {
@@ -1128,8 +1293,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         constexpr int g = G3 + q * KC + kc;
         row_bases(0, (kc + 1) % KC, 0, rbn, false);
         if constexpr (q > 0) {
-          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < GEND, rbn, A, std::integral_constant<int, 12>{},
-                [&] { epi_piece(std::integral_constant<int, q - 1>{}, kc / MT2, kc % MT2, Aprev); });
+          dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < GEND, rbn, A, std::integral_constant<int, FOLD ? 4 : 12>{},
+                [&] {
+                  if constexpr (FOLD) fold_tail(std::integral_constant<int, q - 1>{}, kc / MT2, kc % MT2, Aprev);
+                  epi_piece(std::integral_constant<int, q - 1>{}, kc / MT2, kc % MT2, Aprev);
+                });
         } else {
           dstep(std::integral_constant<int, g % NS>{}, g, rb, g + 1 < GEND, rbn, A, nx0{}, no_extra);
         }
@@ -1147,11 +1315,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 #pragma unroll
     for (int i = 0; i < CTW; ++i)
 #pragma unroll
-      for (int j = 0; j < MT2; ++j) epi_piece(std::integral_constant<int, 3>{}, i, j, acc_b);
+      for (int j = 0; j < MT2; ++j) {
+        if constexpr (FOLD) fold_tail(std::integral_constant<int, 3>{}, i, j, acc_b);
+        epi_piece(std::integral_constant<int, 3>{}, i, j, acc_b);
+      }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BNS_BARRIER();
     readout(std::integral_constant<int, 3>{});
-#else
+    } else {
     bns_unroll<4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       bns_unroll<KC>([&](auto kcc) {
@@ -1162,6 +1333,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 #pragma unroll
         for (int j = 0; j < MT2; ++j) rb[j] = rbn[j];
       });
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int i = 0; i < CTW; ++i)
+#pragma unroll
+          for (int j = 0; j < MT2; ++j) fold_tail(qc, i, j, acc);
+      }
 #pragma unroll
       for (int i = 0; i < CTW; ++i)
 #pragma unroll
@@ -1174,7 +1351,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
       readout(qc);
 #endif
     });
-#endif
+    }
   }
   if (p.dbg & 32) {
     ts[5] = __builtin_amdgcn_s_memtime();
@@ -1350,9 +1527,9 @@ static int bns_plan(const ft_bottleneck_desc* d, BnsPlan* out) {
   return FT_OK;
 }
 
-template <int P, int MT1, int MT2>
+template <int P, int MT1, int MT2, bool FOLD = false>
 static int bns_launch(const BnsParams& p, hipStream_t s) {
-  auto k = bottleneck_stream_kernel<P, MT1, MT2>;
+  auto k = bottleneck_stream_kernel<P, MT1, MT2, FOLD>;
   static bool attr_done[64] = {};          // the LDS opt-in is per device
   int dev = 0;
   FT_HIP_CHECK(hipGetDevice(&dev));
@@ -1374,9 +1551,9 @@ static int bns_launch(const BnsParams& p, hipStream_t s) {
 #ifndef FT_BNS_WAVES_DEFAULT
 #define FT_BNS_WAVES_DEFAULT 4      // waves per workgroup of the direct kernels unless FT_BNS_WAVES says otherwise
 #endif
-template <int MT1, int MT2, bool XH, int HEADC = 0, int NW = 4>
+template <int MT1, int MT2, bool XH, int HEADC = 0, int NW = 4, bool FOLD = false>
 static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
-  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : FT_BNS_SLOTS, HEADC, NW>;
+  auto k = bottleneck_stream_direct_kernel<MT1, MT2, XH, XH ? FT_BNS_XH_SLOTS : FT_BNS_SLOTS, HEADC, NW, FOLD>;
   constexpr int lds = 81920 + 2 * MT2 * 32 * 512;
   static bool attr_done[64] = {};          // the LDS opt-in is per device
   int dev = 0;
@@ -1396,6 +1573,12 @@ static int bns_launch_direct(const BnsParams& p, hipStream_t s) {
 extern "C" int ft_bottleneck_stream_supported(const ft_bottleneck_desc* d) {
   ft::BnsPlan pl;
   return ft::bns_plan(d, &pl);
+}
+
+extern "C" int ft_bottleneck_stream_folds(const ft_bottleneck_desc* d) {
+  ft::BnsPlan pl;
+  if (ft::bns_plan(d, &pl) != FT_OK) return 0;
+  return pl.variant != 4;
 }
 
 extern "C" long long ft_bottleneck_stream_weight_bytes(const ft_bottleneck_desc* d) {
@@ -1438,6 +1621,7 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   const int st = bns_plan(d, &pl);
   if (st != FT_OK) return st;
   if (!x || !wstream || !tables || !y || x == y) return FT_ERR_INVALID_ARG;
+  if (d->folded && pl.variant == 4) return FT_ERR_UNSUPPORTED;      // the stride-2 head keeps its tables (ft_bottleneck_stream_folds)
   BnsParams p{};
   p.x = static_cast<const char*>(x);
   p.y = static_cast<char*>(y);
@@ -1462,6 +1646,17 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
   // full-width strips (batch 64: 46.1 vs 46.0 us — the eight-wave form gains in phases 1 and 3 what its doubled pixel-operand
   // reads cost in phase 2; both forms sit on the CU's 64 B/clk weight path: 32 KiB of fragments per 16-MFMA step)
   const bool waves8 = getenv("FT_BNS_WAVES") ? atoi(getenv("FT_BNS_WAVES")) == 8 : (FT_BNS_WAVES_DEFAULT == 8 || pl.variant == 3);
+  static const bool no_direct = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;
+  if (d->folded) {
+    switch (pl.variant) {
+      case 0: return bns_launch<128, 4, 3, true>(p, s);
+      case 5: return bns_launch<128, 3, 2, true>(p, s);
+      case 1: return bns_launch<256, 4, 3, true>(p, s);
+      case 3: return waves8 ? bns_launch_direct<2, 1, true, 0, 8, true>(p, s) : bns_launch_direct<2, 1, true, 0, 4, true>(p, s);
+      default: return no_direct ? bns_launch<256, 3, 2, true>(p, s)
+                                : (waves8 ? bns_launch_direct<3, 2, false, 0, 8, true>(p, s) : bns_launch_direct<3, 2, false, 0, 4, true>(p, s));
+    }
+  }
   switch (pl.variant) {
     case 0: return bns_launch<128, 4, 3>(p, s);
     case 5: return bns_launch<128, 3, 2>(p, s);
@@ -1470,7 +1665,6 @@ extern "C" int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void*
     case 4: return waves8 ? bns_launch_direct<4, 1, false, 8, 8>(p, s) : bns_launch_direct<4, 1, false, 8>(p, s);
     default: {
       // 64-pixel strips at 256 planes: weights straight to registers (FT_BNS_DIRECT=0: through the LDS ring, dev A/B)
-      static const bool no_direct = getenv("FT_BNS_DIRECT") && atoi(getenv("FT_BNS_DIRECT")) == 0;
       return no_direct ? bns_launch<256, 3, 2>(p, s) : (waves8 ? bns_launch_direct<3, 2, false, 0, 8>(p, s) : bns_launch_direct<3, 2, false>(p, s));
     }
   }

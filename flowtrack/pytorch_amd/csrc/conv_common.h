@@ -71,16 +71,17 @@ template <typename T> struct Elem;
 template <> struct Elem<half_t> { static constexpr int VEC = 8; };
 template <> struct Elem<float> { static constexpr int VEC = 4; };
 
-// act(v) = max(v, k * v) with k = 0 (ReLU), slope (LeakyReLU, 0 <= slope <= 1) or 1 (none): the values of `v > 0 ? v : v * k`
-// in two vector instructions, k loop-invariant scalar work.  (The branchy form compiled to two scalar compare-and-branch pairs
-// PER ELEMENT inside the unrolled epilogues: 64 s_cbranch per 128-pixel tile in the stem kernel.)  Non-finite inputs: NaN stays
-// NaN (max(NaN, NaN); the earlier k * min(v, 0) + max(v, 0) form returned 0 for it — v_min / v_max drop a NaN operand), +-inf
-// stay what torch gives, with ONE exception: ReLU(-inf) returns -inf where torch returns 0 (-inf * 0 = NaN, and max(-inf, NaN)
-// = -inf).  A slope > 1 takes the compare-and-select form (uniform branch).  conv_direct.hip uses the same max(v, k * v) in its own
-// epilogues; the ReLU-only fused bottleneck kernels use max(v, 0) and conv_igemm8.hip max(v, 0) + k * min(v, 0) (NaN -> 0 in both).
+// act(v) = `v > 0 ? v : k * v` with k = 0 (ReLU), slope (LeakyReLU, 0 <= slope <= 1) or 1 (none), branch-free (ft_common.h: act_mul,
+// three vector instructions; the branchy form compiled to two scalar compare-and-branch pairs PER ELEMENT inside the unrolled
+// epilogues: 64 s_cbranch per 128-pixel tile in the stem kernel).  Non-finite inputs come out as torch has them: NaN stays NaN,
+// +inf stays +inf, -inf becomes k * -inf and 0 under ReLU (rounds 2-5 returned -inf there: max(v, 0 * v) with the IEEE product
+// NaN).  A slope > 1 takes the compare-and-select form (uniform branch).  conv_direct.hip / conv_wstat.hip call act_mul() in their
+// own epilogues; the ReLU-only fused bottleneck kernels use max(v, 0) and conv_igemm8.hip max(v, 0) + k * min(v, 0) (NaN -> 0 in both,
+// documented there).  tests/test_conv_gpu.py: test_epilogue_keeps_non_finite_values, test_relu_of_non_finite_values.
+// (act_mul: ft_common.h)
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   const float k = act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f);
-  if (k <= 1.f) return __builtin_fmaxf(v, v * k);
+  if (k <= 1.f) return act_mul(v, k);
   return v > 0.f ? v : v * k;
 }
 

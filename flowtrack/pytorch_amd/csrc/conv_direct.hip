@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
         const int r = h * 8 + e;
         float v = a[r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3];
         if constexpr (HAS_RES) v += (float)rs[e];
-        o[h][e] = (half_t)__builtin_fmaxf(v, v * act_k);
+        o[h][e] = (half_t)act_mul(v, act_k);
       }
       *reinterpret_cast<half8_t*>(stg + row * G::STG_ROWB + ((((ch >> 3) + h) ^ (row & SMASK)) << 4)) = o[h];
     }
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float u = v[e] * sc[g4][e] + sh[g4][e];
-          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)__builtin_fmaxf(u, u * act_k);
+          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)act_mul(u, act_k);
         }
       }
 #pragma unroll
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2_direct_kernel(const C3Params
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float u = v[e] * sc[g4][e] + sh[g4][e];
-          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)__builtin_fmaxf(u, u * act_k);
+          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)act_mul(u, act_k);
         }
       }
 #pragma unroll
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2p_direct_kernel(const C3Param
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float u = v[e] * sc[g4][e] + sh[g4][e];
-          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)__builtin_fmaxf(u, u * act_k);
+          o[g4 >> 1][(g4 & 1) * 4 + e] = (half_t)act_mul(u, act_k);
         }
       }
 #pragma unroll
@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(64 * WC * WP, 1) void conv1x1_stream_kernel(const C
           for (int e = 0; e < 8; ++e) {
             const int r = h * 8 + e;
             const float v = acc[i][j][r] * sc[i][r >> 2][r & 3] + sh[i][r >> 2][r & 3];
-            o[e] = (half_t)__builtin_fmaxf(v, v * act_k);
+            o[e] = (half_t)act_mul(v, act_k);
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo, h * 16, 0);
         }

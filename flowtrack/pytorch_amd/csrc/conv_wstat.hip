@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void conv5x5s2_wstat_kernel(const WsParams 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float u = v[e] * sc[e] + sh[e];
-      o[e] = (half_t)__builtin_fmaxf(u, u * act_k);
+      o[e] = (half_t)act_mul(u, act_k);
     }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), rsrc_y, vo_prev, 0, FT_YSTORE_BUF_AUX);
   };

@@ -53,6 +53,16 @@ typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+// act(v) for k = 0 (ReLU) / 0 < k <= 1 (LeakyReLU) / 1 (none) = `v > 0 ? v : k * v` with torch's value for EVERY input, three vector
+// instructions: t = k (*) v with (*) = v_mul_legacy_f32 (0 * x = 0 for every x, so ReLU(-inf) = 0 where the IEEE product -inf * 0 = NaN
+// made the two-instruction max(v, k * v) of rounds 2-5 return -inf), then `!(v <= 0) ? v : t`: the negated ordered compare keeps a NaN
+// (F.relu(NaN) = NaN; v_max would drop it) and +inf, every other value takes t.  conv_common.h: apply_act.
+__device__ __forceinline__ float act_mul(float v, float k) {
+  float t;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(t) : "v"(k), "v"(v));      // hipcc has no builtin for the legacy multiply
+  return !(v <= 0.f) ? v : t;
+}
+
 // Packed epilogues.  The fused kernels are bound by instruction ISSUE (a SIMD issues about one instruction per four cycles; of
 // the ~7000 instructions of a 128- / 256-plane block's workgroup 8-12 % are MFMAs, 30-40 % are the BatchNorm + ReLU + fp16
 // epilogues: profiles/README.md, round 5), so two results per instruction where the ISA has it:
@@ -101,6 +111,17 @@ __device__ __forceinline__ half8_t bn_res_relu_acc8(const float16_t& acc, int h,
     o[e + 1] = v[1];
   }
   return o;
+}
+
+// Folded form (round 6): the BatchNorm scale sits in the fp16 weights, the shift (and the identity residual) reach the accumulator as
+// extra MFMA k-steps, so the epilogue of a 32 x 32 block is fp16(relu(acc)): v_cvt_pk_f16_f32 + v_pk_max_f16 per pair of values.
+__device__ __forceinline__ void relu_acc16(const float16_t& acc, half8_t (&h8)[2]) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const half2_t o = __builtin_elementwise_max(__builtin_convertvector(float2_t{acc[r], acc[r + 1]}, half2_t), half2_t{(half_t)0.f, (half_t)0.f});
+    h8[r >> 3][r & 7] = o[0];
+    h8[r >> 3][(r & 7) + 1] = o[1];
+  }
 }
 
 // Activation-output stores.  FT_YSTORE_AUX = 16 (sc1) makes them write-through: nothing is left dirty in the XCD L2s for

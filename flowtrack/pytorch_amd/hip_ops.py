@@ -1185,21 +1185,53 @@ def bottleneck_cluster_supported(x: ActView, y: ActView, planes: int) -> bool:
     return _lib.load().ft_bottleneck_cluster_supported(ctypes.byref(d)) == 0
 
 
-def _bottleneck_stream_operands(c1: "FusedConv", d, x: ActView, planes: int, p1, p2, p3):
-    """(weight stream, folded-BN tables) of ft_bottleneck_stream_fwd / ft_bottleneck_cluster_fwd, built once per weight set."""
+#: folded operands for the streamed-weights bottleneck kernels (round 6; FT_BNS_FOLD=0 = the scale / shift tables of round 2)
+FOLD_BOTTLENECK_STREAM = os.environ.get("FT_BNS_FOLD", "1") != "0"
+
+
+def _folded_kmajor(conv: "FusedConv"):
+    """fp16 [cout][(ky * kw + kx) * cin + ci] weights with the folded BatchNorm SCALE multiplied in (one rounding from the fp32 weights,
+    like the plain fp16 weights), and the fp32 shift: the operands of the kernels that add the shift by MFMA."""
+    scale, shift = fold_scale_shift(conv.cout, conv.cout, conv._bias, conv._bn, torch.device("cpu"))
+    w = conv._weight.detach().float().cpu().permute(0, 2, 3, 1).reshape(conv.cout, -1)
+    if scale is not None:
+        w = w * scale[:, None]
+    return w.half().contiguous(), (shift if shift is not None else torch.zeros(conv.cout))
+
+
+def shift_pairs(shift: torch.Tensor) -> torch.Tensor:
+    """fp32 shifts as (hi, lo) fp16 pairs in one int32 each: hi = fp16(shift) in bits 0-15, lo = fp16(shift - hi) in bits 16-31
+    (ft_bottleneck_desc.folded): the two halves are two k-slots of the MFMA slice that adds the shift, so it arrives with ~22 bits."""
+    hi = shift.float().half()
+    lo = (shift.float() - hi.float()).half()
+    return torch.stack([hi, lo], dim=-1).contiguous().view(torch.int32).reshape(-1)
+
+
+def _bottleneck_stream_operands(c1: "FusedConv", d, x: ActView, planes: int, p1, p2, p3, convs=None):
+    """(weight stream, tables) of ft_bottleneck_stream_fwd / ft_bottleneck_cluster_fwd, built once per weight set.  `convs` = the three
+    FusedConv layers: the FOLDED operands (d.folded = 1: scales in the weights, tables = shift pairs); None = the table form."""
     lib = _lib.load()
     (w1, s1, b1), (w2, s2, b2), (w3, s3, b3) = p1, p2, p3
-    key = ("bns_stream", x.N, x.H, x.W)
+    folded = convs is not None
+    key = ("bns_stream_folded" if folded else "bns_stream", x.N, x.H, x.W)
     cached = c1._packed.get(key) if hasattr(c1, "_packed") else None
     if cached is None:
+        P = planes
+        if folded:
+            dev = x.t.device
+            (w1, sh1), (w2, sh2), (w3, sh3) = (_folded_kmajor(c) for c in convs)
+            if (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape)) != ((P, 4 * P), (P, 9 * P), (4 * P, P)):
+                raise FlowtrackHipError(f"folded bottleneck weights: unexpected shapes {tuple(w1.shape)} {tuple(w2.shape)} {tuple(w3.shape)}")
+            w1, w2, w3 = w1.to(dev), w2.to(dev), w3.to(dev)
+            tables = torch.cat([shift_pairs(sh1), shift_pairs(sh2), shift_pairs(sh3)]).contiguous().to(dev)
+        else:
+            tables = torch.cat([s1.flatten()[:P], b1.flatten()[:P], s2.flatten()[:P], b2.flatten()[:P]] +
+                               [t.flatten()[q * P:(q + 1) * P] for q in range(4) for t in (s3, b3)]).float().contiguous()
         nbytes = int(lib.ft_bottleneck_stream_weight_bytes(ctypes.byref(d)))
         wstream = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
         check(lib.ft_bottleneck_stream_pack(ctypes.byref(d), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), wstream.data_ptr(),
                                             current_stream_handle(x.t.device)), "ft_bottleneck_stream_pack")
         torch.cuda.current_stream(x.t.device).synchronize()     # plan-build time: the plan may replay on another stream
-        P = planes
-        tables = torch.cat([s1.flatten()[:P], b1.flatten()[:P], s2.flatten()[:P], b2.flatten()[:P]] +
-                           [t.flatten()[q * P:(q + 1) * P] for q in range(4) for t in (s3, b3)]).float().contiguous()
         cached = (wstream, tables)
         if hasattr(c1, "_packed"):
             c1._packed[key] = cached
@@ -1242,11 +1274,12 @@ def bottleneck_strips_supported(x: ActView, y: ActView, planes: int) -> bool:
 
 
 def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", x: ActView, y: ActView,
-                      label: str, cluster: bool = False, form: str = "auto") -> None:
+                      label: str, cluster: bool = False, form: str = "auto", fold: Optional[bool] = None) -> None:
     """conv1 + bn1 + relu -> conv2 + bn2 + relu -> conv3 + bn3 + residual(x) + relu as ONE launch (ft_bottleneck_fwd);
     the packed weights / folded BN are those the three FusedConv layers would use on channel-aligned views.
     `form` (64-plane blocks): "patch" = ft_bottleneck_fwd, "strips" = ft_bottleneck_rstat_fwd, "auto" = strips where the library's
-    cost rule takes them."""
+    cost rule takes them.  `fold` (128- / 256-plane blocks): the folded operands of ft_bottleneck_desc.folded (None = FOLD_BOTTLENECK_STREAM,
+    i.e. on unless FT_BNS_FOLD=0; the cluster form only has the table form)."""
     lib = _lib.load()
     if y.t.data_ptr() == x.t.data_ptr():
         raise FlowtrackHipError(f"{label}: the fused bottleneck cannot run in place")
@@ -1260,7 +1293,10 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
         # 128 / 256 planes: the streamed-weights kernel; its weight stream is built once per weight set by the library
         check(lib.ft_bottleneck_stream_supported(ctypes.byref(d)), "ft_bottleneck_stream_supported")
         flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
-        wstream, tables = _bottleneck_stream_operands(c1, d, x, planes, (w1, s1, b1), (w2, s2, b2), (w3, s3, b3))
+        fold = (FOLD_BOTTLENECK_STREAM if fold is None else fold) and not cluster and lib.ft_bottleneck_stream_folds(ctypes.byref(d)) == 1
+        d.folded = 1 if fold else 0
+        wstream, tables = _bottleneck_stream_operands(c1, d, x, planes, (w1, s1, b1), (w2, s2, b2), (w3, s3, b3),
+                                                      convs=(c1, c2, c3) if fold else None)
         prog.flops += flops
         prog.fused_records.append((label, len(prog.calls), flops))
         if cluster:

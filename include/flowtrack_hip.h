@@ -259,6 +259,12 @@ typedef struct ft_bottleneck_desc {
                              y = t2 [N, H/2, W/2, P]; weight stream = w1 [P][C] then w2 [P][9P]; tables = float[6][2P] of
                              which {scale1, shift1} {scale2, shift2} are read.  (Appended in round 3: zero-initialised
                              descriptors of older callers keep their meaning.) */
+  int folded;             /* ft_bottleneck_stream_fwd only (round 6; see ft_bottleneck_stream_folds).  1: the weight stream was packed
+                             from weights with the BatchNorm SCALE already folded in (fp16(w * scale[co]), one rounding from the fp32
+                             weights) and `tables` is NOT float[6][2P] but uint32 [P + P + C]: shift1, shift2, shift3 as (hi, lo) fp16
+                             pairs, hi = fp16(shift) in bits 0-15, lo = fp16(shift - hi) in bits 16-31.  The kernels add the shift and
+                             the identity residual as extra MFMA k-steps and their epilogues are fp16(relu(acc)).  0 = the scale /
+                             shift tables of round 2. */
 } ft_bottleneck_desc;
 int ft_bottleneck_supported(const ft_bottleneck_desc* d);   /* FT_OK or FT_ERR_UNSUPPORTED / FT_ERR_INVALID_ARG */
 int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,
@@ -267,18 +273,6 @@ int ft_bottleneck_fwd(const ft_bottleneck_desc* d, const void* x,
 /* algorithmic FLOPs of the three convs (2*MACs, no halo recompute) */
 double ft_bottleneck_flops(const ft_bottleneck_desc* d);
 
-/* Register-stationary strip form of the same identity block (csrc/bottleneck_rstat.hip; fp16, C = 256, P = 64, stride 1,
- * 3 <= W <= 62): one persistent 8-wave workgroup per strip of full-width rows keeps all weights in registers.  The folded
- * BatchNorms travel INSIDE the weight buffer, which the caller builds once per weight set (fp16, from the fp32 weights):
- *   [64][272]  w1[co][ci] * scale1[co], then 16 columns {hi(shift1[co]), lo(shift1[co]), 0 x 14}
- *   [64][592]  w2[co][(ky*3+kx)*64 + ci] * scale2[co], then the 16 shift columns
- *   [256][80]  w3[co][ci] * scale3[co], then the 16 shift columns          (hi = fp16(shift), lo = fp16(shift - hi))
- * (the shift is added by one extra MFMA k-step against a vector of ones, the residual by two k-steps against an identity).
- * _supported also applies the cost rule (at least eight 64-pixel steps per strip) unless FT_BNK_RSTAT=2; FT_BNK_RSTAT=0 -> unsupported. */
-int ft_bottleneck_rstat_supported(const ft_bottleneck_desc* d);
-long long ft_bottleneck_rstat_weight_bytes(void);
-int ft_bottleneck_rstat_fwd(const ft_bottleneck_desc* d, const void* x, const void* wpack, void* y, ft_stream_t stream);
-
 /* Streamed-weights form of the same fusion for the 128- and 256-plane stages (fp16, C = 4P, P = 128 or 256, stride 1,
  * head_only = 0; ResNet layer2.1+ / layer3.1+): a workgroup owns a full-width strip of output rows of one image, keeps
  * t1 / t2 in LDS and streams the block's weights once through an LDS ring (csrc/bottleneck_stream.hip).
@@ -286,27 +280,17 @@ int ft_bottleneck_rstat_fwd(const ft_bottleneck_desc* d, const void* x, const vo
  *   ft_bottleneck_stream_pack          builds it from the three convs' ft_conv_pack_geometry layouts
  *                                      (w1 [P][C], w2 [P][9P] with k = (ky*3+kx)*P + ci, w3 [C][P]); once per weight set
  *   ft_bottleneck_stream_fwd           tables = float[6][2P]: {scale1, shift1} {scale2, shift2} then {scale3, shift3} of
- *                                      output channels [qP, qP+P) for q = 0..3; y must not alias x. */
+ *                                      output channels [qP, qP+P) for q = 0..3 (d->folded = 0), or the shift pairs described at
+ *                                      ft_bottleneck_desc.folded; y must not alias x. */
 int ft_bottleneck_stream_supported(const ft_bottleneck_desc* d);
+/* 1 when ft_bottleneck_stream_fwd takes the FOLDED operands for this block (d->folded = 1; every stride-1 identity block), 0 when only
+ * the table form exists (the stride-2 head); the value of d->folded itself is ignored. */
+int ft_bottleneck_stream_folds(const ft_bottleneck_desc* d);
 long long ft_bottleneck_stream_weight_bytes(const ft_bottleneck_desc* d);
 int ft_bottleneck_stream_pack(const ft_bottleneck_desc* d, const void* w1, const void* w2, const void* w3, void* wstream,
                               ft_stream_t stream);
 int ft_bottleneck_stream_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
                              ft_stream_t stream);
-
-/* CLUSTER form of the same block for the 256-plane stage on maps of <= 192 pixels (fp16, P = 256, C = 1024, stride 1;
- * layer3.1+ of the ResNets at 256 x 192; csrc/bottleneck_cluster.hip, round 5): the work of one image is shared by four
- * workgroups that exchange t1 / t2 through `workspace` INSIDE the launch (agent-scope hand-off, bounded spins), so a CU
- * streams about half the weight bytes of the strip form and no MFMA tile is padded.  Same wstream / tables as
- * ft_bottleneck_stream_fwd.  workspace: ft_bottleneck_cluster_workspace_bytes(d) bytes, ZEROED ONCE by the caller and
- * then left alone (it holds monotonic per-cluster arrival counters across calls); one workspace must not be used by two
- * launches that may run concurrently.  The 32-bit word at ft_bottleneck_cluster_status_offset(d) becomes non-zero if a
- * hand-off ever timed out (a member was not resident in time: the output of that call is wrong). */
-int ft_bottleneck_cluster_supported(const ft_bottleneck_desc* d);
-long long ft_bottleneck_cluster_workspace_bytes(const ft_bottleneck_desc* d);
-long long ft_bottleneck_cluster_status_offset(const ft_bottleneck_desc* d);
-int ft_bottleneck_cluster_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
-                              void* workspace, ft_stream_t stream);
 
 /* ---- layout / pooling helpers -------------------------------------------- */
 /* NCHW fp32 [N,C,H,W] -> NHWC `dtype` [N,H,wpitch,cpad]: pixel x lands in column lpad + x, channels
@@ -499,6 +483,38 @@ int ft_crop_affine_fwd(const uint8_t* img, int H, int W, int C, const float* box
 int ft_crop_affine_cv2_fwd(const uint8_t* img, int H, int W, int C, const double* minv, int nb, int rh, int rw,
                            const float* mean, const float* inv_std, float pre_scale, uint8_t* out_u8, float* out,
                            ft_stream_t stream);
+
+/* ---- experimental entry points (NOT part of the drop-in boundary) -------------------------------------------
+ * Measured alternatives of the fused-block kernels that the default plans do not record (profiles/README.md has their
+ * numbers).  They are exported by the library so that the tests and tools/dev can reach them, but they are declared only
+ * when the includer defines FT_EXPERIMENTAL; signatures may change between rounds. */
+#ifdef FT_EXPERIMENTAL
+/* Register-stationary strip form of the same identity block (csrc/bottleneck_rstat.hip; fp16, C = 256, P = 64, stride 1,
+ * 3 <= W <= 62): one persistent 8-wave workgroup per strip of full-width rows keeps all weights in registers.  The folded
+ * BatchNorms travel INSIDE the weight buffer, which the caller builds once per weight set (fp16, from the fp32 weights):
+ *   [64][272]  w1[co][ci] * scale1[co], then 16 columns {hi(shift1[co]), lo(shift1[co]), 0 x 14}
+ *   [64][592]  w2[co][(ky*3+kx)*64 + ci] * scale2[co], then the 16 shift columns
+ *   [256][80]  w3[co][ci] * scale3[co], then the 16 shift columns          (hi = fp16(shift), lo = fp16(shift - hi))
+ * (the shift is added by one extra MFMA k-step against a vector of ones, the residual by two k-steps against an identity).
+ * _supported also applies the cost rule (at least eight 64-pixel steps per strip) unless FT_BNK_RSTAT=2; FT_BNK_RSTAT=0 -> unsupported. */
+int ft_bottleneck_rstat_supported(const ft_bottleneck_desc* d);
+long long ft_bottleneck_rstat_weight_bytes(void);
+int ft_bottleneck_rstat_fwd(const ft_bottleneck_desc* d, const void* x, const void* wpack, void* y, ft_stream_t stream);
+
+/* CLUSTER form of the same block for the 256-plane stage on maps of <= 192 pixels (fp16, P = 256, C = 1024, stride 1;
+ * layer3.1+ of the ResNets at 256 x 192; csrc/bottleneck_cluster.hip, round 5): the work of one image is shared by four
+ * workgroups that exchange t1 / t2 through `workspace` INSIDE the launch (agent-scope hand-off, bounded spins), so a CU
+ * streams about half the weight bytes of the strip form and no MFMA tile is padded.  Same wstream / tables as
+ * ft_bottleneck_stream_fwd.  workspace: ft_bottleneck_cluster_workspace_bytes(d) bytes, ZEROED ONCE by the caller and
+ * then left alone (it holds monotonic per-cluster arrival counters across calls); one workspace must not be used by two
+ * launches that may run concurrently.  The 32-bit word at ft_bottleneck_cluster_status_offset(d) becomes non-zero if a
+ * hand-off ever timed out (a member was not resident in time: the output of that call is wrong). */
+int ft_bottleneck_cluster_supported(const ft_bottleneck_desc* d);
+long long ft_bottleneck_cluster_workspace_bytes(const ft_bottleneck_desc* d);
+long long ft_bottleneck_cluster_status_offset(const ft_bottleneck_desc* d);
+int ft_bottleneck_cluster_fwd(const ft_bottleneck_desc* d, const void* x, const void* wstream, const float* tables, void* y,
+                              void* workspace, ft_stream_t stream);
+#endif /* FT_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from flowtrack.pytorch_amd import synth
+from flowtrack.pytorch_amd import hip_ops, synth
 from flowtrack.pytorch_amd.hip_ops import ActView, FusedConv, act_stride, bottleneck_fusable, record_bottleneck
 from util import make_program, nchw_to_view, run_program, view_to_nchw
 
@@ -95,7 +95,13 @@ def test_fused_bottleneck_matches_oracle_and_the_three_launches(hip_lib, case):
     sep = view_to_nchw(y3)
     diff = (got - sep).abs()
     assert diff.max().item() <= 1e-2 * scale, f"{name}: fused vs separate launches max abs diff {diff.max().item():.3e}"
-    assert (diff > 0).float().mean().item() < 0.05, "fused and separate launches should agree bit for bit almost everywhere"
+    if prog.calls[0][0] == "ft_bottleneck_stream_fwd" and hip_ops.FOLD_BOTTLENECK_STREAM:
+        # folded operands (round 6): the BatchNorm scale is rounded INTO the fp16 weights instead of multiplying the fp32 sum, so the
+        # two paths are one fp16 weight-rounding apart: they agree to a fraction of an fp16 step on average, not bit for bit
+        print(f"{name}: folded vs separate launches: {100 * (diff > 0).float().mean().item():.1f} % of outputs differ, mean |diff| {diff.mean().item():.2e}")
+        assert diff.mean().item() <= 4e-4 * scale, f"{name}: folded form drifts from the separate launches (mean |diff| {diff.mean().item():.3e})"
+    else:
+        assert (diff > 0).float().mean().item() < 0.05, "fused and separate launches should agree bit for bit almost everywhere"
     if P != 64:
         assert prog.calls[0][0] == "ft_bottleneck_stream_fwd", prog.calls[0][0]
 
@@ -220,7 +226,7 @@ def test_cluster_256_matches_oracle_and_the_strip_form(hip_lib, case):
     assert int(ws[soff:soff + 4].view(torch.int32).item()) == 0, "a cluster hand-off timed out"
     ys = ActView(torch.zeros((N, H, W, C), dtype=dtype, device=dev), C, 0)
     prog_s = make_program()
-    record_bottleneck(prog_s, c1, c2, c3, xv, ys, name)
+    record_bottleneck(prog_s, c1, c2, c3, xv, ys, name, fold=False)     # the table form: the very operands the cluster form reads
     assert prog_s.calls[0][0] == "ft_bottleneck_stream_fwd"
     run_program(prog_s)
     diff = (got - view_to_nchw(ys)).abs()

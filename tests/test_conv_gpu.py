@@ -122,6 +122,46 @@ def test_conv_matches_oracle(hip_lib, case, dtype, layout):
     assert torch.all(ybuf[..., :8] == 7.0) and torch.all(ybuf[..., 8 + Cout:] == 7.0), "wrote outside its channel slice"
 
 
+NONFINITE = [
+    # name, N, Cin, H, W, Cout, k, stride, pad: one shape per epilogue family that implements ReLU as max(v, 0 (*) v)
+    ("igemm_3x3_64", 2, 64, 16, 12, 64, 3, 1, 1),               # conv_igemm_dma_kernel (conv_common.h: apply_act)
+    ("direct_1x1_cin2048", 64, 2048, 8, 6, 512, 1, 1, 0),       # layer4.x.conv1 at the benchmarked batch: conv_direct_kernel
+    ("direct_1x1_cout2048", 64, 512, 8, 6, 2048, 1, 1, 0),      # layer4.x.conv3 (without its residual)
+    ("direct_3x3_512", 64, 512, 8, 6, 512, 3, 1, 1),            # layer4.x.conv2: conv3x3_direct_kernel
+]
+
+
+@pytest.mark.parametrize("case", NONFINITE, ids=[c[0] for c in NONFINITE])
+def test_relu_of_non_finite_values(hip_lib, case):
+    """ReLU of a pre-activation that is -inf / +inf / NaN: the epilogues computed max(v, k * v) with k = 0, and
+    the IEEE product -inf * 0 = NaN turned ReLU(-inf) into -inf (torch: 0), which then rode every following residual.  Now
+    `!(v <= 0) ? v : k (*) v` with the legacy multiply (0 * x = 0): ft_common.h, act_mul.  The non-finite values enter through the bias (a conv sum with an infinite input
+    would be NaN in the other channels by itself): channel 1 gets -inf, channel 2 +inf, channel 3 NaN (stays NaN, as in torch), every
+    other channel must still match the oracle."""
+    name, N, Cin, H, W, Cout, k, stride, pad = case
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 37
+    w = synth.normal(seed, name + ".w", (Cout, Cin, k, k), std=(2.0 / (Cin * k * k)) ** 0.5).half().float()
+    x = synth.normal(seed, name + ".x", (N, Cin, H, W)).half().float()
+    bias = synth.normal(seed, name + ".b", (Cout,), std=0.2)
+    bias[1], bias[2], bias[3] = float("-inf"), float("inf"), float("nan")
+    layer = FusedConv(w, dtype=dtype, device=dev, stride=stride, pad=pad, bias=bias, act="relu", label=name)
+    want = F.relu(F.conv2d(x, w, bias, stride=stride, padding=pad))
+    xv = nchw_to_view(x, dtype, dev, cstride=act_stride(Cin))
+    Ho, Wo = layer.out_hw(H, W)
+    yv = ActView(torch.full((N, Ho, Wo, act_stride(Cout)), 7.0, dtype=dtype, device=dev), Cout, 0)
+    prog = make_program()
+    layer.record(prog, xv, yv)
+    run_program(prog)
+    got = view_to_nchw(yv)
+    print(f"{name}: launched {[c[0] for c in prog.calls]}")
+    assert torch.all(got[:, 1] == 0.0), f"{name}: ReLU(-inf) must be 0, got {got[:, 1].flatten()[:4].tolist()}"
+    assert torch.all(torch.isposinf(got[:, 2])), f"{name}: ReLU(+inf) must stay +inf"
+    assert torch.all(torch.isnan(got[:, 3])), f"{name}: ReLU(NaN) must stay NaN (F.relu does the same)"
+    keep = [c for c in range(Cout) if c not in (1, 2, 3)]
+    scale = max(1.0, want[:, keep].abs().max().item())
+    assert (got[:, keep] - want[:, keep]).abs().max().item() <= 2e-2 * scale
+
+
 # ---- row-packed small-Cin stems (7x7/s2 on 3/6/12 channels): whole kernel rows as K-runs -----------------
 ROWPACK = [
     # name, N, Cin, H, W, Cout, k, stride, pad, bias, bn, act
@@ -481,9 +521,9 @@ def test_pack_input_rowpacked_layout(hip_lib, shape):
 
 @pytest.mark.parametrize("act", [None, "relu", "leaky"])
 def test_epilogue_keeps_non_finite_values(hip_lib, act):
-    """conv_common.h: apply_act on NaN / +-inf: a NaN accumulator stays NaN through every activation (torch's
-    F.relu / F.leaky_relu do the same), +inf stays +inf, -inf follows torch except ReLU(-inf), which the two-instruction form
-    max(v, 0 * v) leaves at -inf (documented in the header) instead of 0."""
+    """conv_common.h: apply_act on NaN / +-inf: a NaN accumulator stays NaN through every activation
+    (torch's F.relu / F.leaky_relu do the same), +inf stays +inf, -inf follows torch — including ReLU(-inf) = 0, which the
+    two-instruction max(v, 0 * v) of rounds 2-5 left at -inf."""
     dev = torch.device("cuda:0")
     N, C, H, W = 1, 32, 4, 8
     w = torch.eye(C).reshape(C, C, 1, 1)
@@ -503,8 +543,7 @@ def test_epilogue_keeps_non_finite_values(hip_lib, act):
     want = _reference(x, w, None, None, 1, 0, False, act, None)
     fin = torch.isfinite(want)
     if act == "relu":
-        fin[0, 3, 2, 2] = False                     # the documented exception: ReLU(-inf) = -inf here, 0 in torch
-        assert got[0, 3, 2, 2] == float("-inf") and want[0, 3, 2, 2] == 0
+        assert got[0, 3, 2, 2] == 0 and want[0, 3, 2, 2] == 0
     assert torch.equal(torch.isnan(got), torch.isnan(want))
     assert torch.allclose(got[fin], want[fin], atol=1e-6)
     assert torch.isnan(got[0, 1, 0, 0]) and torch.isnan(got[0, 0, 0, 0])          # NaN in -> NaN out, under every activation

@@ -145,3 +145,65 @@ def test_clip_sharding_world2_matches_unsharded():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results)
+
+
+def _entry_points_worker(rank, world, port, q):
+    """tools/pose/main.validate and tools/flownet/demo.run_pairs under a two-rank launch (gloo, CPU stand-in networks): every rank
+    must end up with exactly the arrays of the unsharded run — including a batch with fewer crops than ranks (an empty shard)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import numpy as np
+    from flowtrack.pytorch_amd.pose import evaluation
+    from tools.flownet import demo as flow_demo
+    from tools.pose import main as pose_main
+
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 17, 5, stride=4, padding=2)).eval()     # [B,3,64,48] -> [B,17,16,12] "heat maps"
+
+    def preds_fn(hm, center, scale, adjust):                 # host-only final_preds: torch arg-max + the reference's inverse affine
+        x, y, sc = evaluation._argmax_xy(hm.detach())
+        coords = torch.stack((x, y), dim=2).numpy().astype(np.float64)
+        return evaluation.transform_preds(coords, np.asarray(center, np.float64), np.asarray(scale, np.float64), hm.shape[2:]), sc.unsqueeze(-1).numpy()
+
+    def batches():
+        done = 0
+        for b in (5, 4, 1):                                  # 5 = ragged shards, 1 = fewer crops than ranks
+            x = torch.randn(b, 3, 64, 48, generator=torch.Generator().manual_seed(100 + done))
+            yield x, {"center": np.stack([[24.0 + i, 32.0 + 2 * i] for i in range(b)]), "scale": np.full(b, 80.0), "index": np.arange(done, done + b)}
+            done += b
+
+    with torch.no_grad():
+        ref = pose_main.validate(net, batches(), flip_test=True, device="cpu", preds_fn=preds_fn)
+        parallel.init_from_env(backend="gloo")
+        got = pose_main.validate(net, batches(), flip_test=True, rank=rank, world=world, device="cpu", preds_fn=preds_fn)
+    ok = all(np.array_equal(ref[k], got[k]) for k in ("preds", "scores", "index")) and got["preds"].shape == (10, 17, 2)
+
+    rng = np.random.default_rng(3)
+    pairs = [(rng.integers(0, 255, (64, 64, 3)).astype(np.uint8), rng.integers(0, 255, (64, 64, 3)).astype(np.uint8)) for _ in range(7)]
+
+    def flow_net(x):                                         # [B,3,2,H,W] -> [B,2,H,W]: depends on both frames of the pair
+        return torch.stack((x[:, :, 1].mean(1) - x[:, :, 0].mean(1), x[:, 0, 0] * 0.01), 1)
+
+    seen_ref, seen = {}, {}
+    tab_ref = flow_demo.run_pairs(flow_net, pairs, 0, 1, batch=3, device="cpu", on_flow=lambda k, f: seen_ref.__setitem__(k, f.copy()))
+    tab = flow_demo.run_pairs(flow_net, pairs, rank, world, batch=3, device="cpu", on_flow=lambda k, f: seen.__setitem__(k, f.copy()))
+    lo, hi = parallel.shard_range(len(pairs), rank, world)
+    ok = ok and np.array_equal(tab, tab_ref) and sorted(seen) == list(range(lo, hi)) and all(np.array_equal(seen[k], seen_ref[k]) for k in seen)
+    parallel.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_pose_validate_and_flow_batch_entry_points_shard_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry_points_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results)

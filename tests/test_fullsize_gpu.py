@@ -137,8 +137,10 @@ def test_full_size_batches_match_the_cpu_oracle(hip_lib, oracle_lib):
     f16.compute_dtype = torch.float16
     err = (f16(pairs.cuda()).cpu() - want_flow).abs()
     mag = torch.norm(want_flow, dim=1).mean().item()
-    assert err.max().item() <= 0.25 * max(mag, 1.0), "a fp16 flow pixel far off the oracle (corrupted tile?)"
-    assert torch.norm(err, dim=1).mean().item() <= 0.02 * max(mag, 1.0) + 0.05
+    print(f"FlowNet2S fp16 at 16x512x384: max abs err {err.max().item():.4f} px, EPE {torch.norm(err, dim=1).mean().item():.5f} px, mean |flow| {mag:.3f} px")
+    # measured (round 6): worst pixel 0.017 px, EPE 0.0031 px at a mean |flow| of 2.9 px; the guards leave ~3-4x room
+    assert err.max().item() <= 0.02 * max(mag, 1.0) + 0.01, "a fp16 flow pixel far off the oracle (corrupted tile?)"
+    assert torch.norm(err, dim=1).mean().item() <= 0.003 * max(mag, 1.0) + 0.002
 
 
 @pytest.mark.parametrize("name", ["FlowNet2C", "FlowNet2CS", "FlowNet2SD", "FlowNet2"])
@@ -164,8 +166,10 @@ def test_other_flow_stacks_at_512x384_match_the_cpu_oracle(hip_lib, oracle_lib, 
     m16 = m16.cuda().eval()
     m16.compute_dtype = torch.float16
     err = (m16(pairs.cuda()).cpu() - want).abs()
-    assert torch.norm(err, dim=1).mean().item() <= 0.03 * max(mag, 1.0) + 0.05, f"{name} fp16 EPE"
-    assert err.max().item() <= 0.5 * max(mag, 1.0) + 0.5, f"{name} fp16: a pixel far off the oracle (corrupted tile?)"
+    print(f"{name} fp16 at 4x512x384: max abs err {err.max().item():.4f} px, EPE {torch.norm(err, dim=1).mean().item():.5f} px, mean |flow| {mag:.3f} px")
+    # measured (round 6, mean |flow| 3.0-4.0 px): EPE 0.0017 (2C) .. 0.0069 px (FlowNet2), worst pixel 0.008 .. 0.056 px; guards ~3x the worst
+    assert torch.norm(err, dim=1).mean().item() <= 0.006 * max(mag, 1.0) + 0.003, f"{name} fp16 EPE"
+    assert err.max().item() <= 0.05 * max(mag, 1.0) + 0.02, f"{name} fp16: a pixel far off the oracle (corrupted tile?)"
 
 
 def test_r101_384x288_batch16_matches_the_cpu_oracle(hip_lib):

@@ -35,5 +35,8 @@ d = t[:, 1:7] - t[:, :6]
 print(f"P={P} B={B}: {t.shape[0]} strips; kernel span {(t[:, 6].max() - t0):.0f} ticks (100 MHz?); per-strip lifetime mean {(t[:, 6] - t[:, 0]).mean():.0f}")
 for i, nme in enumerate(names):
     print(f"  {nme:20s} mean {d[:, i].mean():8.0f}  p10 {d[:, i].quantile(0.1):8.0f}  p90 {d[:, i].quantile(0.9):8.0f}")
+if t[:, 7].max() > 0:
+    su = t[:, 7] - t[:, 0]
+    print(f"  {'start-up (x chunk 0)':20s} mean {su.mean():8.0f}  p10 {su.quantile(0.1):8.0f}  p90 {su.quantile(0.9):8.0f}   (inside phase 1)")
 starts = torch.sort(t[:, 0] - t0).values
 print("  strip start quantiles:", [int(starts[int(q * (len(starts) - 1))]) for q in (0, 0.25, 0.5, 0.75, 1.0)])

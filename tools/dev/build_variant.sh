@@ -8,4 +8,4 @@ for s in conv_igemm conv_igemm8 bottleneck bottleneck_rstat bottleneck_stream bo
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p || exit 1; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $P/build_$name/*.o -o $P/libflowtrack_hip_$name.so && echo built $P/libflowtrack_hip_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$P/csrc/exports.map $P/build_$name/*.o -o $P/libflowtrack_hip_$name.so && echo built $P/libflowtrack_hip_$name.so

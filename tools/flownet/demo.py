@@ -7,7 +7,13 @@ loads `checkpoint['state_dict']`, packs the pair as [1,3,2,H,W] RGB 0..255, runs
 `<save>/output.flo` + `<save>/flow.png`.  Differences: images are read with PIL (scipy.misc.imread is gone);
 frames whose size is not a multiple of 64 are edge-replicated bottom/right (pack_pair) and the flow cropped back;
 `--random_weights` allows a run without a checkpoint (the reference quits, demo.py:57-59);
-`--number_gpus > 1` is accepted but the single pair runs on one GPU (multi-GPU = one process per GPU, bench.py).
+`--number_gpus > 1` is accepted but the single pair runs on one GPU.  Batches of pairs shard one process per GPU:
+
+    torchrun --nproc-per-node 8 tools/flownet/demo.py --model FlowNet2S --resume CKPT --pair_list pairs.txt -s results
+
+(`--pair_list`: one `img0 img1` per line, all of one size; every rank runs its contiguous slice of the list (run_pairs), writes
+`<save>/<k>.flo` for the pairs it owns and the per-pair flow statistics are all-gathered so that rank 0 prints the whole table —
+the role of the reference's nn.DataParallel scatter / gather in tools/flownet/main.py:133-134,186,197.)
 """
 from __future__ import absolute_import, division, print_function
 
@@ -37,6 +43,9 @@ def build_parser():
     parser.add_argument('--fp16', action='store_true', help='Run model in pseudo-fp16 mode (fp16 storage fp32 math).')
     parser.add_argument('--rgb_max', type=float, default=255.)
     parser.add_argument('--random_weights', action='store_true', help='run without a checkpoint (results are meaningless)')
+    parser.add_argument('--pair_list', default='', type=str, help='text file, one "img0 img1" per line: batch mode, sharded over the '
+                        'ranks of a torchrun launch')
+    parser.add_argument('--batch_size', '-b', type=int, default=4, help='pairs per forward in batch mode')
     tools.add_arguments_for_module(parser, models, argument_for_class='model', default='FlowNet2S', choices=MODEL_CHOICES)
     return parser
 
@@ -64,6 +73,32 @@ def run_pair(model, im1, im2):
     return flow[0, :, :H, :W].numpy().transpose(1, 2, 0)
 
 
+def run_pairs(model, pairs, rank=0, world=1, batch=4, device='cuda', on_flow=None):
+    """pairs: list of (im1, im2) HxWx3 arrays of one size.  Rank `rank` of `world` runs its contiguous slice (parallel.shard_range)
+    in batches of `batch`, hands every flow field to `on_flow(global_index, flow HxWx2)` and returns the [len(pairs), 4] table
+    (index, mean u, mean v, max |flow|) of ALL pairs, all-gathered so that every rank holds it (one collective)."""
+    from flowtrack.pytorch_amd import parallel
+    n = len(pairs)
+    lo, hi = parallel.shard_range(n, rank, world)
+    rows = []
+    for b0 in range(lo, hi, batch):
+        chunk = pairs[b0:min(b0 + batch, hi)]
+        H, W = chunk[0][0].shape[:2]
+        x = torch.cat([pack_pair(a, b) for a, b in chunk], 0).to(device)
+        with torch.no_grad():
+            flow = model(x).float().cpu()
+        for k in range(len(chunk)):
+            f = flow[k, :, :H, :W].numpy().transpose(1, 2, 0)
+            if on_flow is not None:
+                on_flow(b0 + k, f)
+            rows.append([float(b0 + k), float(f[..., 0].mean()), float(f[..., 1].mean()), float(np.sqrt((f ** 2).sum(-1)).max())])
+    local = torch.tensor(rows, dtype=torch.float64).reshape(-1, 4)
+    if world > 1:
+        on_gpu = torch.device(device).type == 'cuda'
+        local = parallel.all_gather_rows(local.to(device) if on_gpu else local, n).cpu()
+    return local.numpy()
+
+
 def main(argv=None):
     parser = build_parser()
     args = parser.parse_args(argv)
@@ -89,10 +124,27 @@ def main(argv=None):
         # runs on GPU 0 there as well.  Here multi-GPU is one process per GPU (torchrun + bench.py / parallel.py).
         print('[demo] --number_gpus %d: one frame pair cannot be sharded, it runs on GPU 0 (as under the reference\'s '
               'DataParallel); batches shard one process per GPU via torchrun, see bench.py' % args.number_gpus, file=sys.stderr)
+    from flowtrack.pytorch_amd import parallel
+    rank, local_rank, world = parallel.init_from_env()
+    if world > 1:
+        torch.cuda.set_device(local_rank)
     model = model.cuda()
     if args.fp16:
         model = model.half()
     model.eval()
+    if args.pair_list:
+        with open(args.pair_list) as f:
+            names = [ln.split() for ln in f if ln.strip()]
+        pairs = [(load_image(a), load_image(b)) for a, b in (nm[:2] for nm in names)]
+        table = run_pairs(model, pairs, rank, world, args.batch_size,
+                          on_flow=lambda k, fl: tools.write_flow(fl, os.path.join(args.save, '%06d.flo' % k)))
+        if rank == 0:
+            for k, mu, mv, mx in table:
+                print('%06d  mean flow (%.3f, %.3f) px  max |flow| %.3f px' % (int(k), mu, mv, mx))
+            print('wrote %d flow fields to %s (%d rank%s)' % (len(pairs), args.save, world, 's' if world > 1 else ''))
+        return 0
+    if world > 1 and rank != 0:
+        return 0            # the single-pair demo runs on rank 0 only
     flow = run_pair(model, load_image(args.input1), load_image(args.input2))
     tools.write_flow(flow, os.path.join(args.save, 'output.flo'))
     from PIL import Image

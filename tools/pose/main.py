@@ -71,25 +71,53 @@ def synthetic_batches(n, batch, res, seed):
         done += b
 
 
-def validate(model, batches, flip_test=False, adjust_coords=True, flip_pairs=COCO_FLIP_PAIRS):
-    """Inference loop of main.py:254-372 (eval mode, forward, flip test, final_preds). Returns dict of arrays."""
-    model.eval()
+def validate(model, batches, flip_test=False, adjust_coords=True, flip_pairs=COCO_FLIP_PAIRS, rank=0, world=1, device='cuda',
+             preds_fn=None):
+    """Inference loop of main.py:254-372 (eval mode, forward, flip test, final_preds). Returns dict of arrays.
+
+    world > 1 (one process per GPU under torchrun, parallel.init_from_env): every rank walks the SAME batches, runs the net on its
+    contiguous slice of each batch (parallel.shard_range) and the key points / scores of the slices are all-gathered
+    (parallel.all_gather_rows: one collective per batch), so every rank returns the full arrays in dataset order — what the
+    reference gets from nn.DataParallel's scatter / gather (tools/flownet/main.py:133-134,186).  `preds_fn(heatmaps, center,
+    scale, adjust_coords)` defaults to the device path (evaluation.final_preds); `device` / `preds_fn` exist for the gloo test."""
+    from flowtrack.pytorch_amd import parallel
+    if hasattr(model, 'eval'):
+        model.eval()
+    preds_fn = preds_fn or evaluation.final_preds
+    on_gpu = torch.device(device).type == 'cuda'
     all_preds, all_scores, all_idx = [], [], []
     n, t0 = 0, time.time()
     for inputs, meta in batches:
-        inputs = inputs.cuda(non_blocking=True)
-        output = model(inputs)
-        if flip_test:
-            flipped = _flip_back(model(torch.flip(inputs, dims=[3])), flip_pairs)
-            output = (output + flipped) * 0.5
-        preds, scores = evaluation.final_preds(output, meta['center'], meta['scale'], adjust_coords)
-        all_preds.append(preds)
-        all_scores.append(scores)
-        all_idx.append(meta['index'])
-        n += inputs.shape[0]
-    torch.cuda.synchronize()
+        B = inputs.shape[0]
+        lo, hi = parallel.shard_range(B, rank, world)
+        center, scale = np.asarray(meta['center'])[lo:hi], np.asarray(meta['scale'])[lo:hi]
+        if hi > lo:
+            x = inputs[lo:hi].to(device, non_blocking=True)
+            output = model(x)
+            if flip_test:
+                flipped = _flip_back(model(torch.flip(x, dims=[3])), flip_pairs)
+                output = (output + flipped) * 0.5
+            preds, scores = preds_fn(output, center, scale, adjust_coords)
+            rows = torch.from_numpy(np.concatenate((np.asarray(preds, np.float64), np.asarray(scores, np.float64)), axis=2))
+        else:
+            rows = None
+        if world > 1:
+            if B < world:           # more ranks than crops in this batch: the empty shards learn the joint count, then join the collective
+                k = torch.tensor([0 if rows is None else rows.shape[1]], dtype=torch.int64, device=device if on_gpu else None)
+                torch.distributed.all_reduce(k, op=torch.distributed.ReduceOp.MAX)
+                if rows is None:
+                    rows = torch.zeros((0, int(k.item()), 3), dtype=torch.float64)
+            rows = parallel.all_gather_rows(rows.to(device) if on_gpu else rows, B).cpu()
+        all_preds.append(rows[..., :2].numpy())
+        all_scores.append(rows[..., 2:].numpy().astype(np.float32))
+        all_idx.append(np.asarray(meta['index']))
+        n += B
+    if on_gpu:
+        torch.cuda.synchronize()
     dt = time.time() - t0
-    print('validate: {} crops in {:.3f} s ({:.1f} crops/s incl. host post-processing)'.format(n, dt, n / max(dt, 1e-9)))
+    if rank == 0:
+        print('validate: {} crops in {:.3f} s ({:.1f} crops/s incl. host post-processing{})'.format(
+            n, dt, n / max(dt, 1e-9), ', sharded over {} ranks'.format(world) if world > 1 else ''))
     return {'preds': np.concatenate(all_preds), 'scores': np.concatenate(all_scores), 'index': np.concatenate(all_idx),
             'seconds': dt}
 
@@ -105,6 +133,11 @@ def main(**kwargs):
     opt.model_name = '{}_{}'.format(opt.model, opt.backbone)
     if not opt.use_gpu:
         raise ValueError('the HIP path needs use_gpu=True (CPU reference results: oracle/)')
+    # one process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): the batches are sharded in validate()
+    from flowtrack.pytorch_amd import parallel
+    rank, local_rank, world = parallel.init_from_env()
+    if world > 1:
+        torch.cuda.set_device(local_rank)
     model = model.cuda()
     if opt.resume:
         model_path = os.path.join(opt.work_dir, opt.resume)
@@ -122,7 +155,7 @@ def main(**kwargs):
         raise ValueError("run_type '{}': training is out of scope of the HIP path (use 'valid')".format(opt.run_type))
     batches = kwargs.get('batches') or synthetic_batches(opt.num_samples, opt.test_batch_size, opt.input_res, opt.seed)
     out = validate(model, batches, flip_test=opt.flip_test, adjust_coords=opt.adjust_coords,
-                   flip_pairs=get_flip_pairs(opt.dataset) if opt.flip_test else ())
+                   flip_pairs=get_flip_pairs(opt.dataset) if opt.flip_test else (), rank=rank, world=world)
     out['model'] = model
     return out
 
