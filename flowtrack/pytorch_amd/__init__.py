@@ -13,7 +13,22 @@ import os as _os
 # branches, and the kernarg fetch is part of every launch's latency.  Measured on FlowNet2S (16 x 512x384, two interleaved runs):
 # 19.28 / 19.30 -> 20.02 / 20.01 k pairs/s (+3.7 %); the ResNet-50 pose step (29 larger launches) does not move.  An explicit
 # HIP_FORCE_DEV_KERNARG in the environment wins.
+# The switch only takes effect if no HIP call has happened yet in this process: what was found at import time is kept in
+# KERNARG_STATE, logged at debug level, and bench.py prints it in its JSON line so that results stay comparable
+# (import this package before the first torch.cuda call).
+import logging as _logging
+import sys as _sys
+
+_preset = _os.environ.get("HIP_FORCE_DEV_KERNARG")
+_torch = _sys.modules.get("torch")
+_hip_up = bool(_torch is not None and _torch.cuda.is_initialized())
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+#: value = what the HIP runtime will read / has read; source = who set it; effective = False when the runtime was already initialised
+#: before this package could set the variable (the setting is then ignored by this process)
+KERNARG_STATE = {"value": _os.environ["HIP_FORCE_DEV_KERNARG"], "source": "environment" if _preset is not None else "package default",
+                 "effective": not (_hip_up and _preset is None)}
+_logging.getLogger(__name__).debug("HIP_FORCE_DEV_KERNARG=%s (%s)%s", KERNARG_STATE["value"], KERNARG_STATE["source"],
+                                   "" if KERNARG_STATE["effective"] else " — HIP was initialised before the import: NOT applied")
 
 from ._lib import FlowtrackHipError, LIB_PATH  # noqa: E402,F401
 

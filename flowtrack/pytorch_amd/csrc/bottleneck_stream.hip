@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   constexpr bool STAGED = P == 128 || NOUT * ROWB <= WSTEP;
   static_assert(XROWS * 128 <= G::XSTRIDE, "x chunk buffer");
   static_assert(NOUT * ROWB <= 49152, "T2 fits below the staging tile / inside the T1 region");
-  static_assert(2 * (LX + LW) <= 63, "vmcnt immediate");
+  static_assert(2 * (LX + LW) + 6 + 12 <= 63, "vmcnt immediate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   using c0 = std::integral_constant<int, 0>;
@@ -165,14 +165,16 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   [[maybe_unused]] unsigned shp[6][2];
   [[maybe_unused]] uint4_t permA[2];
   [[maybe_unused]] const uint4_t onesB = uint4_t{0x3C003C00u, 0u, 0u, 0u};
-  if constexpr (FOLD) {
-    const int sg = bns_sigma(l31);
-    const unsigned so = lhi == 0 ? 4u * (unsigned)sg : kOOB;
+  auto load_shp = [&]() {
+    const unsigned so = lhi == 0 ? 4u * (unsigned)bns_sigma(l31) : kOOB;
 #pragma unroll
     for (int e = 0; e < 6; ++e)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         shp[e][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, so, 4 * (e * P + (2 * wcol + i) * 32), 0);
+  };
+  if constexpr (FOLD) {
+    const int sg = bns_sigma(l31);
     const bool on = lhi == (sg >> 4);
     const int ph = (sg >> 3) & 1, pe = sg & 7;
 #pragma unroll
@@ -182,7 +184,6 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
       for (int k = 0; k < 4; ++k) w[k] = (on && ph == hh && (pe >> 1) == k) ? (0x3C00u << (16 * (pe & 1))) : 0u;
       permA[hh] = uint4_t{w[0], w[1], w[2], w[3]};
     }
-    asm volatile("" ::: "memory");     // older than every hand-counted load below
   }
   [[maybe_unused]] auto add_shift = [&](int e, auto& A, auto mtc) {      // A[i][j] += shift of epilogue e (one MFMA per tile)
     constexpr int MT = decltype(mtc)::value;
@@ -195,22 +196,29 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
     }
   };
 
-#if FT_BNS_L2_TOUCH
   // the first round of workgroups on an XCD pulls the block's weight stream into that XCD's L2, each its own 1/n-th, one
-  // dword per 128-byte line (see the direct kernel); the scratch corner sits between the zero row and the weight ring
-  if (blockIdx.x < 256 && !(p.dbg & (512 | 1024))) {
+  // dword per 128-byte line (see the direct kernel); the scratch corner sits between the zero row and the weight ring.
+  // EXACTLY kTouch loads per thread (lines past the share: out of range, no traffic): the touch is issued BEHIND the first x
+  // chunk (round 6: it used to sit in front of it in every wave's in-order load queue) and the first hand-counted wait counts it
+  constexpr int kTouch = FT_BNS_L2_TOUCH ? 6 : 0;
+  auto issue_touch = [&]() {
+#if FT_BNS_L2_TOUCH
     constexpr int SCR = P == 256 ? 64000 : 102400;
     static_assert(SCR >= G::ZROW + ROWB && SCR + 1024 <= G::WBASE, "scratch of the L2 touch loads");
+    const bool on = blockIdx.x < 256 && !(p.dbg & (512 | 1024));
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
     const int first = p.total < 256 ? p.total : 256;
     const int nloc = (first - xcd + 7) >> 3;
     const unsigned lines = (p.ws_bytes + 127u) >> 7;
     const unsigned per = (lines + nloc - 1) / nloc;
     const unsigned lo = loc * per, hi = lo + per < lines ? lo + per : lines;
-    for (unsigned l = lo + tid; l < hi; l += 256)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + SCR + wave * 256), 4, l << 7, 0, 0, 0);
-  }
+#pragma unroll
+    for (int k = 0; k < kTouch; ++k) {
+      const unsigned l = lo + tid + 256u * k;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + SCR + wave * 256), 4, (on && l < hi) ? l << 7 : kOOB, 0, 0, 0);
+    }
 #endif
+  };
   // ---- loaders -------------------------------------------------------------------------------------------------------
   // x chunk: row = halo pixel, 128 bytes (64 channels); a 1-KiB wave load covers 8 rows, lane -> (row = lane / 8,
   // 16-byte position lane % 8), the XOR swizzle (position ^= row & 7) is applied to the SOURCE position
@@ -253,9 +261,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BNS_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
   BNS_TS(0);
-  // prologue: table 0, chunks 0..2 (x + W1 slice each), the zero row
-  issue_tab(0);
+  // prologue: chunk 0 (x + W1 slice) leads every wave's load queue, then the L2 touch and table 0 / the shift pairs, chunks 1 and 2,
+  // the zero row
   issue_x(0, 0); issue_w(0, 0);
+  issue_touch();
+  if constexpr (FOLD) load_shp();
+  else issue_tab(0);
+  asm volatile("" ::: "memory");
   issue_x(1, 1); issue_w(1, 1);
   issue_x(2, 2); issue_w(2, 2);
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + G::ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
@@ -300,8 +312,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
           acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[S][i]), __builtin_bit_cast(half8_t, fx[S][j]),
                                                               acc1[i][j], 0, 0, 0);
     };
-    // chunk 0 has landed (this wave's share) while chunks 1 and 2 fly; after the barrier everyone's share has
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (LX + LW)) : "memory");
+    // chunk 0 has landed (this wave's share) while the touch, the table / shift loads and chunks 1 and 2 fly; after the barrier everyone's share has
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (LX + LW) + kTouch + (FOLD ? 12 : G::LT)) : "memory");
     BNS_BARRIER();
     ld1(c0{}, 0, 0);
     bns_unroll<NC1>([&](auto cc) {
@@ -801,24 +813,31 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BNSD_TS(i) do { if (p.dbg & 32) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
   BNSD_TS(0);
-#if FT_BNS_L2_TOUCH
   // Inside a network the block's weights are not in this XCD's L2 when the kernel starts, and every workgroup of the XCD
   // asks for the same lines at the same moment: the stream then costs 17 us of a 46-us block (FT_BNS_DBG=64 in situ).  The
   // first round of workgroups on an XCD therefore TOUCHES the whole stream once, each its own 1/n-th (one dword per
   // 128-byte line, results discarded): the lines are on their way into the L2 before the lock-step demand loads reach them.
-  if (blockIdx.x < 256 && !(p.dbg & 512)) {
+  // (as LDS-DMA into a scratch corner: no destination register whose reuse the compiler would have to guard.)  Round 6: EXACTLY
+  // kTouch loads per thread (lines past the share: out of range, no traffic), issued BEHIND x chunk 0 and the weights of step 0 —
+  // the touch used to lead every wave's in-order load queue, so the first chunk waited for 100 KB of line fetches per CU (start-up
+  // 5.4 k cycles of a 71 k-cycle workgroup, tools/dev/bns_phases.py) — and counted by the first hand-counted wait.
+  constexpr int kTouch = FT_BNS_L2_TOUCH ? 6 : 0;
+  auto issue_touch = [&]() {
+#if FT_BNS_L2_TOUCH
+    const bool on = blockIdx.x < 256 && !(p.dbg & 512);
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
     const int first = p.total < 256 ? p.total : 256;
     const int nloc = (first - xcd + 7) >> 3;                       // workgroups of the first round on this XCD
     const unsigned lines = (p.ws_bytes + 127u) >> 7;
     const unsigned per = (lines + nloc - 1) / nloc;
     const unsigned lo = loc * per, hi = lo + per < lines ? lo + per : lines;
-    // (as LDS-DMA into a scratch corner: no destination register whose reuse the compiler would have to guard; issued
-    // before the prologue's loads, so the hand-counted vmcnt waits below still see the order they assume)
-    for (unsigned l = lo + tid; l < hi; l += NT)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + 77824 + wave * 256), 4, l << 7, 0, 0, 0);
-  }
+#pragma unroll
+    for (int k = 0; k < kTouch; ++k) {
+      const unsigned l = lo + tid + (unsigned)(NT * k);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(smem + 77824 + wave * 256), 4, (on && l < hi) ? l << 7 : kOOB, 0, 0, 0);
+    }
 #endif
+  };
   // prologue: all six tables (12 KiB, 3 x 256-byte pieces per wave ... 48 pieces), x chunks 0..2, weights of steps 0 and 1, zero row
   // folded form: no tables in LDS; the shift pair of MFMA row l31 of every (epilogue, channel tile) of this wave sits in a register
   // (lanes 32..63 hold k = 8..15 of the shift slice: zeros, fetched out of range), and the two residual slices' 0/1 matrix is built here:
@@ -829,12 +848,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   [[maybe_unused]] const uint4_t onesB = uint4_t{0x3C003C00u, 0u, 0u, 0u};
   if constexpr (FOLD) {
     const int sg = bns_sigma(l31);
-    const unsigned so = lhi == 0 ? 4u * (unsigned)sg : kOOB;
-#pragma unroll
-    for (int e = 0; e < 6; ++e)
-#pragma unroll
-      for (int i = 0; i < CTW; ++i)
-        shp[e][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, so, 4 * (e * P + (CTW * wcol + i) * 32), 0);
     const bool on = lhi == (sg >> 4);
     const int ph = (sg >> 3) & 1, pe = sg & 7;
 #pragma unroll
@@ -844,12 +857,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
       for (int k = 0; k < 4; ++k) w[k] = (on && ph == hh && (pe >> 1) == k) ? (0x3C00u << (16 * (pe & 1))) : 0u;
       permA[hh] = uint4_t{w[0], w[1], w[2], w[3]};
     }
-    asm volatile("" ::: "memory");     // older than every hand-counted load below
-  } else {
-#pragma unroll
-    for (int t = 0; t < 48 / NW; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * NW + wave) * 256), 4, (unsigned)lane * 4u, (t * NW + wave) * 256, 0, 0);
   }
+  constexpr int kTabLoads = FOLD ? 6 * CTW : 48 / NW;
+  auto load_tables = [&]() {
+    if constexpr (FOLD) {
+      const unsigned so = lhi == 0 ? 4u * (unsigned)bns_sigma(l31) : kOOB;
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+#pragma unroll
+        for (int i = 0; i < CTW; ++i)
+          shp[e][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_t, so, 4 * (e * P + (CTW * wcol + i) * 32), 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 48 / NW; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_ptr)(smem + TABS + (t * NW + wave) * 256), 4, (unsigned)lane * 4u, (t * NW + wave) * 256, 0, 0);
+    }
+  };
   [[maybe_unused]] auto add_shift = [&](int e, auto& A, auto mtc) {      // A[i][j] += shift of epilogue e (one MFMA per tile)
     constexpr int MT = decltype(mtc)::value;
 #pragma unroll
@@ -860,10 +883,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         A[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, sa), __builtin_bit_cast(half8_t, onesB), A[i][j], 0, 0, 0);
     }
   };
+  // order of every wave's (in-order) load queue: x chunk 0, the weights of step 0, the L2 touch, the tables / shift pairs, x chunks 1
+  // and 2, the weights of steps 1 .. D-1
   issue_x(0, 0);
+  load_a(std::integral_constant<int, 0>{}, 0);
+  issue_touch();
+  load_tables();
+  asm volatile("" ::: "memory");
   issue_x(1, 1);
   issue_x(2, 2);
-  bns_unroll<D>([&](auto sc) { load_a(sc, decltype(sc)::value); });
+  bns_unroll<D - 1>([&](auto sc) { load_a(std::integral_constant<int, decltype(sc)::value + 1>{}, decltype(sc)::value + 1); });
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
 
   uint4_t res[4][CTW][MT2][2];
@@ -919,7 +948,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
                                                               __builtin_bit_cast(half8_t, fx[S][j]), acc1[i][j], 0, 0, 0);
     };
     // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight steps (8 loads each) may fly
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 4 * CTW * D) : "memory");
+    static_assert(2 * LX + 4 * CTW * D + kTouch + kTabLoads <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 4 * CTW * D + kTouch + kTabLoads) : "memory");
     BNS_BARRIER();
     BNSD_TS(7);             // start-up: x chunk 0 of every wave has landed
     ldx(c0{}, 0, 0);

@@ -125,6 +125,7 @@ class HipModule(nn.Module):
                                           # another order: the first call must be bit-identical to the replays)
                 else:
                     prog.resolve_choices()    # no benchmark: the recorder's first option of every alternative
+                hip_ops.check_cluster_status(prog)    # (only plans recorded with FT_CLUSTER_KERNELS=1 hold such launches)
                 if self.use_graph:
                     prog.stream.synchronize()
                     prog.capture()

@@ -1238,6 +1238,20 @@ def _bottleneck_stream_operands(c1: "FusedConv", d, x: ActView, planes: int, p1,
     return cached
 
 
+def check_cluster_status(prog: Program) -> None:
+    """Raise if a cluster-form launch recorded in `prog` ever reported a timed-out hand-off (ft_bottleneck_cluster_fwd sets only the
+    status word of its workspace).  Synchronises the program's stream; no-op for plans without a cluster launch."""
+    words = prog.__dict__.get("_cluster_status")
+    if not words:
+        return
+    prog.stream.synchronize()
+    for shape, (ws, soff) in words.items():
+        code = int(ws[soff:soff + 4].view(torch.int32).item())
+        if code:
+            raise FlowtrackHipError(f"ft_bottleneck_cluster_fwd: a hand-off between the workgroups of a cluster timed out (status {code}, map "
+                                    f"{shape}): the block's output is wrong; run without FT_CLUSTER_KERNELS=1 (the strip form)")
+
+
 def _bottleneck_rstat_weights(c1: "FusedConv", c2: "FusedConv", c3: "FusedConv", device) -> torch.Tensor:
     """Weight buffer of ft_bottleneck_rstat_fwd (layout: include/flowtrack_hip.h), built once per weight set from the fp32 weights:
     each conv's BatchNorm scale folded into its fp16 weights (ONE rounding, like the plain fp16 weights), the shift as a
@@ -1311,6 +1325,9 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
                 ws = pool[(x.N, x.H, x.W)] = torch.zeros(nbytes, dtype=torch.uint8, device=x.t.device)
             prog.add("ft_bottleneck_cluster_fwd", ctypes.byref(d), x.t.data_ptr(), wstream.data_ptr(), tables.data_ptr(), y.t.data_ptr(),
                      ws.data_ptr(), keep=(d, x.t, y.t, wstream, tables, ws))
+            # the 32-bit status word of that workspace: non-zero once a hand-off of the cluster form timed out (its output is then
+            # wrong); HipModule._run_plan reads the recorded words after the first run / the choice benchmark (check_cluster_status)
+            prog.__dict__.setdefault("_cluster_status", {})[(x.N, x.H, x.W)] = (ws, int(lib.ft_bottleneck_cluster_status_offset(ctypes.byref(d))))
             return
         prog.add("ft_bottleneck_stream_fwd", ctypes.byref(d), x.t.data_ptr(), wstream.data_ptr(), tables.data_ptr(), y.t.data_ptr(),
                  keep=(d, x.t, y.t, wstream, tables))

@@ -487,6 +487,32 @@ class DeconvResnet(HipModule):
             ent = st[key] = {"slots": slots, "next": 0}
         return ent
 
+    def release_exact_state(self) -> None:
+        """Destroy the events and drop the pinned headers / staging buffers of the asynchronous exact-arg-max paths (exact_submit
+        slots and the per-plan state of exact_submit_plan).  Called when the plans are invalidated (weights, dtype or device changed)
+        and by close(); a step that is still in flight is abandoned (its handle must not be finished afterwards)."""
+        from .. import _lib
+        lib = _lib.load() if (self.__dict__.get("_exact_state") or any(getattr(pl, "exact", None) for pl in self.__dict__.get("_plans", {}).values())) else None
+        for ent in self.__dict__.get("_exact_state", {}).values():
+            for sl in ent["slots"]:
+                if sl.get("event") is not None:
+                    lib.ft_event_destroy(sl["event"])
+                    sl["event"] = None
+        self.__dict__["_exact_state"] = {}
+        for pl in self.__dict__.get("_plans", {}).values():
+            ex = getattr(pl, "exact", None)
+            if ex and ex.get("event") is not None:
+                lib.ft_event_destroy(ex["event"])
+                ex["event"], ex["busy"] = None, False
+
+    def _invalidate(self):
+        self.release_exact_state()
+        super()._invalidate()
+
+    def close(self) -> None:
+        """Release what the module holds outside torch's allocator (events of the exact-arg-max paths) and its captured plans."""
+        self._invalidate()
+
     @torch.no_grad()
     def exact_submit(self, x: torch.Tensor) -> "_ExactHandle":
         """First half of the exact-arg-max step (see above): everything is queued on the current stream, nothing is waited for."""
@@ -557,12 +583,14 @@ class DeconvResnet(HipModule):
         ex = plan.exact
         if not ex["busy"]:
             raise FlowtrackHipError("exact_finish_plan: nothing submitted")
-        check(_lib.load().ft_event_synchronize(ex["event"]), "ft_event_synchronize")
-        ex["busy"] = False
-        n = int(ex["header_host"][0])
-        if n:
-            B, _, H, W = plan.x_static.shape
-            self._rerun_flagged(ex["header_host"], ex["stage"], plan.kp_rows, n, B, H, W)
+        try:
+            check(_lib.load().ft_event_synchronize(ex["event"]), "ft_event_synchronize")
+            n = int(ex["header_host"][0])
+            if n:
+                B, _, H, W = plan.x_static.shape
+                self._rerun_flagged(ex["header_host"], ex["stage"], plan.kp_rows, n, B, H, W)
+        finally:
+            ex["busy"] = False
         return plan.kp_rows, n
 
     def _rerun_flagged(self, hdr, stage, rows, n, B, H, W):
@@ -603,9 +631,11 @@ class DeconvResnet(HipModule):
         hdr = sl["header_host"]
         n = int(hdr[0])
         h.done = True
-        if n:
-            self._rerun_flagged(hdr, sl["stage"], h.rows, n, h.B, h.H, h.W)
-        sl["busy"] = False
+        try:
+            if n:
+                self._rerun_flagged(hdr, sl["stage"], h.rows, n, h.B, h.H, h.W)
+        finally:
+            sl["busy"] = False       # an exception inside the fp32 re-run must not pin the slot
         return h.rows, n
 
     @torch.no_grad()

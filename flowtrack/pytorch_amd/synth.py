@@ -81,6 +81,21 @@ def flow_field(seed: int, B: int, H: int, W: int, magnitude: float = 6.0) -> tor
     return normal(seed, "flow_field", (B, 2, H, W), std=magnitude)
 
 
+def peaked_heatmaps(seed: int, N: int, K: int = 17, h: int = 64, w: int = 48, sigma: float = 2.0, noise: float = 1e-3) -> torch.Tensor:
+    """[N,K,h,w] heat maps shaped like a TRAINED pose net's output: one Gaussian bump per map with the training target's sigma
+    (lib/pose/utils/heatmap.py:19-60: exp(-d^2 / (2 sigma^2)), sigma = 2 map pixels, tools/pose/config.py:85), amplitude
+    0.7 .. 1.0, its centre at a uniformly random SUB-PIXEL position (a joint does not sit on the 4-pixel grid of the map), plus
+    N(0, noise^2) of background.  The top-1 / top-2 margin of such a map is ~ amplitude * (1 - 2 |offset|) / (2 sigma)^2 per axis:
+    near-ties between the two pixels that straddle the centre are a property of the maps, not of the arithmetic."""
+    cy = 4.0 + uniform01(seed, "peak.cy", (N, K)) * (h - 8.0)
+    cx = 4.0 + uniform01(seed, "peak.cx", (N, K)) * (w - 8.0)
+    amp = 0.7 + 0.3 * uniform01(seed, "peak.amp", (N, K))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    d2 = (yy[None, None] - cy[..., None, None]) ** 2 + (xx[None, None] - cx[..., None, None]) ** 2
+    hm = amp[..., None, None] * np.exp(-d2 / (2.0 * sigma * sigma))
+    return torch.from_numpy(hm.astype(np.float32)) + noise * normal(seed, "peak.noise", (N, K, h, w))
+
+
 # ---- weights ---------------------------------------------------------------------------------------
 def _fan_in(name: str, shape: Tuple[int, ...], transposed: bool) -> int:
     if transposed:  # [Cin, Cout, 4, 4]; every output pixel sees 2x2 of the 4x4 taps
