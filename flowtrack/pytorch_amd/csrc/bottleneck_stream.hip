@@ -65,6 +65,11 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 #ifndef FT_BNS_STG
 #define FT_BNS_STG 1    // dev A/B: 0 = phase 3 of the direct kernel stores straight from the accumulator layout (no LDS staging tile)
 #endif
+#ifndef FT_BNS_WSTG
+#define FT_BNS_WSTG 1   // round 6: phase 3 of the direct kernel (two channel tiles per wave) transposes a quarter's tile through a WAVE-PRIVATE
+                        // piece of the staging tile: the wave's 64 channels of a pixel are one aligned 128-byte run of y, so it writes whole
+                        // lines without meeting the other waves — no workgroup barrier per quarter (the LDS queue of a wave is in order)
+#endif
 #ifndef FT_BNS_DIRECT_AUX
 #define FT_BNS_DIRECT_AUX 0   // cache policy of those stores (plain: the L2 merges the 16-byte pieces of a line)
 #endif
@@ -1231,15 +1236,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
 
   // ---- phase 3: four quarters of P output channels; the tile of a quarter leaves through one of two LDS staging tiles ----
   {
-    constexpr int CPR = ROWB / 16, NSTG = NOUT * CPR / NT;
+    // WSTG: the wave's own [NOUT pixels][128 bytes = its 64 channels of the quarter] tile, 16-byte chunk c of pixel m at chunk
+    // c ^ (m & 7): the eight lanes of a ds_write_b128 group (eight pixels, one chunk) and the sixteen of a ds_read_b128 group
+    // (two pixels x eight chunks ...) cover distinct bank groups.  Read-out: lane -> pixel lane / 8 + 8 k, chunk lane % 8.
+    constexpr bool WSTG = FT_BNS_WSTG && FT_BNS_STG && CTW == 2;
+    constexpr int CPR = ROWB / 16, NSTG = WSTG ? NOUT / 8 : NOUT * CPR / NT;
     unsigned s_voff[NSTG];
     int s_off[NSTG];
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
-      const int idx = tid + NT * k, m = idx / CPR, ch = idx % CPR;
-      const int r = m / TWc, c = m - r * TWc;
-      s_voff[k] = (m < npix_out && c < cols_out) ? (unsigned)((((n * p.H + y0 + r) * W + x0 + c) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
-      s_off[k] = m * ROWB + ((ch ^ (m & 15)) << 4);
+      if constexpr (WSTG) {
+        const int m = (lane >> 3) + 8 * k, ch = lane & 7;
+        const int r = m / TWc, c = m - r * TWc;
+        s_voff[k] = (m < npix_out && c < cols_out)
+                        ? (unsigned)((((n * p.H + y0 + r) * W + x0 + c) * p.y_cstride + p.y_coff + wcol * 64 + ch * 8) * 2) : kOOB;
+        s_off[k] = wave * (NOUT * 128) + m * 128 + ((ch ^ (m & 7)) << 4);
+      } else {
+        const int idx = tid + NT * k, m = idx / CPR, ch = idx % CPR;
+        const int r = m / TWc, c = m - r * TWc;
+        s_voff[k] = (m < npix_out && c < cols_out) ? (unsigned)((((n * p.H + y0 + r) * W + x0 + c) * p.y_cstride + p.y_coff + ch * 8) * 2) : kOOB;
+        s_off[k] = m * ROWB + ((ch ^ (m & 15)) << 4);
+      }
     }
     int rb[MT2], rbn[MT2];
     row_bases(0, 0, 0, rb, false);
@@ -1268,7 +1285,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
         if constexpr (FOLD) o = o8[h];
         else o = bn_res_relu_acc8(A[i][j], h, sc, sh, __builtin_bit_cast(half8_t, res[q][i][j][h]));
 #if FT_BNS_STG
-        *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((CTW * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
+        if constexpr (WSTG) *reinterpret_cast<half8_t*>(stg + wave * (NOUT * 128) + m * 128 + (((i * 4 + 2 * lhi + h) ^ (m & 7)) << 4)) = o;
+        else *reinterpret_cast<half8_t*>(stg + m * ROWB + ((((CTW * wcol + i) * 4 + 2 * lhi + h) ^ (m & 15)) << 4)) = o;
 #else
         // straight from the accumulator layout: the lane's 16 consecutive channels = two adjacent 16-byte stores
         const int orow = m / TWc, ocol = m - orow * TWc;
@@ -1376,8 +1394,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
       zero_acc();
 #if FT_BNS_STG
       // the two staging tiles alternate: a tile's previous readers (quarter q-2) are two barriers behind
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      BNS_BARRIER();
+      // (wave-private pieces: a wave reads back only what it wrote itself, its LDS operations execute in order: no barrier)
+      if constexpr (!WSTG) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BNS_BARRIER();
+      } else {
+        asm volatile("" ::: "memory");       // compiler fence only: the read-out must stay behind the tile's writes in program order
+      }
       readout(qc);
 #endif
     });
