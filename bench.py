@@ -60,7 +60,7 @@ def build_flow(device, dtype, seed=1234, name="FlowNet2S"):
 def pmc_traffic(workload):
     """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE; tools/dev/prof_traffic.sh + pmc_traffic.py on this same command). None if not measured."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):       # the latest committed round
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):       # the latest committed round
         name = f"{tag}_{workload}_hbm_traffic_pmc.json"
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:

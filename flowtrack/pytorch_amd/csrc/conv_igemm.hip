@@ -1558,13 +1558,20 @@ __global__ __launch_bounds__(512, 1) void conv_stem_persist_kernel(const ConvPar
 // fp16 in LDS, and writes only the pooled maxima: the [N, H/2, W/2, 64] stem map — the largest activation of the trunk,
 // 100 MB at batch 64 — is never written or re-read.  Pooling happens on the same fp16 values the separate launches
 // would pool, so the result is bit-identical to conv_stem_kernel + maxpool3x3s2.
+// Round 6, tried and left OFF (FT_STEM_POOL_ALLW=1): all seven kernel rows' weights (28 KiB) DMA'd into LDS in the prologue and the K
+// walk without a wait or a barrier (the three-slot ring puts a full vmcnt(0) + s_barrier in front of every ten MFMAs of a wave).
+// Bit-identical, and SLOWER: 54.3 vs 50.3 us in the network (three interleaved runs each, one box) — a workgroup then waits for 28 KiB of
+// weights before its first MFMA instead of 8, and the barriers were not what the patch gather leaves exposed.
+#ifndef FT_STEM_POOL_ALLW
+#define FT_STEM_POOL_ALLW 0
+#endif
 template <int RUNB>
 __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams p, int Hp, int Wp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KH = 7, STRIDE = 2, BC = 64, NW = 4, WGP = 2;
   constexpr int PT = 8, TS = 2 * PT + 1, NPX = TS * TS;      // pooled tile edge, stem patch edge (17), stem pixels (289)
   constexpr int MT_P = 5, WT_P = MT_P * 32;                  // 2 x 160 >= 289 pixels
-  constexpr int S = 3, A_STAGE = BC * RUNB;
+  constexpr int S = FT_STEM_POOL_ALLW ? KH : 3, A_STAGE = BC * RUNB;
   constexpr int CH = RUNB / 16, SWZ_DIV = 256 / RUNB >= 1 ? 256 / RUNB : 1, RPI = 64 / CH;
   constexpr int NIA = BC / RPI / NW;
   constexpr int G = RUNB / 32;
@@ -1664,7 +1671,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(ring + slot * A_STAGE + (wave + NW * t) * 1024), 16,
                                                live ? a_voff[t] : kOOB, live ? ky * RUNB : 0, 0, 0);
   };
-  static_for<S - 1>([&](auto sc) { load_a(sc, decltype(sc)::value < KH, decltype(sc)::value); });
+  static_for<FT_STEM_POOL_ALLW ? S : S - 1>([&](auto sc) { load_a(sc, decltype(sc)::value < KH, decltype(sc)::value); });
   if (p.x_planar) {                            // the gathered pixels land in the patch while the first weight rows are on their way
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
@@ -1695,9 +1702,11 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
   static_for<KH>([&](auto ky_c) {
     constexpr int ky = decltype(ky_c)::value;
     constexpr int slot = ky % S, nslot = (ky + S - 1) % S;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // full wait: see conv_stem_kernel
-    FT_LDS_BARRIER();
-    load_a(std::integral_constant<int, nslot>{}, ky + S - 1 < KH, ky + S - 1);
+    if constexpr (!FT_STEM_POOL_ALLW || ky == 0) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // full wait: see conv_stem_kernel
+      FT_LDS_BARRIER();
+    }
+    if constexpr (!FT_STEM_POOL_ALLW) load_a(std::integral_constant<int, nslot>{}, ky + S - 1 < KH, ky + S - 1);
     const char* sa = ring + slot * A_STAGE;
     const char* pb = patch + ky * RBp;
 #pragma unroll
@@ -2482,7 +2491,7 @@ static int launch_stem_pool(ConvParams p, const ft_conv_desc* d, const Geometry&
   p.h_tx = ceil_div(Wp, 8);
   p.npt = d->N * p.h_ty * p.h_tx;
   p.nct = 1;
-  size_t lds = (size_t)3 * 64 * runb + p.h_pb;
+  size_t lds = (size_t)(FT_STEM_POOL_ALLW ? 7 : 3) * 64 * runb + p.h_pb;
   if (lds < 320 * 128) lds = 320 * 128;
   hipLaunchKernelGGL(conv_stem_pool_kernel<64>, dim3(p.npt), dim3(256), lds, s, p, Hp, Wp);
   FT_LAUNCH_CHECK("conv_stem_pool_kernel");

@@ -6,7 +6,8 @@
 // (cv2 defaults), optional per-channel normalisation, output already in the net's NCHW fp32 input layout.
 // Two forms.  `ft_crop_affine_fwd`: the ideal bilinear crop in fp32 (fast default; differs from cv2's uint8 result by
 // up to 0.5 grey level + cv2's 1/32-px coordinate snap).  `ft_crop_affine_cv2_fwd` (round 5): what cv2.warpAffine RETURNS
-// for a uint8 frame, bit for bit — OpenCV's fixed-point INTER_LINEAR (imgwarp.cpp: cv::warpAffine, WarpAffineInvoker,
+// for a uint8 frame — bit-exact to the RESTATED classic OpenCV path (oracle/tracking_ref.py; parity with a real cv2 build is unpinned:
+// none is installed here) — OpenCV's fixed-point INTER_LINEAR (imgwarp.cpp: cv::warpAffine, WarpAffineInvoker,
 // initInterTab2D, remapBilinear<FixedPtCast<int, uchar, 15>>): inverse map in AB_BITS = 10 fixed point with
 // round_delta = 16, 1/32-px fractional index, 15-bit weights a * b * 32, (sum + 2^14) >> 15, constant-0 border taps.
 // Integer work => the test bar is bit-exact against oracle/tracking_ref.py::warp_affine_cv2_ref.

@@ -70,7 +70,8 @@ def crop_boxes(frame_dev: torch.Tensor, centers: np.ndarray, scales: np.ndarray,
                cv2_exact: bool = False, return_u8: bool = False):
     """frame_dev: uint8 [H,W,3] (BGR) on the GPU -> crops [N,3,h,w] fp32 on the GPU in one launch
     (ft_crop_affine_fwd; replaces N x cv2.warpAffine + N H2D copies, net_utils.py:49-57).
-    cv2_exact: the crops are cv2.warpAffine's uint8 values bit for bit (ft_crop_affine_cv2_fwd: OpenCV's fixed-point
+    cv2_exact: the crops are cv2.warpAffine's uint8 values as the restated classic OpenCV path computes them, bit for bit (unpinned
+    against a real cv2 build; ft_crop_affine_cv2_fwd: OpenCV's fixed-point
     INTER_LINEAR) before the normalisation; return_u8 additionally returns them as uint8 [N,h,w,3] = cv2's return value."""
     require_gpu(frame_dev.device)
     if frame_dev.dtype != torch.uint8 or frame_dev.dim() != 3 or not frame_dev.is_contiguous():
@@ -170,7 +171,8 @@ class PoseRunner:
     def __init__(self, net, inp_res=(256, 192), normalize=True, replica: int = 0, stream=None, cv2_exact: bool = False):
         """replica / stream: a runner of its own plan copies (DeconvResnet.plan_for(..., replica)) whose launches go to
         `stream` — several runners on one net then overlap on the GPU (one per clip, tools/tracking/demo.run_clips).
-        cv2_exact: crops are cv2.warpAffine's uint8 values bit for bit (ft_crop_affine_cv2_fwd) instead of the fp32 bilinear."""
+        cv2_exact: crops in cv2.warpAffine's fixed-point arithmetic (bit-exact to the restated classic OpenCV path, unpinned against a
+        real cv2 build: ft_crop_affine_cv2_fwd) instead of the fp32 bilinear."""
         self.net, self.inp_res = net, inp_res
         self.replica, self.stream = int(replica), stream
         self.cv2_exact = bool(cv2_exact)

@@ -474,7 +474,9 @@ int ft_crop_affine_fwd(const uint8_t* img, int H, int W, int C, const float* box
                        const float* mean, const float* inv_std, float pre_scale, float* out,
                        ft_stream_t stream);
 
-/* The same crop as cv2 RETURNS it for a uint8 frame, bit for bit (round 5): OpenCV's fixed-point INTER_LINEAR
+/* The same crop in the fixed-point arithmetic of cv2.warpAffine for a uint8 frame (round 5) — bit-exact to the RESTATED classic OpenCV
+ * path (oracle/tracking_ref.py::warp_affine_cv2_ref; no cv2 in this image, so parity with a real cv2 build is UNPINNED; OpenCV >= 4.11,
+ * IPP and HAL builds may differ in the last bit): OpenCV's fixed-point INTER_LINEAR
  * (imgwarp.cpp cv::warpAffine / WarpAffineInvoker / remapBilinear<FixedPtCast<int, uchar, 15>>; the third-party
  * dependency behind lib/pose/utils/transforms.py:238).  minv: double[nb*6], per box the dst -> src 2x3 map that
  * cv::warpAffine derives from the matrix it is handed (the caller inverts in double, cv2's operation order:

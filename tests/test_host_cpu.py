@@ -16,11 +16,22 @@ from flowtrack.pytorch_amd.pose import evaluation
 
 def test_library_exports_every_declared_symbol(hip_lib):
     header = open(os.path.join(ROOT, "include", "flowtrack_hip.h")).read()
-    declared = set(re.findall(r"\b(ft_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no declarations parsed"
-    for name in declared:
+    # the drop-in boundary = everything outside `#ifdef FT_EXPERIMENTAL`; the experimental block holds measured alternatives
+    a, b = header.index("#ifdef FT_EXPERIMENTAL"), header.index("#endif /* FT_EXPERIMENTAL */")
+    stable_text, exp_text = header[:a] + header[b:], header[a:b]
+    pat = r"^(?:int|long long|double|size_t|const char\*)\s+(ft_[a-z0-9_]+)\s*\("
+    declared = set(re.findall(pat, stable_text, flags=re.M))
+    experimental = set(re.findall(pat, exp_text, flags=re.M))
+    assert declared and experimental, "no declarations parsed"
+    for name in declared | experimental:
         assert hasattr(hip_lib, name), f"{name} declared in flowtrack_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert experimental == set(_lib.EXPERIMENTAL_SYMBOLS), experimental ^ set(_lib.EXPERIMENTAL_SYMBOLS)
+    # the library exports the C ABI and nothing else (csrc/exports.map): no mangled C++ helper, no kernel stub
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared | experimental, sorted(exported ^ (declared | experimental))[:10]
     assert hip_lib.ft_version() >= 100
     assert hip_lib.ft_status_string(1) == b"invalid argument"
 
