@@ -1565,7 +1565,18 @@ __global__ __launch_bounds__(512, 1) void conv_stem_persist_kernel(const ConvPar
 #ifndef FT_STEM_POOL_ALLW
 #define FT_STEM_POOL_ALLW 0
 #endif
-template <int RUNB>
+#ifndef FT_STEM_ABL
+#define FT_STEM_ABL 0     // dev ablations (timing only, wrong results): 1 = no planar gather loads, 2 = no output stores, 4 = no weight loads, 8 = no MFMAs
+#endif
+// Round 6: the kernel is bound by instruction ISSUE, not by a memory or the matrix pipe (tools/dev/isa_phases.py: 70 MFMAs against
+// 1461 vector + 506 scalar instructions per wave, four workgroups per CU: 33 per MFMA; ~1200 of them were the address arithmetic of
+// the planar gather in the prologue).  CPRC > 0 = the 16-byte chunks per patch row as a COMPILE-TIME constant (the pose stem: 20)
+// and a gather mapping without divisions: thread -> (chunk tid % CPRC, row tid / CPRC + (256 / CPRC) t): the column tests and the
+// base offset are computed once, a round adds one constant and tests its row; the epilogue multiplies and adds in pairs
+// (v_pk_mul_f32 / v_pk_add_f32: the same two roundings as the scalar pair), ReLU and the 3x3 pool are INTEGER maxima on the fp16
+// bit patterns (v_pk_max_i16: exact for the non-negative values behind a ReLU, -0 and negatives order below +0, and no
+// canonicalising v_pk_max in front of every maximum as with the fp16 form).  Bit-identical to the forms it replaces.
+template <int RUNB, int CPRC = 0>
 __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams p, int Hp, int Wp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KH = 7, STRIDE = 2, BC = 64, NW = 4, WGP = 2;
@@ -1600,7 +1611,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
   const int py0 = tyi * PT, px0 = txi * PT;              // pooled origin
   const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;        // stem-output origin (row / column -1 = the pool's padding)
   const int cpb = p.x_cstride * 2;
-  const int CPR = p.h_pw;
+  const int CPR = CPRC > 0 ? CPRC : p.h_pw;
   const int RBp = CPR * 16;
   const int iy_org = oy0 * STRIDE - p.pad;
   const int col0 = ox0 * STRIDE - p.pad_x;               // >= 0: the host requires x_lpad >= pad + 2
@@ -1625,6 +1636,30 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
     // every one of the 30 sat in its own divergent region behind a full wait: 66 us instead of 42.5 + 18.4 for pack + stem)
     const __amdgpu_buffer_rsrc_t rsrc_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
     const int HWb = p.Hi * p.x_w * 4;
+    if constexpr (CPRC > 0) {
+      constexpr int RPR = 256 / CPRC;                     // patch rows per round
+      static_assert((PH + RPR - 1) / RPR <= NR, "rounds");
+      const int r0 = tid / CPRC, ch = tid - r0 * CPRC;
+      const int ix0 = col0 + 2 * ch - p.x_lpad;
+      const bool lane_on = r0 < RPR;
+      const bool in0 = lane_on && (unsigned)ix0 < (unsigned)p.x_w, in1 = lane_on && (unsigned)(ix0 + 1) < (unsigned)p.x_w;
+      const int rstep = RPR * p.x_w * 4;
+      unsigned rbase = (unsigned)(((n * 3 * p.Hi + iy_org + r0) * p.x_w + ix0) * 4);
+#pragma unroll
+      for (int t = 0; t < NR; ++t) {
+        if (t * RPR < PH) {
+          const int row = r0 + t * RPR;
+          const bool row_in = row < PH && (unsigned)(iy_org + row) < (unsigned)p.Hi;
+          const unsigned vo0 = (row_in && in0 && !(FT_STEM_ABL & 1)) ? rbase : kOOB, vo1 = (row_in && in1 && !(FT_STEM_ABL & 1)) ? rbase + 4u : kOOB;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            v[t][0][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_f, vo0, c * HWb, 0));
+            v[t][1][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_f, vo1, c * HWb, 0));
+          }
+          rbase += (unsigned)rstep;
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
       const int gci = (t * NW + wave) * 64 + lane;
@@ -1639,6 +1674,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
         for (int c = 0; c < 3; ++c)
           v[t][e][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_f, c < p.x_c ? vo : kOOB, c * HWb, 0));
       }
+    }
     }
   } else {
 #pragma unroll
@@ -1669,15 +1705,18 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
 #pragma unroll
     for (int t = 0; t < NIA; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr)(ring + slot * A_STAGE + (wave + NW * t) * 1024), 16,
-                                               live ? a_voff[t] : kOOB, live ? ky * RUNB : 0, 0, 0);
+                                               (live && !(FT_STEM_ABL & 4)) ? a_voff[t] : kOOB, live ? ky * RUNB : 0, 0, 0);
   };
   static_for<FT_STEM_POOL_ALLW ? S : S - 1>([&](auto sc) { load_a(sc, decltype(sc)::value < KH, decltype(sc)::value); });
   if (p.x_planar) {                            // the gathered pixels land in the patch while the first weight rows are on their way
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
-      if (t < p.h_npww) {
-        const half8_t h8 = {(half_t)v[t][0][0], (half_t)v[t][0][1], (half_t)v[t][0][2], (half_t)0.f,
-                            (half_t)v[t][1][0], (half_t)v[t][1][1], (half_t)v[t][1][2], (half_t)0.f};
+      const half8_t h8 = {(half_t)v[t][0][0], (half_t)v[t][0][1], (half_t)v[t][0][2], (half_t)0.f,
+                          (half_t)v[t][1][0], (half_t)v[t][1][1], (half_t)v[t][1][2], (half_t)0.f};
+      if constexpr (CPRC > 0) {
+        constexpr int RPR = 256 / CPRC;
+        if (t * RPR < PH && tid < RPR * CPRC && tid / CPRC + t * RPR < PH) *reinterpret_cast<half8_t*>(patch + (tid + t * RPR * CPRC) * 16) = h8;
+      } else if (t < p.h_npww) {
         *reinterpret_cast<half8_t*>(patch + ((t * NW + wave) * 64 + lane) * 16) = h8;
       }
     }
@@ -1716,8 +1755,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
 #pragma unroll
       for (int j = 0; j < MT_P; ++j) fb[j] = *reinterpret_cast<const uint4_t*>(pb + b_off[j] + g * 32);
 #pragma unroll
-      for (int j = 0; j < MT_P; ++j)
+      for (int j = 0; j < MT_P; ++j) {
+#if FT_STEM_ABL & 8
+        acc[j][0] += __builtin_bit_cast(float, fa.x ^ fb[j].x);
+        continue;
+#endif
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa), __builtin_bit_cast(half8_t, fb[j]), acc[j], 0, 0, 0);
+      }
     }
   });
 
@@ -1744,10 +1788,17 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
       const int msw = (m & 7) << 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        half4_t h;
+        typedef short short2_t __attribute__((ext_vector_type(2)));
+        uint2 hb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (half_t)__builtin_fmaxf(acc[j][g * 4 + e] * sc[g][e] + sh[g][e], 0.f);
-        uint2 hb = __builtin_bit_cast(uint2, h);
+        for (int e = 0; e < 4; e += 2) {
+          const float2_t prod = float2_t{acc[j][g * 4 + e], acc[j][g * 4 + e + 1]} * float2_t{sc[g][e], sc[g][e + 1]};   // rounded
+          const float2_t sum = prod + float2_t{sh[g][e], sh[g][e + 1]};                                                      // rounded again
+          const half2_t hh = __builtin_convertvector(sum, half2_t);
+          // ReLU on the fp16 bit pattern: as 16-bit integers every negative half (and -0) is below +0
+          const short2_t r = __builtin_elementwise_max(__builtin_bit_cast(short2_t, hh), short2_t{0, 0});
+          (e == 0 ? hb.x : hb.y) = __builtin_bit_cast(unsigned, r);
+        }
         hb.x = inside ? hb.x : 0u;
         hb.y = inside ? hb.y : 0u;
         *reinterpret_cast<uint2*>(rowp + (((wc * 4 + g) << 4) ^ msw)) = hb;
@@ -1762,16 +1813,17 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
     const int idx = tid + 256 * i, pp = idx >> 3, ch = idx & 7;
     const int ppy = pp >> 3, ppx = pp & 7;
     const int py = py0 + ppy, px = px0 + ppx;
-    half8_t best = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef short short8_t __attribute__((ext_vector_type(8)));
+    short8_t best = {0, 0, 0, 0, 0, 0, 0, 0};            // the tile holds non-negative halves: their order is the order of their bit patterns
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int m = (2 * ppy + dy) * TS + 2 * ppx + dx;
         const uint4_t v = *reinterpret_cast<const uint4_t*>(stage + m * 128 + ((ch ^ (m & 7)) << 4));
-        best = __builtin_elementwise_max(best, __builtin_bit_cast(half8_t, v));
+        best = __builtin_elementwise_max(best, __builtin_bit_cast(short8_t, v));
       }
-    if (py < Hp && px < Wp)
+    if (py < Hp && px < Wp && !(FT_STEM_ABL & 2))
       store_out16(p.y + ((((long long)n * Hp + py) * Wp + px) * p.y_cstride + p.y_coff + ch * 8) * 2, __builtin_bit_cast(uint4_t, best));
   }
 #endif
@@ -2493,7 +2545,10 @@ static int launch_stem_pool(ConvParams p, const ft_conv_desc* d, const Geometry&
   p.nct = 1;
   size_t lds = (size_t)(FT_STEM_POOL_ALLW ? 7 : 3) * 64 * runb + p.h_pb;
   if (lds < 320 * 128) lds = 320 * 128;
-  hipLaunchKernelGGL(conv_stem_pool_kernel<64>, dim3(p.npt), dim3(256), lds, s, p, Hp, Wp);
+  if (p.x_planar && p.h_pw == 20 && d->Cin == 3)      // the pose stem from the NCHW fp32 crop: compile-time patch pitch, division-free gather
+    hipLaunchKernelGGL((conv_stem_pool_kernel<64, 20>), dim3(p.npt), dim3(256), lds, s, p, Hp, Wp);
+  else
+    hipLaunchKernelGGL(conv_stem_pool_kernel<64>, dim3(p.npt), dim3(256), lds, s, p, Hp, Wp);
   FT_LAUNCH_CHECK("conv_stem_pool_kernel");
   return FT_OK;
 }
