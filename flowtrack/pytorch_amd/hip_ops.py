@@ -1199,6 +1199,17 @@ def _folded_kmajor(conv: "FusedConv"):
     return w.half().contiguous(), (shift if shift is not None else torch.zeros(conv.cout))
 
 
+def _fold_representable(convs) -> bool:
+    """The folded form keeps scale * weight and the shift's high part in fp16: a BatchNorm whose folded scale pushes a weight, or
+    whose shift lies, beyond the fp16 range (|v| > 65504: never seen in a pose / flow checkpoint, but legal) must take the table form,
+    which applies both in fp32."""
+    for c in convs:
+        w, sh = _folded_kmajor(c)
+        if not bool(torch.isfinite(w.float()).all()) or not bool(torch.isfinite(sh.float().half().float()).all()):
+            return False
+    return True
+
+
 def shift_pairs(shift: torch.Tensor) -> torch.Tensor:
     """fp32 shifts as (hi, lo) fp16 pairs in one int32 each: hi = fp16(shift) in bits 0-15, lo = fp16(shift - hi) in bits 16-31
     (ft_bottleneck_desc.folded): the two halves are two k-slots of the MFMA slice that adds the shift, so it arrives with ~22 bits."""
@@ -1308,6 +1319,11 @@ def record_bottleneck(prog: Program, c1: "FusedConv", c2: "FusedConv", c3: "Fuse
         check(lib.ft_bottleneck_stream_supported(ctypes.byref(d)), "ft_bottleneck_stream_supported")
         flops = float(lib.ft_bottleneck_flops(ctypes.byref(d)))
         fold = (FOLD_BOTTLENECK_STREAM if fold is None else fold) and not cluster and lib.ft_bottleneck_stream_folds(ctypes.byref(d)) == 1
+        if fold:
+            ok = c1._packed.get(("bns_fold_ok",))
+            if ok is None:
+                ok = c1._packed[("bns_fold_ok",)] = _fold_representable((c1, c2, c3))
+            fold = ok
         d.folded = 1 if fold else 0
         wstream, tables = _bottleneck_stream_operands(c1, d, x, planes, (w1, s1, b1), (w2, s2, b2), (w3, s3, b3),
                                                       convs=(c1, c2, c3) if fold else None)

@@ -577,3 +577,56 @@ def test_register_stationary_strip_form_matches_oracle_and_the_patch_form(hip_li
     diff = (outs[2] - outs[0]).abs()
     assert diff.max().item() <= 1e-2 * scale, f"{name}: strip form vs patch form max abs diff {diff.max().item():.3e}"
     assert diff.mean().item() <= 5e-4 * scale, f"{name}: strip form vs patch form mean abs diff {diff.mean().item():.3e}"
+
+
+@pytest.mark.parametrize("planes", [128, 256])
+def test_stream_folded_form_edge_cases(hip_lib, planes):
+    """The folded operands (round 6) where they could go wrong: NEGATIVE BatchNorm gammas (the folded weights change sign), shifts of
+    a few hundred (the (hi, lo) fp16 pair must carry them: hi alone is 0.25 off at 300), a zero gamma (a channel that is its shift),
+    and a shift beyond the fp16 range — there hip_ops must fall back to the table form (and still match the oracle)."""
+    P, C = planes, 4 * planes
+    N, H, W = (2, 16, 12) if P == 256 else (2, 32, 24)
+    dev, dtype, seed = torch.device("cuda:0"), torch.float16, 41
+    name = f"fold_edge_{P}"
+    w1 = synth.normal(seed, name + ".w1", (P, C, 1, 1), std=(2.0 / C) ** 0.5)
+    w2 = synth.normal(seed, name + ".w2", (P, P, 3, 3), std=(2.0 / (9 * P)) ** 0.5)
+    w3 = synth.normal(seed, name + ".w3", (C, P, 1, 1), std=(2.0 / P) ** 0.5)
+    x = synth.normal(seed, name + ".x", (N, C, H, W)).half().float()
+    for case in ("negative_gamma_big_shift", "shift_beyond_fp16"):
+        bn1, bn2, bn3 = _bn(seed, name + ".bn1", P), _bn(seed, name + ".bn2", P), _bn(seed, name + ".bn3", C)
+        sign = torch.where(synth.uniform(seed, name + ".sg", (P,)) < 0.4, -1.0, 1.0)
+        bn1["weight"] = bn1["weight"] * sign
+        bn2["weight"] = bn2["weight"] * torch.flip(sign, dims=[0])
+        bn2["weight"][5] = 0.0
+        bn3["weight"] = bn3["weight"] * torch.where(synth.uniform(seed, name + ".sg3", (C,)) < 0.5, -1.0, 1.0)
+        bn3["bias"] = bn3["bias"] + synth.normal(seed, name + ".big", (C,), std=150.0)          # shifts of a few hundred on the output
+        bn1["bias"][3] = 300.3
+        if case == "shift_beyond_fp16":
+            bn3["bias"][7] = 1.0e5
+        t1 = F.relu(_bnf(F.conv2d(x, w1), bn1))
+        t2 = F.relu(_bnf(F.conv2d(t1, w2, padding=1), bn2))
+        want = F.relu(_bnf(F.conv2d(t2, w3), bn3) + x)
+        mk = dict(dtype=dtype, device=dev, act="relu")
+        c1, c2, c3 = FusedConv(w1, bn=bn1, **mk), FusedConv(w2, pad=1, bn=bn2, **mk), FusedConv(w3, bn=bn3, **mk)
+        xv = nchw_to_view(x, dtype, dev)
+        y = ActView(torch.zeros((N, H, W, C), dtype=dtype, device=dev), C, 0)
+        prog = make_program()
+        record_bottleneck(prog, c1, c2, c3, xv, y, name)
+        assert prog.calls[0][0] == "ft_bottleneck_stream_fwd"
+        folded = bool(prog.calls[0][1][0]._obj.folded)
+        assert folded == (case != "shift_beyond_fp16"), f"{case}: folded = {folded}"
+        run_program(prog)
+        got = view_to_nchw(y)
+        fin = torch.isfinite(want) & (want.abs() < 6.0e4)                  # (the 1e5 channel overflows fp16 on every path)
+        # t1 carries a channel of ~300 into conv2 and the outputs reach several hundred: the yardstick is the TABLE form on the same
+        # operands (fp32 scale / shift, the same fp16 storage of t1 / t2 / y): the folded form must be as close to the oracle as it is
+        yt = ActView(torch.zeros((N, H, W, C), dtype=dtype, device=dev), C, 0)
+        prog_t = make_program()
+        record_bottleneck(prog_t, c1, c2, c3, xv, yt, name, fold=False)
+        run_program(prog_t)
+        rel = lambda a: ((a - want).abs() / (1.0 + want.abs()))[fin]
+        err, err_t = rel(got).max().item(), rel(view_to_nchw(yt)).max().item()
+        print(f"{name} {case}: max relative err folded {err:.3e} / table form {err_t:.3e}; mean {rel(got).mean().item():.2e} / {rel(view_to_nchw(yt)).mean().item():.2e}")
+        assert err <= 1.5 * err_t + 1e-3 and rel(got).mean().item() <= 1.5 * rel(view_to_nchw(yt)).mean().item() + 1e-5, f"{case}: folded {err:.3e} vs table {err_t:.3e}"
+        if case == "shift_beyond_fp16":
+            assert torch.isinf(got[:, 7]).all() and (got[:, 7] > 0).all()
