@@ -1623,11 +1623,17 @@ static int cd_launch(const CdParams& p, hipStream_t s) {
   return FT_OK;
 }
 
+#ifndef FT_CD_TAPS72
+#define FT_CD_TAPS72 1
+#endif
 template <int KSPLIT>
 static int cd_dispatch_taps(const CdParams& p, hipStream_t s) {
   if (KSPLIT == 1) {
     switch (p.nc1) {   // 3x3 on 256 channels in 64-channel chunks; longer walks take the run-time loop
       case 36: return cd_launch<KSPLIT, false, 36, true>(p, s);
+#if FT_CD_TAPS72
+      case 72: return cd_launch<KSPLIT, false, 72, true>(p, s);     // 3x3 on 512 channels (FlowNet conv4_1 / conv5 / conv5_1)
+#endif
       default: return cd_launch<KSPLIT, false, 0, true>(p, s);
     }
   }
