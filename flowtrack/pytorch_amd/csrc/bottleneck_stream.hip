@@ -65,6 +65,9 @@ __device__ __forceinline__ void bns_unroll(F&& f) {
 #ifndef FT_BNS_STG
 #define FT_BNS_STG 1    // dev A/B: 0 = phase 3 of the direct kernel stores straight from the accumulator layout (no LDS staging tile)
 #endif
+#ifndef FT_BNS_TOUCH_FIRST
+#define FT_BNS_TOUCH_FIRST 0   // 1 = the L2 touch and the table / shift loads in FRONT of x chunk 0 (rounds 3-5), 0 = behind it and the first weight step
+#endif
 #ifndef FT_BNS_WSTG
 #define FT_BNS_WSTG 1   // round 6: phase 3 of the direct kernel (two channel tiles per wave) transposes a quarter's tile through a WAVE-PRIVATE
                         // piece of the staging tile: the wave's 64 channels of a pixel are one aligned 128-byte run of y, so it writes whole
@@ -268,11 +271,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
   BNS_TS(0);
   // prologue: chunk 0 (x + W1 slice) leads every wave's load queue, then the L2 touch and table 0 / the shift pairs, chunks 1 and 2,
   // the zero row
+#if FT_BNS_TOUCH_FIRST
+  issue_touch();
+  if constexpr (FOLD) load_shp();
+  else issue_tab(0);
+  asm volatile("" ::: "memory");
+  issue_x(0, 0); issue_w(0, 0);
+#else
   issue_x(0, 0); issue_w(0, 0);
   issue_touch();
   if constexpr (FOLD) load_shp();
   else issue_tab(0);
   asm volatile("" ::: "memory");
+#endif
   issue_x(1, 1); issue_w(1, 1);
   issue_x(2, 2); issue_w(2, 2);
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + G::ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_stream_kernel(const BnsPara
                                                               acc1[i][j], 0, 0, 0);
     };
     // chunk 0 has landed (this wave's share) while the touch, the table / shift loads and chunks 1 and 2 fly; after the barrier everyone's share has
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (LX + LW) + kTouch + (FOLD ? 12 : G::LT)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (LX + LW) + (FT_BNS_TOUCH_FIRST ? 0 : kTouch + (FOLD ? 12 : G::LT))) : "memory");
     BNS_BARRIER();
     ld1(c0{}, 0, 0);
     bns_unroll<NC1>([&](auto cc) {
@@ -890,11 +901,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
   };
   // order of every wave's (in-order) load queue: x chunk 0, the weights of step 0, the L2 touch, the tables / shift pairs, x chunks 1
   // and 2, the weights of steps 1 .. D-1
+#if FT_BNS_TOUCH_FIRST
+  issue_touch();
+  load_tables();
+  asm volatile("" ::: "memory");
+  issue_x(0, 0);
+  load_a(std::integral_constant<int, 0>{}, 0);
+#else
   issue_x(0, 0);
   load_a(std::integral_constant<int, 0>{}, 0);
   issue_touch();
   load_tables();
   asm volatile("" ::: "memory");
+#endif
   issue_x(1, 1);
   issue_x(2, 2);
   bns_unroll<D - 1>([&](auto sc) { load_a(std::integral_constant<int, decltype(sc)::value + 1>{}, decltype(sc)::value + 1); });
@@ -954,7 +973,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bottleneck_stream_direct_kern
     };
     // x chunk 0 has landed (this wave's share): behind it chunks 1, 2 and the two weight steps (8 loads each) may fly
     static_assert(2 * LX + 4 * CTW * D + kTouch + kTabLoads <= 63, "vmcnt immediate");
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 4 * CTW * D + kTouch + kTabLoads) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LX + 4 * CTW * D + (FT_BNS_TOUCH_FIRST ? 0 : kTouch + kTabLoads)) : "memory");
     BNS_BARRIER();
     BNSD_TS(7);             // start-up: x chunk 0 of every wave has landed
     ldx(c0{}, 0, 0);
