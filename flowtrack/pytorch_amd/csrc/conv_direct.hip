@@ -44,7 +44,23 @@ struct CdParams {
   unsigned x_bytes, x2_bytes, y_bytes, res_bytes, ws_bytes;
   int cpt, kw, Hi, Wi, stride, pad;   // TAPS form (kh x kw, any stride): chunks per tap, kernel width, input map, geometry
   int dbg;                     // FT_CD_DBG (dev): 32 = phase timestamps of wave 0 into the tile's first output row
+  int wmajor;                  // workgroup order: 0 = channel block fastest (an XCD shares pixel tiles), 1 = pixel tile fastest (an XCD shares weights)
 };
+
+// Which operand should an XCD's L2 share?  Block b runs on XCD b % 8 and the kernels hand each XCD one contiguous range of the
+// (pixel tile, channel block) grid.  Channel block fastest: the range covers few pixel tiles and EVERY channel block, so each of
+// the eight L2s pulls the whole weight stream.  Right for the ResNet stages (2-5 MB of weights against 3-100 MB of activations),
+// wrong for FlowNet's deep end: conv6_1 has 18.9 MB of weights for 1.5 MB of input, and 8 x 18.9 MB through HBM is 30 us of a
+// 36-us launch.  Pixel tile fastest gives an XCD 1 / 8 of the channel blocks and every pixel tile: 8 x the input + 1 x the weights.
+static inline int cd_wmajor(long long x_bytes, long long w_bytes, int npt, int ncb) {
+  // Measured (round 6, one call): alone and L2-warm conv6_1 36.2 -> 27.1 us, conv6 21.4 -> 20.2 us; behind cold caches 35.7 -> 32.8 us;
+  // FlowNet2S with the rule below 18.93 / 19.00 / 19.00 k against 19.00 / 19.02 / 19.06 k pairs/s without: nothing in the network, so
+  // the order is OFF unless FT_CD_WMAJOR says otherwise (1 = every layer, 2 = the byte rule).
+  static const int mode = getenv("FT_CD_WMAJOR") ? atoi(getenv("FT_CD_WMAJOR")) : 0;
+  if (mode != 2) return mode == 1;
+  if (ncb < 8 || npt < 2) return 0;
+  return 8 * x_bytes + w_bytes < x_bytes + 8 * w_bytes;
+}
 
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void cd_unroll(F&& f) {
@@ -120,7 +136,9 @@ __global__ __launch_bounds__(256, 1) void conv_direct_kernel(const CdParams p) {
     const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  // wmajor (round 6): the XCD's contiguous range walks the pixel tiles of ONE channel block first, so an XCD's L2 holds its own
+  // 1 / 8 of the weight stream instead of all of it (layers whose weights outweigh their input: see cd_wmajor)
+  const int cb = p.wmajor ? logical / p.npt : logical % p.ncb, pt = p.wmajor ? logical % p.npt : logical / p.ncb;
   const int m0 = pt * BP;
   const int nchunk = NCH > 0 ? NCH : p.nc1 + p.nc2;
 
@@ -453,6 +471,7 @@ struct C3Params {
   float slope;
   int npt, ncb;
   unsigned x_bytes, y_bytes, ws_bytes;
+  int wmajor;                  // see CdParams / cd_wmajor
 };
 
 // TT > MT: the STRIP form for maps too large to be resident whole (FlowNet's conv5_1 on 12 x 16, FlowNetS.py:30): a workgroup owns
@@ -482,7 +501,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_kernel(const C3Params p
     const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  // wmajor (round 6): the XCD's contiguous range walks the pixel tiles of ONE channel block first, so an XCD's L2 holds its own
+  // 1 / 8 of the weight stream instead of all of it (layers whose weights outweigh their input: see cd_wmajor)
+  const int cb = p.wmajor ? logical / p.npt : logical % p.ncb, pt = p.wmajor ? logical % p.npt : logical / p.ncb;
   // whole images: tile rows = output pixels = the pixels of ipw images.  Strip: the tile starts one image row above the strip.
   int npix, m0, tile_m0, tile_rows;
   if constexpr (STRIP) {
@@ -742,7 +763,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2_direct_kernel(const C3Params
     const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  // wmajor (round 6): the XCD's contiguous range walks the pixel tiles of ONE channel block first, so an XCD's L2 holds its own
+  // 1 / 8 of the weight stream instead of all of it (layers whose weights outweigh their input: see cd_wmajor)
+  const int cb = p.wmajor ? logical / p.npt : logical % p.ncb, pt = p.wmajor ? logical % p.npt : logical / p.ncb;
   // whole image: the tile is the image's input map.  STRIP form (p.strip_rows > 0: maps of more than 256 input pixels, FlowNet's
   // conv5 on 24 x 32): the workgroup owns strip_rows output rows; its tile = the 2 R + 1 input rows under them (rows outside the
   // image are out-of-range loads = zeros: only the x borders need the tap mask)
@@ -1020,7 +1043,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3s2p_direct_kernel(const C3Param
     const int q = total >> 3, r = total & 7, xcd = b & 7, loc = b >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int cb = logical % p.ncb, pt = logical / p.ncb;
+  // wmajor (round 6): the XCD's contiguous range walks the pixel tiles of ONE channel block first, so an XCD's L2 holds its own
+  // 1 / 8 of the weight stream instead of all of it (layers whose weights outweigh their input: see cd_wmajor)
+  const int cb = p.wmajor ? logical / p.npt : logical % p.ncb, pt = p.wmajor ? logical % p.npt : logical / p.ncb;
   const int npix_in = p.HW, npo = p.Ho * p.Wo;
   const int rows_in = 2 * npix_in;                  // input pixels of this workgroup's two images
   const int npix = 2 * npo;                         // its output pixels
@@ -1775,6 +1800,7 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
     q.x_bytes = (unsigned)((size_t)d->N * q.HW * d->x_cstride * 2);
     q.y_bytes = (unsigned)((size_t)q.M * d->y_cstride * 2);
     q.ws_bytes = (unsigned)ft_conv_direct_weight_bytes(d);
+    q.wmajor = cd_wmajor((long long)d->N * q.HW * d->Cin * 2, q.ws_bytes, q.npt, q.ncb);
     if (p3.stride == 2 && p3.ipw == 2) {
       const int nld = (2 * q.HW * 256 + 4095) / 4096;            // 1-KiB tile pieces per wave
       if (p3.mt <= 2) return nld <= 16 ? c3s2p_launch<2, 16>(q, as_stream(stream)) : c3s2p_launch<2, 32>(q, as_stream(stream));
@@ -1847,6 +1873,8 @@ extern "C" int ft_conv_direct_fwd(const ft_conv_desc* d, const void* x, const vo
   }
   static const int dbg = getenv("FT_CD_DBG") ? atoi(getenv("FT_CD_DBG")) : 0;
   p.dbg = dbg;
+  p.wmajor = cd_wmajor((long long)d->N * d->Hi * d->Wi * d->Cin * 2 + (d->x2_cin ? (long long)d->N * d->x2_hi * d->x2_wi * d->x2_cin * 2 : 0), p.ws_bytes,
+                       p.npt, p.ncb);
   hipStream_t s = as_stream(stream);
   if (taps) return pl.ksplit == 1 ? cd_dispatch_taps<1>(p, s) : cd_dispatch_taps<4>(p, s);
   if (pl.ksplit == 1) return d->has_residual ? cd_dispatch<1, true>(p, s) : cd_dispatch<1, false>(p, s);
