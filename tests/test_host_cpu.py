@@ -503,3 +503,37 @@ def test_bench_line_summary_is_flat_and_last():
     out["summary"] = s
     line = json.dumps(out, separators=(",", ":"))
     assert line.rstrip("}").rsplit('"summary":', 1)[1].startswith("{") and len(line) < 4000
+
+
+def test_folded_bottleneck_operands_reproduce_batchnorm():
+    """hip_ops._folded_kmajor / shift_pairs (round 6: the operands of ft_bottleneck_stream_fwd with d.folded = 1), host side only: the
+    fp16 weights carry conv * scale with ONE rounding from the fp32 weights, in the K-major order the pack kernel expects
+    ([co][(ky * 3 + kx) * cin + ci]), and the (hi, lo) fp16 pair restores the fp32 shift to ~2^-21 relative: a conv with the folded
+    weights plus hi + lo equals eval-mode BatchNorm(conv) up to the fp16 rounding of the weights."""
+    import torch.nn.functional as F
+    from flowtrack.pytorch_amd import hip_ops, synth
+    co, ci = 32, 48
+    w = synth.normal(5, "fold.w", (co, ci, 3, 3), std=0.1)
+    bn = {"weight": synth.uniform(5, "fold.g", (co,), -1.5, 1.5), "bias": synth.normal(5, "fold.b", (co,), 40.0),
+          "running_mean": synth.normal(5, "fold.m", (co,), 0.3), "running_var": synth.uniform(5, "fold.v", (co,), 0.5, 1.5), "eps": 1e-5}
+    conv = types.SimpleNamespace(cout=co, _weight=w, _bias=None, _bn=bn)
+    wf, shift = hip_ops._folded_kmajor(conv)
+    assert wf.dtype == torch.float16 and tuple(wf.shape) == (co, 9 * ci)
+    scale = bn["weight"].double() / torch.sqrt(bn["running_var"].double() + 1e-5)
+    want_w = (w.double() * scale[:, None, None, None]).permute(0, 2, 3, 1).reshape(co, -1)
+    assert torch.equal(wf, want_w.float().half()), "one rounding from the fp32 product, K-major (tap, channel) order"
+    pairs = hip_ops.shift_pairs(shift)
+    assert pairs.dtype == torch.int32 and pairs.shape == (co,)
+    halves = pairs.view(torch.float16).reshape(co, 2).float()
+    assert torch.equal(halves[:, 0], shift.half().float())                       # hi in the low 16 bits (little endian), lo above it
+    rel = ((halves[:, 0].double() + halves[:, 1].double()) - shift.double()).abs() / shift.double().abs().clamp_min(1e-6)
+    assert rel.max().item() < 2.0 ** -20, rel.max().item()
+    x = synth.normal(5, "fold.x", (2, ci, 9, 7)).half().float()
+    ref = F.batch_norm(F.conv2d(x, w, padding=1), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], training=False, eps=1e-5)
+    w_back = wf.float().reshape(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
+    got = F.conv2d(x, w_back, padding=1) + (halves[:, 0] + halves[:, 1])[None, :, None, None]
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # the guard that sends unrepresentable operands to the table form
+    bn_big = dict(bn, bias=bn["bias"].clone())
+    bn_big["bias"][3] = 1.0e5
+    assert hip_ops._fold_representable((conv,)) and not hip_ops._fold_representable((types.SimpleNamespace(cout=co, _weight=w, _bias=None, _bn=bn_big),))
