@@ -1829,6 +1829,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(const ConvParams
 #endif
 }
 
+// Round 6, tried and removed: the <64, 20> form as a PERSISTENT kernel (three workgroups per CU walking four tiles each, the next
+// tile's patch gather and the previous tile's stores issued right after the K loop so that they fly under the epilogue and the pool;
+// patch behind the stem tile in LDS, scale / shift from LDS, 164 VGPRs).  Bit-identical, 49.6 / 50.0 us against 49.2 / 49.0 us for
+// this kernel in the network (same call): the 15 us the gather costs (FT_STEM_ABL=1) are not exposed latency — four workgroups per
+// CU already overlap one another's gathers — profiles/README.md, round 6.
+
 // ---- few-output-channel conv (FlowNet predict_flow: Cout = 2, K up to 9 * 1026) -----------------------
 // A GEMM tile would leave 30/32 MFMA columns idle and serialise a 9k-long K loop in a handful of
 // workgroups.  Instead: one wave per group of PIX consecutive output pixels, the 64 lanes split the

@@ -364,7 +364,15 @@ __global__ __launch_bounds__(256, 1) void correlation_mfma_rows_kernel(const hal
   // act(v) = max(v, s*v) for s in [0, 1] (relu: 0, leaky: slope, none: 1); the 1/C of the correlation rides along
   const float k_pos = inv_c, k_neg = inv_c * (act == FT_ACT_RELU ? 0.f : (act == FT_ACT_LEAKY ? slope : 1.f));
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting ..
+  // .. and the compiler has to know it: it cannot see the wait above, and with the products behind branches it kept "a[] may still be
+  // in flight" alive at every join, i.e. s_waitcnt vmcnt(15) .. vmcnt(0) in front of the sixteen MFMAs of EVERY step — the last one
+  // drains the whole queue (look-ahead ring rows and the band stores of the previous steps).  An empty asm that redefines the
+  // registers ends that (round 6; found in the ISA of the DIRECT form: 23 x sixteen descending waits).
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[r][s]));
   issue(0, 0);
   issue(1, 1);
   int slot = 0;
@@ -592,7 +600,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void correlation_mfma_rows64_kernel(co
     }
   }
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the f1 fragments sit in registers before the ring starts counting ..
+  // .. and the compiler has to know it: it cannot see the wait above, and with the products behind branches it kept "a[] may still be
+  // in flight" alive at every join, i.e. s_waitcnt vmcnt(15) .. vmcnt(0) in front of the sixteen MFMAs of EVERY step — the last one
+  // drains the whole queue (look-ahead ring rows and the band stores of the previous steps).  An empty asm that redefines the
+  // registers ends that (round 6; found in the ISA of the DIRECT form: 23 x sixteen descending waits).
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a[r][s]));
   if (tid < ROWB / 16) *reinterpret_cast<uint4_t*>(smem + ZROW + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
   corr_unroll<DEPTH>([&](auto pc) { issue(decltype(pc)::value, decltype(pc)::value); });
   corr_unroll<NJ>([&](auto jc) {
@@ -954,6 +970,34 @@ __global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __r
           v += w01[k] * p[oT + oR];
           v += w10[k] * p[oB + oL];
           v += w11[k] * p[oB + oR];
+          out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
+        }
+      }
+    }
+  } else if (W >= 2) {
+    // resample2d_pair_kernel's gathers for this tile: the two x-neighbours of a row as ONE 8-byte request (the gather is bound by
+    // cache-line requests: 6 per pixel instead of 12).  Round 6: this branch issued the four taps one by one until now, which is why
+    // a field whose tiles all fall back (the bench's per-pixel noise) had dropped from the pair kernel's 44 us to 55 us.
+    typedef float float2_t __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+    for (int k = 0; k < kRsPPT; ++k) {
+      const int y = ty0 + k * 4 + wave;
+      if (x < W && y < H) {
+        const int xb = xL[k] < W - 2 ? xL[k] : W - 2;       // pair [xb, xb + 1] holds columns xL and xR
+        const bool l1 = xL[k] != xb, r1 = xR[k] != xb;
+        float2_t t[C], u[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* p = in1 + ((size_t)b * C + c) * HW;
+          t[c] = *reinterpret_cast<const float2_t*>(p + (size_t)yT[k] * W + xb);
+          u[c] = *reinterpret_cast<const float2_t*>(p + (size_t)yB[k] * W + xb);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float v = w00[k] * (l1 ? t[c][1] : t[c][0]);
+          v += w01[k] * (r1 ? t[c][1] : t[c][0]);
+          v += w10[k] * (l1 ? u[c][1] : u[c][0]);
+          v += w11[k] * (r1 ? u[c][1] : u[c][0]);
           out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
         }
       }
