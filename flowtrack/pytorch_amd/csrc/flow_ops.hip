@@ -850,6 +850,10 @@ __global__ __launch_bounds__(256) void resample2d_pair_kernel(const float* __res
 // resample2d_pair_kernel for that tile only (workgroup-uniform branch).  Same weights, same order of the four products as
 // Resample2d_kernel.cu:42-59 restated above: results are bit-identical to the gather kernels.
 constexpr int kRsTH = 16, kRsTW = 64, kRsPPT = 4;          // tile rows / columns, pixels per thread
+#ifndef FT_RS_CLIP_PITCH
+#define FT_RS_CLIP_PITCH 96
+#endif
+constexpr int kRsClipPitch = FT_RS_CLIP_PITCH;                           // row pitch (floats) of a window clipped around its tile: 16 + 2 x 8 rows x 64 + 2 x 15 columns at the default budget
 constexpr int kRsMaxWindow = 6656;                         // window floats per plane (row pitch x rows): 3 planes x 26 KiB = 78 KiB, two workgroups per CU
 
 template <int C>
@@ -911,34 +915,82 @@ __global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __r
   // 16-byte DMA pieces need 16-byte-aligned sources: the window starts at a multiple of four columns (W % 4 == 0: every row base
   // is aligned); otherwise 4-byte pieces, four times as many instructions
   const bool vec4 = (W & 3) == 0;
-  if (vec4) bx0 &= ~3;
-  const int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
-  const int pitch = ww <= 64 ? 64 : (ww <= 128 ? 128 : (ww <= 256 ? 256 : ((ww + 255) & ~255)));   // floats per LDS row: a power of two up to 256
-  const bool fits = (((long long)pitch * wh + 255) & ~255LL) <= wbudget;
-  if (fits) {
+  const int pgran = vec4 ? 32 : 64;                        // floats per LDS row: a multiple of 32 (16-byte pieces) / 64 (4-byte pieces)
+  int wx0 = vec4 ? bx0 & ~3 : bx0, wx1 = bx1, wy0 = by0, wy1 = by1;
+  int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+  int pitch = (ww + pgran - 1) / pgran * pgran;
+  pitch = pitch < 64 ? 64 : pitch;
+  bool window = (((long long)pitch * wh + 255) & ~255LL) <= wbudget;     // the whole box fits: every tap comes from LDS
+  // Round 6: a box that does not fit no longer sends the whole tile to the gathers.  The window is CLIPPED around the tile (rows of
+  // kRsClipPitch floats, as many as the budget holds, centred on the tile's own pixels), pixels whose four taps lie inside it take
+  // them from LDS and only the others gather from memory (8-byte x-neighbour pairs, issued before the window's wait): with
+  // per-pixel N(0, 4 px) flows about one pixel in eight gathers instead of all of them.  A field that spreads over more than four
+  // such windows (the "wide" image of the tests) skips the window.
+  const int clip_pitch = vec4 ? kRsClipPitch : 128;        // (4-byte pieces fill 64-float row segments)
+  if (!window && ww <= 4 * clip_pitch && wh <= 4 * (wbudget / clip_pitch)) {
+    const int cp = pitch < clip_pitch ? pitch : clip_pitch;
+    const int rows = wbudget / cp;
+    if (rows >= kRsTH + 2 && cp >= kRsTW + 2) {
+      int cx0 = tx0 - ((cp - (kRsTW + 1)) >> 1);
+      cx0 = cx0 > wx0 ? cx0 : wx0;
+      if (vec4) cx0 &= ~3;                                  // wx0 is a multiple of four already: cx0 >= wx0 still
+      int cy0 = ty0 - ((rows - (kRsTH + 1)) >> 1);
+      cy0 = cy0 > wy0 ? cy0 : wy0;
+      wx0 = cx0;
+      wx1 = wx1 < cx0 + cp - 1 ? wx1 : cx0 + cp - 1;
+      wy0 = cy0;
+      wy1 = wy1 < cy0 + rows - 1 ? wy1 : cy0 + rows - 1;
+      ww = wx1 - wx0 + 1;
+      wh = wy1 - wy0 + 1;
+      pitch = cp;
+      window = ww > 0 && wh > 0;
+    }
+  }
+  // pixels outside the window: their taps as 8-byte pairs straight from memory, in flight while the window loads
+  typedef float float2_t __attribute__((ext_vector_type(2), aligned(4)));
+  float2_t gt[kRsPPT][C], gu[kRsPPT][C];
+  bool inw[kRsPPT];
+#pragma unroll
+  for (int k = 0; k < kRsPPT; ++k) {
+    const int y = ty0 + k * 4 + wave;
+    const bool live = x < W && y < H;
+    inw[k] = window && xL[k] >= wx0 && xR[k] <= wx1 && yT[k] >= wy0 && yB[k] <= wy1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gt[k][c] = gu[k][c] = float2_t{0.f, 0.f};
+    if (live && !inw[k]) {
+      const int xb = xL[k] < W - 2 ? xL[k] : W - 2;         // pair [xb, xb + 1] holds columns xL and xR (W >= 2: the host's condition)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float* p = in1 + ((size_t)b * C + c) * HW;
+        gt[k][c] = *reinterpret_cast<const float2_t*>(p + (size_t)yT[k] * W + xb);
+        gu[k][c] = *reinterpret_cast<const float2_t*>(p + (size_t)yB[k] * W + xb);
+      }
+    }
+  }
+  const int plane = (pitch * wh + 255) & ~255;             // whole 1-KiB pieces per plane: a piece's tail never reaches the next plane
+  if (window) {
     // the window of every plane through LDS-DMA, straight into LDS (no VGPR round trip, every piece in flight at once: the tile's
-    // latency is ONE memory round trip, not one per row).  A wave instruction moves 1 KiB = 256 consecutive LDS floats = 256 / pitch
-    // window rows (vec4) or 64 floats of one row (4-byte pieces); lanes past the window read out of range = 0
+    // latency is ONE memory round trip, not one per row).  A wave instruction moves 1 KiB = 256 consecutive LDS floats; lanes past
+    // the window read out of range = 0
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in1), 0, in_bytes, 0x00020000);
     constexpr unsigned kOOB = 0x80000000u;
-    const int plane = (pitch * wh + 255) & ~255;           // whole 1-KiB pieces per plane: a piece's tail never reaches the next plane
     if (vec4) {
-      const int nfl = plane;                               // floats of one plane's window image
-      const int lrow = (lane * 4) / pitch, lcol = (lane * 4) % pitch;   // this lane's place inside a piece (pitch <= 256: 1, 2 or 4 rows per piece)
-      const int rpp = pitch >= 256 ? 1 : 256 / pitch;      // rows per piece
-      const int ppr = pitch >= 256 ? pitch / 256 : 1;      // pieces per row
-      const int npieces = pitch >= 256 ? wh * ppr : (wh + rpp - 1) / rpp;
+      // lane -> (row, column) of its four floats in piece `wave`, then + 1024 floats per round (no division in the loop)
+      const int f0 = wave * 256 + lane * 4;
+      const int r0 = f0 / pitch, q0 = f0 - r0 * pitch;
+      const int dr = 1024 / pitch, dq = 1024 - dr * pitch;
+      const int npieces = plane >> 8;
 #pragma unroll 1
       for (int c = 0; c < C; ++c) {
-        const unsigned cbase = (unsigned)((((size_t)b * C + c) * HW + (size_t)by0 * W + bx0) * 4);
+        const unsigned cbase = (unsigned)((((size_t)b * C + c) * HW + (size_t)wy0 * W + wx0) * 4);
+        int r = r0, q = q0;
 #pragma unroll 4
         for (int pc = wave; pc < npieces; pc += 4) {
-          int r, q;
-          if (pitch >= 256) { r = pc / ppr; q = (pc - r * ppr) * 256 + lane * 4; }
-          else { r = pc * rpp + lrow; q = lcol; }
           const unsigned voff = (r < wh && q < ww) ? cbase + (unsigned)((r * W + q) * 4) : kOOB;
-          if (pc * 256 < nfl)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(rs_smem + c * plane + pc * 256), 16, voff, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(rs_smem + c * plane + pc * 256), 16, voff, 0, 0, 0);
+          q += dq;
+          r += dr;
+          if (q >= pitch) { q -= pitch; ++r; }
         }
       }
     } else {
@@ -946,7 +998,7 @@ __global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __r
       const int npieces = wh * nch;
 #pragma unroll 1
       for (int c = 0; c < C; ++c) {
-        const unsigned cbase = (unsigned)((((size_t)b * C + c) * HW + (size_t)by0 * W + bx0) * 4);
+        const unsigned cbase = (unsigned)((((size_t)b * C + c) * HW + (size_t)wy0 * W + wx0) * 4);
 #pragma unroll 4
         for (int pc = wave; pc < npieces; pc += 4) {
           const int r = pc / nch, j = pc - r * nch;
@@ -958,64 +1010,35 @@ __global__ __launch_bounds__(256) void resample2d_window_kernel(const float* __r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
 #pragma unroll
-    for (int k = 0; k < kRsPPT; ++k) {
-      const int y = ty0 + k * 4 + wave;
-      if (x < W && y < H) {
-        const int oT = (yT[k] - by0) * pitch, oB = (yB[k] - by0) * pitch, oL = xL[k] - bx0, oR = xR[k] - bx0;
+  for (int k = 0; k < kRsPPT; ++k) {
+    const int y = ty0 + k * 4 + wave;
+    if (x < W && y < H) {
+      float tL[C], tR[C], uL[C], uR[C];
+      if (inw[k]) {
+        const int oT = (yT[k] - wy0) * pitch, oB = (yB[k] - wy0) * pitch, oL = xL[k] - wx0, oR = xR[k] - wx0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const float* p = rs_smem + c * plane;
-          float v = w00[k] * p[oT + oL];
-          v += w01[k] * p[oT + oR];
-          v += w10[k] * p[oB + oL];
-          v += w11[k] * p[oB + oR];
-          out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
+          tL[c] = p[oT + oL]; tR[c] = p[oT + oR]; uL[c] = p[oB + oL]; uR[c] = p[oB + oR];
         }
-      }
-    }
-  } else if (W >= 2) {
-    // resample2d_pair_kernel's gathers for this tile: the two x-neighbours of a row as ONE 8-byte request (the gather is bound by
-    // cache-line requests: 6 per pixel instead of 12).  Round 6: this branch issued the four taps one by one until now, which is why
-    // a field whose tiles all fall back (the bench's per-pixel noise) had dropped from the pair kernel's 44 us to 55 us.
-    typedef float float2_t __attribute__((ext_vector_type(2), aligned(4)));
-#pragma unroll
-    for (int k = 0; k < kRsPPT; ++k) {
-      const int y = ty0 + k * 4 + wave;
-      if (x < W && y < H) {
-        const int xb = xL[k] < W - 2 ? xL[k] : W - 2;       // pair [xb, xb + 1] holds columns xL and xR
+      } else {
+        const int xb = xL[k] < W - 2 ? xL[k] : W - 2;
         const bool l1 = xL[k] != xb, r1 = xR[k] != xb;
-        float2_t t[C], u[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const float* p = in1 + ((size_t)b * C + c) * HW;
-          t[c] = *reinterpret_cast<const float2_t*>(p + (size_t)yT[k] * W + xb);
-          u[c] = *reinterpret_cast<const float2_t*>(p + (size_t)yB[k] * W + xb);
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          float v = w00[k] * (l1 ? t[c][1] : t[c][0]);
-          v += w01[k] * (r1 ? t[c][1] : t[c][0]);
-          v += w10[k] * (l1 ? u[c][1] : u[c][0]);
-          v += w11[k] * (r1 ? u[c][1] : u[c][0]);
-          out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
+          tL[c] = l1 ? gt[k][c][1] : gt[k][c][0]; tR[c] = r1 ? gt[k][c][1] : gt[k][c][0];
+          uL[c] = l1 ? gu[k][c][1] : gu[k][c][0]; uR[c] = r1 ? gu[k][c][1] : gu[k][c][0];
         }
       }
-    }
-  } else {
 #pragma unroll
-    for (int k = 0; k < kRsPPT; ++k) {
-      const int y = ty0 + k * 4 + wave;
-      if (x < W && y < H) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float* p = in1 + ((size_t)b * C + c) * HW;
-          float v = w00[k] * p[(size_t)yT[k] * W + xL[k]];
-          v += w01[k] * p[(size_t)yT[k] * W + xR[k]];
-          v += w10[k] * p[(size_t)yB[k] * W + xL[k]];
-          v += w11[k] * p[(size_t)yB[k] * W + xR[k]];
-          out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
-        }
+      for (int c = 0; c < C; ++c) {
+        float v = w00[k] * tL[c];
+        v += w01[k] * tR[c];
+        v += w10[k] * uL[c];
+        v += w11[k] * uR[c];
+        out[((size_t)b * C + c) * HW + (size_t)y * W + x] = v;
       }
     }
   }
@@ -1402,7 +1425,7 @@ extern "C" int ft_resample2d_fwd(const float* in1, const float* flow, float* out
   const size_t total = (size_t)B * H * W;
   static const bool no_window = getenv("FT_RESAMPLE_WINDOW") && atoi(getenv("FT_RESAMPLE_WINDOW")) == 0;   // dev A/B: the gather kernels
   const unsigned long long in_bytes = (unsigned long long)B * C * H * W * 4ull;
-  if (!no_window && C >= 1 && C <= 4 && W >= 1 && in_bytes < (1ull << 31)) {
+  if (!no_window && C >= 1 && C <= 4 && W >= 2 && in_bytes < (1ull << 31)) {
     const int tiles_x = ceil_div(W, kRsTW), tiles_y = ceil_div(H, kRsTH);
     const long long nblk = (long long)B * tiles_x * tiles_y;
     if (nblk <= 0x7fffffffLL) {
@@ -1413,9 +1436,13 @@ extern "C" int ft_resample2d_fwd(const float* in1, const float* flow, float* out
       //   budget 6656 (26 KiB per plane, 2 workgroups per CU): noise 45.5 us, smooth 39.7 us
       //   budget 3328 (13 KiB, 4 per CU):                      noise 56.4 us (every tile falls back), smooth 32.3 us
       //   budget 2304 / 1536:                                   noise 55.8 / 55.1, smooth 35.6 / 37.0
-      // Flow fields that reach this operator are network outputs (smooth): 3328 is the default.
+      // Flow fields that reach this operator are network outputs (smooth): 3328 was the default of round 5.
+      // Round 6 (clipped windows: a tile whose box does not fit keeps a window around itself and gathers only the pixels outside it),
+      // same box, noise / smooth: budget 1536: 45.2 / 32.0 us, 1792: 37.5 / 29.9, 2048: 37.0 / 30.0, 2304: 36.3 / 29.4,
+      // 2560: 35.3 / 29.4 (five workgroups per CU), 2816: 37.4 / 31.3, 3072: 36.8 / 31.9, 4096: 38.8 / 33.0, 6656: 47.2 / 40.2;
+      // clip pitch 80 / 96 / 112 / 128 floats at 2560: 34.0 / 34.8-35.0 / 34.8 / 34.6 us noise, 28.0-28.7 smooth.  2560 is the default.
       static const int wb_env = getenv("FT_RESAMPLE_WBUDGET") ? atoi(getenv("FT_RESAMPLE_WBUDGET")) : 0;
-      const int wbudget = wb_env >= 256 && wb_env <= kRsMaxWindow ? (wb_env & ~255) : 3328;
+      const int wbudget = wb_env >= 256 && wb_env <= kRsMaxWindow ? (wb_env & ~255) : 2560;
       const size_t lds = (size_t)C * wbudget * sizeof(float);
 #define FT_RS_LAUNCH(CC)                                                                                                   \
   {                                                                                                                        \

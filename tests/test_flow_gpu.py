@@ -162,13 +162,17 @@ def test_resample2d_and_channelnorm(hip_lib, oracle_lib):
 
 def test_resample2d_window_kernel_paths(hip_lib, oracle_lib):
     """The LDS-window form of Resample2d (16 x 64 tiles, csrc/flow_ops.hip): ragged maps with several tiles in both directions;
-    incoherent per-pixel flows (sigma 4 px: every tile's tap window fits LDS), one image whose flow spreads over the whole map
-    (window too large: that tile's direct gathers), far out-of-frame flows (border clamp without renormalisation,
+    incoherent per-pixel flows (sigma 4 px: clipped windows + gathers for the pixels outside), one image whose flow spreads over the
+    whole map (no window: every pixel gathers), far out-of-frame flows (border clamp without renormalisation,
     Resample2d_kernel.cu:42-59), 1..4 channels."""
-    for (B, C, H, W) in ((3, 3, 70, 150), (2, 4, 33, 200), (2, 1, 16, 64), (1, 2, 50, 65)):
+    for (B, C, H, W) in ((3, 3, 70, 150), (2, 4, 33, 200), (2, 1, 16, 64), (1, 2, 50, 65), (3, 3, 96, 256)):
         img = synth.normal(8, f"img{C}{W}", (B, C, H, W)).numpy()
         flow = (synth.normal(8, f"flow{C}{W}", (B, 2, H, W)) * 4.0).numpy()
-        flow[B - 1] = (synth.normal(9, f"wide{C}{W}", (2, H, W)) * 60.0).numpy()       # spread >> tile: the fallback branch
+        # round 6: a box that does not fit LDS keeps a window CLIPPED around the tile, pixels outside it gather: sigma 4 px at the
+        # default budget is that case (both piece sizes: W % 4 == 0 and not); a sprinkle of 10-25 px vectors lands outside the clip
+        far = synth.uniform(10, f"far{C}{W}", (B, 1, H, W), 0.0, 1.0).numpy() < 0.03
+        flow = np.where(far, flow * 5.0, flow).astype(np.float32)
+        flow[B - 1] = (synth.normal(9, f"wide{C}{W}", (2, H, W)) * 60.0).numpy()       # spread >> four windows: no window, every pixel gathers
         flow[0, :, 0, 0] = (-1000.0, 2500.0)
         flow[0, :, H - 1, W - 1] = (1e9, -1e9)
         want = ops_ref.resample2d_c(img, flow)
