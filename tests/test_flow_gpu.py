@@ -80,6 +80,31 @@ def test_correlation_nhwc_fused(hip_lib, oracle_lib, dtype, shape):
     assert torch.all(y[..., :32] == 5.0) and torch.all(y[..., 473:] == 5.0)
 
 
+def test_correlation_rows_kernel_is_deterministic_under_memory_load(hip_lib):
+    """The matrix-core correlation orders its look-ahead ring rows and band stores by hand-counted vmcnt waits alone (round 6: the
+    compiler's hidden per-step queue drains are gone): 60 launches at FlowNetC's shape [16,256,48,64] and a ragged one, the second
+    half with another stream streaming through HBM, must all equal the first bit for bit (tools/dev/corr_stress.py: the long form)."""
+    for (B, H, W) in ((16, 48, 64), (3, 47, 61)):
+        f = (synth.normal(6, f"corr_det{H}", (2 * B, H, W, 256)) * 1.0).to("cuda", torch.float16)
+        y = torch.zeros((B, H, W, 480), dtype=torch.float16, device="cuda")
+
+        def run():
+            check(hip_lib.ft_correlation_nhwc_fwd(f[:B].data_ptr(), f[B:].data_ptr(), y.data_ptr(), B, 256, H, W, 20, 2, 256, 480, 32,
+                                                  _lib.FT_ACT_LEAKY, 0.1, _lib.FT_F16, _stream()))
+        run()
+        torch.cuda.synchronize()
+        ref = y[..., 32:473].clone()
+        side, junk = torch.cuda.Stream(), torch.empty((128 << 20,), dtype=torch.uint8, device="cuda")
+        for it in range(60):
+            if it >= 30:
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            y.fill_(3.0)
+            run()
+            torch.cuda.synchronize()
+            assert torch.equal(y[..., 32:473], ref), (B, H, W, it)
+
+
 def test_correlation_impulse_known_answers_gpu(hip_lib):
     """The hand-derived impulse responses (tests/golden/correlation_kat.npz) through the C ABI: the reference-API kernel on
     every case, the in-network NHWC kernels (fp32 VALU form and the fp16 matrix-core forms) where their fixed parameters
